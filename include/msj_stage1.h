@@ -1,0 +1,184 @@
+/*
+ * msj_stage1.h -- C ABI of the MI355X-native stage-1 JSON structural indexer.
+ *
+ * This is the drop-in boundary for ONE path of gabrieldemarmiesse/mojo-simdjson:
+ * the call
+ *     JsonStructuralIndexer.index[128](buffer, self)
+ * made by DomParserImplementation.stage1(Span[UInt8])
+ * (reference: src/mojo_simdjson/include/generic/dom_parser_implementation.mojo:65-69,
+ *  callee src/mojo_simdjson/generic/stage1/json_structural_indexer.mojo:81-108,147-186).
+ * The reference has no FFI of its own (it is a plain Mojo static-method call);
+ * the entry points below are what a Mojo `sys.ffi.DLHandle` binding for that
+ * call site binds (INTEGRATION.md shows the shim).  Plain pointers and sizes
+ * only; no torch / HIP types appear in any signature (`stream` is an opaque
+ * hipStream_t passed as void*).
+ *
+ * Contract left behind by a successful call (what stage 2 reads,
+ * generic/stage2/json_iterator.mojo:28-38,256-288, and what the reference's
+ * own test asserts, tests/test_stage_1.mojo:43-82):
+ *   idx[0..n)   strictly increasing uint32 byte offsets of structural starts
+ *   idx[n]   = (uint32) len      \
+ *   idx[n+1] = (uint32) len       } json_structural_indexer.mojo:167-173
+ *   idx[n+2] = 0                 /
+ *   *n_out   = n                   (parser.n_structural_indexes, :160-165)
+ * Return value: the reference's integer error code (errors.mojo:2-36):
+ *   0 SUCCESS, 1 CAPACITY, 13 EMPTY, 14 UNESCAPED_CHARS, 15 UNCLOSED_STRING,
+ *   24 UNEXPECTED_ERROR; 11 UTF8_ERROR only when MSJ_FLAG_STRICT_UTF8 is set
+ *   (the reference's UTF-8 checker is an empty stub that always succeeds,
+ *   json_structural_indexer.mojo:16-30, so reference parity ignores UTF-8).
+ * Error precedence follows finish() (:147-186): 15, then 14, then (trailer
+ * written) 13, then 11.  On 14/15 the reference returns before writing n and
+ * the trailer; the host-pointer entry points do the same (n_out untouched).
+ *
+ * Capacity: the reference allocates exactly `len` slots (allocate(len),
+ * dom_parser_implementation.mojo:85-89) but writes up to n+3 <= len+3 words.
+ * Callers of this ABI must provide idx_capacity >= n + 3; len + 3 is always
+ * enough.  A smaller buffer is accepted: writes are clipped and CAPACITY (1)
+ * is returned if n + 3 > idx_capacity.
+ *
+ * HIP backend only: every entry point fails with MSJ_ERR_NO_DEVICE (-2) when no
+ * gfx950 device / HIP runtime is usable.  There is no CPU fallback.
+ */
+#ifndef MSJ_STAGE1_H
+#define MSJ_STAGE1_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* reference error codes, src/mojo_simdjson/errors.mojo:2-26 */
+#define MSJ_SUCCESS 0
+#define MSJ_CAPACITY 1
+#define MSJ_MEMALLOC 2
+#define MSJ_UTF8_ERROR 11
+#define MSJ_EMPTY 13
+#define MSJ_UNESCAPED_CHARS 14
+#define MSJ_UNCLOSED_STRING 15
+#define MSJ_UNEXPECTED_ERROR 24
+/* library-level failures (negative: never collide with reference codes) */
+#define MSJ_ERR_BAD_ARGUMENT (-1)
+#define MSJ_ERR_NO_DEVICE (-2)
+#define MSJ_ERR_HIP (-3)
+
+/* flags */
+#define MSJ_FLAG_STRICT_UTF8 1u /* return 11 when the input is not valid UTF-8 */
+#define MSJ_FLAG_NO_UTF8 2u     /* skip UTF-8 validation entirely (verdict = 0) */
+
+/* SIMDJSON_MAXSIZE_BYTES, src/mojo_simdjson/include/base.mojo:2: indices are
+ * uint32, so one segment of input is limited to this many bytes. */
+#define MSJ_MAX_SEGMENT_BYTES 0xFFFFFFFFull
+
+/*
+ * Carry state at a byte boundary of the input stream: everything the
+ * reference's scanners carry from one 64-byte block to the next
+ * (JsonEscapeScanner.next_is_escaped json_escape_scanner.mojo:13,
+ *  JsonStringScanner.prev_in_string json_string_scanner.mojo:49,
+ *  JsonScanner.prev_scalar json_scanner.mojo:57,
+ *  JsonStructuralIndexer.unescaped_chars_error json_structural_indexer.mojo:72,
+ *  BitIndexer.tail :34) plus the UTF-8 verdict so far.  Lives in device
+ * memory; 64 bytes.
+ */
+typedef struct msj_carry {
+    uint64_t count;           /* structurals emitted so far (BitIndexer.tail - base) */
+    uint64_t bytes;           /* input bytes consumed so far */
+    uint32_t in_string;       /* 1 = inside a string (prev_in_string != 0) */
+    uint32_t next_is_escaped; /* 1 = next byte is escaped */
+    uint32_t prev_scalar;     /* 1 = previous byte was a non-quote scalar */
+    uint32_t unescaped_error; /* sticky: control char seen inside a string */
+    uint32_t utf8_error;      /* sticky: invalid UTF-8 seen */
+    uint32_t internal_error;  /* sticky: look-back timeout / capacity clip */
+    int32_t code;             /* reference return code, valid after a FINAL segment */
+    uint32_t reserved[5];
+} msj_carry;
+
+/* One <= 4 GiB piece of a larger input: offsets in
+ * idx[index_begin .. index_begin+count) are relative to byte_base. */
+typedef struct msj_segment {
+    uint64_t byte_base;
+    uint64_t byte_len;
+    uint64_t index_begin;
+    uint64_t count;
+} msj_segment;
+
+typedef struct msj_ctx msj_ctx;
+
+/* Library / device probes.  msj_device_count() returns the number of HIP
+ * devices (0 when none or no runtime); never initialises a context. */
+int32_t msj_device_count(void);
+const char *msj_version(void);
+
+/* Context: owns the per-device workspace (tile descriptors, carry structs,
+ * staging buffers).  Not re-entrant: one in-flight call per context, matching
+ * the reference (one parser = one synchronous call). */
+int32_t msj_ctx_create(int32_t device, msj_ctx **out);
+void msj_ctx_destroy(msj_ctx *ctx);
+
+/*
+ * msj_stage1 -- host-pointer form; replaces
+ *   JsonStructuralIndexer.index[128](buffer, self)   (json_structural_indexer.mojo:81-108)
+ * `buf`/`idx_out` are host memory; the library copies the input to the device,
+ * runs the HIP kernels, and copies back idx[0..n+3).  Uses a process-wide
+ * default context on device 0 (created on first use).
+ * utf8_verdict_out (optional): 0 valid, 11 invalid -- reported separately from
+ * the return code unless MSJ_FLAG_STRICT_UTF8.
+ */
+int32_t msj_stage1(const uint8_t *buf, uint64_t len, uint32_t *idx_out, uint64_t idx_capacity,
+                   uint64_t *n_out, int32_t *utf8_verdict_out, uint32_t flags);
+
+/* Same, on an explicit context. */
+int32_t msj_stage1_ctx(msj_ctx *ctx, const uint8_t *buf, uint64_t len, uint32_t *idx_out,
+                       uint64_t idx_capacity, uint64_t *n_out, int32_t *utf8_verdict_out,
+                       uint32_t flags);
+
+/*
+ * msj_stage1_device -- device-resident form (what bench.py times).
+ * d_buf: device pointer, 16-byte aligned, len < 2^32 bytes.
+ * d_idx: device pointer to idx_capacity uint32 slots.
+ * d_result: device pointer to one msj_carry; after the stream drains it holds
+ *   count (= n), code (reference return code), utf8_error, ...
+ * Enqueues on `stream` (hipStream_t as void*, NULL = default stream) and
+ * returns immediately; the return value only reports argument / launch errors.
+ */
+int32_t msj_stage1_device(msj_ctx *ctx, const uint8_t *d_buf, uint64_t len, uint32_t *d_idx,
+                          uint64_t idx_capacity, msj_carry *d_result, void *stream,
+                          uint32_t flags);
+
+/* Blocking read-back of a device msj_carry (synchronises `stream`). */
+int32_t msj_carry_fetch(msj_ctx *ctx, const msj_carry *d_carry, msj_carry *host_out, void *stream);
+
+/*
+ * msj_stage1_shard_device -- one byte-range shard of a larger stream
+ * (multi-GPU sharding and > 4 GiB inputs).
+ * The shard is cut into <= MSJ_MAX_SEGMENT_BYTES segments; indices are written
+ * densely to d_idx (relative to each segment's byte_base, see msj_segment) and
+ * the segment table to d_segments (device, max_segments entries; count is
+ * filled in on the device).
+ *   d_carry_in : device msj_carry with the exact state at the shard's first
+ *                byte (zeroed for the start of the document).
+ *   d_carry_out: device msj_carry receiving the state after the last byte.
+ *   has_prefix : non-zero when d_buf[-64..0) is readable and holds the 64
+ *                stream bytes preceding the shard (used for the UTF-8
+ *                continuation check across the shard boundary).
+ *   is_final   : non-zero for the last shard of the stream: writes the trailer
+ *                (with trailer_len) and the reference return code into
+ *                d_carry_out->code.
+ *   no_emit    : non-zero = summary pass only (no index writes): used to get
+ *                the shard's quote parity before the RCCL stitch.
+ * *n_segments_out receives the number of segments used.
+ */
+int32_t msj_stage1_shard_device(msj_ctx *ctx, const uint8_t *d_buf, uint64_t len, uint32_t *d_idx,
+                                uint64_t idx_capacity, const msj_carry *d_carry_in,
+                                msj_carry *d_carry_out, msj_segment *d_segments,
+                                uint32_t max_segments, uint32_t *n_segments_out,
+                                int32_t has_prefix, int32_t is_final, int32_t no_emit,
+                                uint64_t trailer_len, void *stream, uint32_t flags);
+
+/* Tile geometry (for roofline bookkeeping and tests). */
+uint32_t msj_tile_bytes(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MSJ_STAGE1_H */

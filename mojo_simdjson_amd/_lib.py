@@ -1,0 +1,105 @@
+"""ctypes binding of ``libmsj_stage1.so`` (the C ABI in ``include/msj_stage1.h``).
+
+The HIP extension is the only implementation behind this package: if the shared
+library is missing, or no HIP device is usable, calls raise -- there is no CPU
+fallback of any kind.
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libmsj_stage1.so")
+GEN_LIB_PATH = os.path.join(_HERE, "libmsj_gen.so")
+
+
+class MsjCarry(ctypes.Structure):
+    """``msj_carry`` (include/msj_stage1.h): the scanners' cross-block state."""
+
+    _fields_ = [
+        ("count", ctypes.c_uint64),
+        ("bytes", ctypes.c_uint64),
+        ("in_string", ctypes.c_uint32),
+        ("next_is_escaped", ctypes.c_uint32),
+        ("prev_scalar", ctypes.c_uint32),
+        ("unescaped_error", ctypes.c_uint32),
+        ("utf8_error", ctypes.c_uint32),
+        ("internal_error", ctypes.c_uint32),
+        ("code", ctypes.c_int32),
+        ("reserved", ctypes.c_uint32 * 5),
+    ]
+
+
+class MsjSegment(ctypes.Structure):
+    _fields_ = [
+        ("byte_base", ctypes.c_uint64),
+        ("byte_len", ctypes.c_uint64),
+        ("index_begin", ctypes.c_uint64),
+        ("count", ctypes.c_uint64),
+    ]
+
+
+assert ctypes.sizeof(MsjCarry) == 64
+assert ctypes.sizeof(MsjSegment) == 32
+
+_lib = None
+
+
+class HipExtensionMissing(RuntimeError):
+    pass
+
+
+def load():
+    """Load libmsj_stage1.so once; raise loudly if it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise HipExtensionMissing(
+            f"{LIB_PATH} not found: build the HIP extension first "
+            "(python -c 'import __graft_entry__ as g; g.build()' or make -C mojo_simdjson_amd/csrc)"
+        )
+    lib = ctypes.CDLL(LIB_PATH)
+    u8p, u32p, u64p = ctypes.c_void_p, ctypes.c_void_p, ctypes.POINTER(ctypes.c_uint64)
+    i32p = ctypes.POINTER(ctypes.c_int32)
+    lib.msj_version.restype = ctypes.c_char_p
+    lib.msj_version.argtypes = []
+    lib.msj_device_count.restype = ctypes.c_int32
+    lib.msj_device_count.argtypes = []
+    lib.msj_tile_bytes.restype = ctypes.c_uint32
+    lib.msj_tile_bytes.argtypes = []
+    lib.msj_ctx_create.restype = ctypes.c_int32
+    lib.msj_ctx_create.argtypes = [ctypes.c_int32, ctypes.POINTER(ctypes.c_void_p)]
+    lib.msj_ctx_destroy.restype = None
+    lib.msj_ctx_destroy.argtypes = [ctypes.c_void_p]
+    lib.msj_stage1.restype = ctypes.c_int32
+    lib.msj_stage1.argtypes = [u8p, ctypes.c_uint64, u32p, ctypes.c_uint64, u64p, i32p, ctypes.c_uint32]
+    lib.msj_stage1_ctx.restype = ctypes.c_int32
+    lib.msj_stage1_ctx.argtypes = [ctypes.c_void_p] + lib.msj_stage1.argtypes
+    lib.msj_stage1_device.restype = ctypes.c_int32
+    lib.msj_stage1_device.argtypes = [
+        ctypes.c_void_p, u8p, ctypes.c_uint64, u32p, ctypes.c_uint64, ctypes.c_void_p,
+        ctypes.c_void_p, ctypes.c_uint32,
+    ]
+    lib.msj_carry_fetch.restype = ctypes.c_int32
+    lib.msj_carry_fetch.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.POINTER(MsjCarry), ctypes.c_void_p]
+    lib.msj_stage1_shard_device.restype = ctypes.c_int32
+    lib.msj_stage1_shard_device.argtypes = [
+        ctypes.c_void_p, u8p, ctypes.c_uint64, u32p, ctypes.c_uint64, ctypes.c_void_p,
+        ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint32, ctypes.POINTER(ctypes.c_uint32),
+        ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_uint64, ctypes.c_void_p,
+        ctypes.c_uint32,
+    ]
+    _lib = lib
+    return lib
+
+
+def load_gen():
+    if not os.path.exists(GEN_LIB_PATH):
+        raise HipExtensionMissing(f"{GEN_LIB_PATH} not found: run __graft_entry__.build()")
+    g = ctypes.CDLL(GEN_LIB_PATH)
+    g.msj_gen_unit.restype = ctypes.c_uint64
+    g.msj_gen_unit.argtypes = [ctypes.c_void_p, ctypes.c_uint64, ctypes.c_uint64, ctypes.c_uint64,
+                               ctypes.c_int, ctypes.c_int, ctypes.c_int]
+    g.msj_gen_extreme.restype = ctypes.c_uint64
+    g.msj_gen_extreme.argtypes = [ctypes.c_void_p, ctypes.c_uint64, ctypes.c_int]
+    return g

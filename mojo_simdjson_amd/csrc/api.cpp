@@ -1,0 +1,242 @@
+// api.cpp -- extern "C" entry points declared in include/msj_stage1.h.
+//
+// Host-side counterpart of DomParserImplementation.stage1 / allocate
+// (src/mojo_simdjson/include/generic/dom_parser_implementation.mojo:59-69,85-89):
+// argument checks, workspace management and kernel launches.  There is no CPU
+// implementation behind this ABI: without a usable HIP device every entry
+// point returns MSJ_ERR_NO_DEVICE.
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstring>
+#include <mutex>
+#include <new>
+
+#include "../../include/msj_stage1.h"
+#include "stage1_kernel.h"
+
+struct msj_ctx {
+    int device = 0;
+    uint64_t *ws = nullptr;       // tile ticket + descriptors
+    uint64_t ws_words = 0;
+    msj_carry *carries = nullptr; // [0] = zero carry, [1..] chained segment carries
+    uint32_t n_carries = 0;
+    // staging for the host-pointer entry points
+    uint8_t *d_in = nullptr;
+    uint64_t d_in_bytes = 0;
+    uint32_t *d_idx = nullptr;
+    uint64_t d_idx_words = 0;
+    msj_carry *d_result = nullptr;
+};
+
+namespace {
+
+constexpr uint32_t kMaxChain = 64;  // segments per shard call (64 x ~4 GiB)
+
+bool hip_ok(hipError_t e) { return e == hipSuccess; }
+
+int32_t ensure_workspace(msj_ctx *ctx, uint32_t ntiles) {
+    const uint64_t need = msj::workspace_words(ntiles);
+    if (need <= ctx->ws_words) return MSJ_SUCCESS;
+    if (ctx->ws) (void)hipFree(ctx->ws);
+    ctx->ws = nullptr;
+    ctx->ws_words = 0;
+    // grow with head-room so repeated calls of similar size do not re-allocate
+    const uint64_t words = need + need / 4 + 64;
+    if (!hip_ok(hipMalloc(reinterpret_cast<void **>(&ctx->ws), words * sizeof(uint64_t))))
+        return MSJ_MEMALLOC;
+    ctx->ws_words = words;
+    return MSJ_SUCCESS;
+}
+
+// Enqueue the kernels for one shard: a chain of <= kSegmentBytes launches whose
+// carry structs stay in device memory (no host synchronisation in between).
+int32_t enqueue_shard(msj_ctx *ctx, const uint8_t *d_buf, uint64_t len, uint32_t *d_idx,
+                      uint64_t idx_capacity, const msj_carry *d_carry_in, msj_carry *d_carry_out,
+                      msj_segment *d_segments, uint32_t max_segments, uint32_t *n_segments_out,
+                      bool has_prefix, bool is_final, bool no_emit, uint64_t trailer_len,
+                      hipStream_t stream, uint32_t flags) {
+    if (!ctx || !d_buf || !d_carry_in || !d_carry_out || len == 0) return MSJ_ERR_BAD_ARGUMENT;
+    if ((reinterpret_cast<uintptr_t>(d_buf) & 15u) != 0) return MSJ_ERR_BAD_ARGUMENT;
+    if (!no_emit && !d_idx) return MSJ_ERR_BAD_ARGUMENT;
+    const uint64_t nseg = (len + msj::kSegmentBytes - 1) / msj::kSegmentBytes;
+    if (nseg > kMaxChain) return MSJ_CAPACITY;
+    if (d_segments && nseg > max_segments) return MSJ_CAPACITY;
+    if (!hip_ok(hipSetDevice(ctx->device))) return MSJ_ERR_HIP;
+
+    const uint64_t first_len = len < msj::kSegmentBytes ? len : msj::kSegmentBytes;
+    const uint32_t max_tiles = (uint32_t)((first_len + msj::kTileBytes - 1) / msj::kTileBytes);
+    int32_t rc = ensure_workspace(ctx, max_tiles);
+    if (rc != MSJ_SUCCESS) return rc;
+
+    for (uint64_t s = 0; s < nseg; s++) {
+        const uint64_t base = s * msj::kSegmentBytes;
+        const uint64_t seg_len = (len - base) < msj::kSegmentBytes ? (len - base) : msj::kSegmentBytes;
+        msj::KernelArgs a;
+        a.buf = d_buf + base;
+        a.len = seg_len;
+        a.idx = d_idx;
+        a.capacity = idx_capacity;
+        a.ws = ctx->ws;
+        a.carry_in = (s == 0) ? d_carry_in : &ctx->carries[s];
+        a.carry_out = (s + 1 == nseg) ? d_carry_out : &ctx->carries[s + 1];
+        a.segment = d_segments ? &d_segments[s] : nullptr;
+        a.segment_byte_base = base;
+        a.trailer_len = trailer_len;
+        a.ntiles = (uint32_t)((seg_len + msj::kTileBytes - 1) / msj::kTileBytes);
+        a.flags = flags & (msj::kFlagStrictUtf8 | msj::kFlagNoUtf8);
+        if (is_final && s + 1 == nseg) a.flags |= msj::kFlagFinal;
+        if (has_prefix || s > 0) a.flags |= msj::kFlagHasPrefix;
+        if (no_emit) a.flags |= msj::kFlagNoEmit;
+        // ticket + descriptors must read as "not ready" at launch
+        if (!hip_ok(hipMemsetAsync(ctx->ws, 0, msj::workspace_words(a.ntiles) * sizeof(uint64_t),
+                                   stream)))
+            return MSJ_ERR_HIP;
+        if (msj_launch_stage1(&a, stream) != 0) return MSJ_ERR_HIP;
+    }
+    if (n_segments_out) *n_segments_out = (uint32_t)nseg;
+    return MSJ_SUCCESS;
+}
+
+std::mutex g_default_mutex;
+msj_ctx *g_default_ctx = nullptr;
+
+}  // namespace
+
+extern "C" {
+
+const char *msj_version(void) { return "mojo-simdjson_amd stage1 0.1 (gfx950)"; }
+
+uint32_t msj_tile_bytes(void) { return msj::kTileBytes; }
+
+int32_t msj_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+int32_t msj_ctx_create(int32_t device, msj_ctx **out) {
+    if (!out) return MSJ_ERR_BAD_ARGUMENT;
+    *out = nullptr;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return MSJ_ERR_NO_DEVICE;
+    if (device < 0 || device >= n) return MSJ_ERR_BAD_ARGUMENT;
+    if (!hip_ok(hipSetDevice(device))) return MSJ_ERR_HIP;
+    msj_ctx *ctx = new (std::nothrow) msj_ctx();
+    if (!ctx) return MSJ_MEMALLOC;
+    ctx->device = device;
+    ctx->n_carries = kMaxChain + 2;
+    if (!hip_ok(hipMalloc(reinterpret_cast<void **>(&ctx->carries),
+                          ctx->n_carries * sizeof(msj_carry))) ||
+        !hip_ok(hipMemset(ctx->carries, 0, ctx->n_carries * sizeof(msj_carry))) ||
+        !hip_ok(hipMalloc(reinterpret_cast<void **>(&ctx->d_result), sizeof(msj_carry)))) {
+        msj_ctx_destroy(ctx);
+        return MSJ_MEMALLOC;
+    }
+    *out = ctx;
+    return MSJ_SUCCESS;
+}
+
+void msj_ctx_destroy(msj_ctx *ctx) {
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    if (ctx->ws) (void)hipFree(ctx->ws);
+    if (ctx->carries) (void)hipFree(ctx->carries);
+    if (ctx->d_in) (void)hipFree(ctx->d_in);
+    if (ctx->d_idx) (void)hipFree(ctx->d_idx);
+    if (ctx->d_result) (void)hipFree(ctx->d_result);
+    delete ctx;
+}
+
+int32_t msj_stage1_device(msj_ctx *ctx, const uint8_t *d_buf, uint64_t len, uint32_t *d_idx,
+                          uint64_t idx_capacity, msj_carry *d_result, void *stream,
+                          uint32_t flags) {
+    if (!ctx || !d_result) return MSJ_ERR_BAD_ARGUMENT;
+    if (len == 0) return MSJ_EMPTY;  // json_structural_indexer.mojo:91-92
+    if (len > MSJ_MAX_SEGMENT_BYTES) return MSJ_CAPACITY;  // include/base.mojo:2
+    // carries[0] is the all-zero state at the start of a document (:74-79)
+    return enqueue_shard(ctx, d_buf, len, d_idx, idx_capacity, &ctx->carries[0], d_result, nullptr,
+                         0, nullptr, false, true, false, len, static_cast<hipStream_t>(stream),
+                         flags);
+}
+
+int32_t msj_stage1_shard_device(msj_ctx *ctx, const uint8_t *d_buf, uint64_t len, uint32_t *d_idx,
+                                uint64_t idx_capacity, const msj_carry *d_carry_in,
+                                msj_carry *d_carry_out, msj_segment *d_segments,
+                                uint32_t max_segments, uint32_t *n_segments_out,
+                                int32_t has_prefix, int32_t is_final, int32_t no_emit,
+                                uint64_t trailer_len, void *stream, uint32_t flags) {
+    return enqueue_shard(ctx, d_buf, len, d_idx, idx_capacity, d_carry_in, d_carry_out, d_segments,
+                         max_segments, n_segments_out, has_prefix != 0, is_final != 0, no_emit != 0,
+                         trailer_len, static_cast<hipStream_t>(stream), flags);
+}
+
+int32_t msj_carry_fetch(msj_ctx *ctx, const msj_carry *d_carry, msj_carry *host_out, void *stream) {
+    if (!ctx || !d_carry || !host_out) return MSJ_ERR_BAD_ARGUMENT;
+    if (!hip_ok(hipSetDevice(ctx->device))) return MSJ_ERR_HIP;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (!hip_ok(hipMemcpyAsync(host_out, d_carry, sizeof(msj_carry), hipMemcpyDeviceToHost, s)))
+        return MSJ_ERR_HIP;
+    if (!hip_ok(hipStreamSynchronize(s))) return MSJ_ERR_HIP;
+    return MSJ_SUCCESS;
+}
+
+int32_t msj_stage1_ctx(msj_ctx *ctx, const uint8_t *buf, uint64_t len, uint32_t *idx_out,
+                       uint64_t idx_capacity, uint64_t *n_out, int32_t *utf8_verdict_out,
+                       uint32_t flags) {
+    if (!ctx) return MSJ_ERR_BAD_ARGUMENT;
+    if (len == 0) return MSJ_EMPTY;  // json_structural_indexer.mojo:91-92
+    if (!buf || !idx_out || !n_out) return MSJ_ERR_BAD_ARGUMENT;
+    if (len > MSJ_MAX_SEGMENT_BYTES) return MSJ_CAPACITY;
+    if (!hip_ok(hipSetDevice(ctx->device))) return MSJ_ERR_HIP;
+
+    // device staging (the reference's allocate(len), dom_parser_implementation.mojo:85-89)
+    const uint64_t in_bytes = (len + 63u) & ~63ull;
+    if (in_bytes > ctx->d_in_bytes) {
+        if (ctx->d_in) (void)hipFree(ctx->d_in);
+        ctx->d_in = nullptr;
+        ctx->d_in_bytes = 0;
+        if (!hip_ok(hipMalloc(reinterpret_cast<void **>(&ctx->d_in), in_bytes))) return MSJ_MEMALLOC;
+        ctx->d_in_bytes = in_bytes;
+    }
+    const uint64_t dev_cap = idx_capacity < len + 3 ? idx_capacity : len + 3;
+    if (dev_cap > ctx->d_idx_words) {
+        if (ctx->d_idx) (void)hipFree(ctx->d_idx);
+        ctx->d_idx = nullptr;
+        ctx->d_idx_words = 0;
+        if (!hip_ok(hipMalloc(reinterpret_cast<void **>(&ctx->d_idx), dev_cap * sizeof(uint32_t))))
+            return MSJ_MEMALLOC;
+        ctx->d_idx_words = dev_cap;
+    }
+    if (!hip_ok(hipMemcpy(ctx->d_in, buf, len, hipMemcpyHostToDevice))) return MSJ_ERR_HIP;
+    int32_t rc = msj_stage1_device(ctx, ctx->d_in, len, ctx->d_idx, dev_cap, ctx->d_result, nullptr,
+                                   flags);
+    if (rc != MSJ_SUCCESS) return rc;
+    msj_carry res;
+    rc = msj_carry_fetch(ctx, ctx->d_result, &res, nullptr);
+    if (rc != MSJ_SUCCESS) return rc;
+    if (utf8_verdict_out) *utf8_verdict_out = res.utf8_error ? MSJ_UTF8_ERROR : MSJ_SUCCESS;
+    // On UNCLOSED_STRING / UNESCAPED_CHARS the reference returns before it sets
+    // n_structural_indexes or the trailer (json_structural_indexer.mojo:151-158).
+    if (res.code == MSJ_UNCLOSED_STRING || res.code == MSJ_UNESCAPED_CHARS ||
+        res.code == MSJ_UNEXPECTED_ERROR || res.code == MSJ_CAPACITY)
+        return res.code;
+    const uint64_t n = res.count;
+    if (!hip_ok(hipMemcpy(idx_out, ctx->d_idx, (n + 3) * sizeof(uint32_t), hipMemcpyDeviceToHost)))
+        return MSJ_ERR_HIP;
+    *n_out = n;
+    return res.code;
+}
+
+int32_t msj_stage1(const uint8_t *buf, uint64_t len, uint32_t *idx_out, uint64_t idx_capacity,
+                   uint64_t *n_out, int32_t *utf8_verdict_out, uint32_t flags) {
+    std::lock_guard<std::mutex> lock(g_default_mutex);
+    if (!g_default_ctx) {
+        const int32_t rc = msj_ctx_create(0, &g_default_ctx);
+        if (rc != MSJ_SUCCESS) return rc;
+    }
+    return msj_stage1_ctx(g_default_ctx, buf, len, idx_out, idx_capacity, n_out, utf8_verdict_out,
+                          flags);
+}
+
+}  // extern "C"

@@ -1,0 +1,279 @@
+// lane_math.h -- per-lane math of the stage-1 kernel.
+//
+// One GPU lane owns one 64-byte block of input, i.e. exactly the unit the
+// reference processes per JsonScanner.next call
+// (generic/stage1/json_structural_indexer.mojo:116-126), and every mask below
+// is a uint64 with bit i <-> byte i of the block, LSB = lowest address: the
+// same convention as the reference's pack_bits masks (stuff.mojo:6-9).
+//
+// Instead of per-character compares (the reference's eq[]/classify,
+// stuff.mojo:6-9, haswell.mojo:22-74) the block is bit-transposed into its
+// eight bit-planes (b0..b7, 64 bits each) with a SWAR butterfly + v_perm byte
+// gather (~3 VALU ops per input byte), after which every character class and
+// the whole UTF-8 validator are boolean functions of those planes evaluated 64
+// bytes at a time.
+//
+// This header is plain C++ so that tests/ can compile it with g++ and check
+// each function on the CPU (tests/test_lane_math.py, no GPU needed); on the device
+// msj_perm() is the v_perm_b32 instruction.
+#pragma once
+#include <stdint.h>
+
+#if defined(__HIPCC__)
+#define MSJ_HD __host__ __device__ __forceinline__
+#else
+#define MSJ_HD static inline
+#endif
+
+namespace msj {
+
+// v_perm_b32: result byte i = byte sel[i] of the 8-byte value {s0:s1} (s1 = low
+// dword); selector values 0..7 only are used here.
+MSJ_HD uint32_t perm(uint32_t s0, uint32_t s1, uint32_t sel) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_perm(s0, s1, sel);
+#else
+    uint64_t d = ((uint64_t)s0 << 32) | s1;
+    uint32_t r = 0;
+    for (int i = 0; i < 4; i++) {
+        uint32_t s = (sel >> (8 * i)) & 0xFF;
+        r |= (uint32_t)((d >> (8 * (s & 7))) & 0xFF) << (8 * i);
+    }
+    return r;
+#endif
+}
+
+MSJ_HD uint64_t u64(uint32_t lo, uint32_t hi) { return ((uint64_t)hi << 32) | lo; }
+
+// 8x8 bit-matrix transpose of one octet (8 bytes = lo,hi dwords): afterwards
+// byte k of {hi:lo} holds bit k of the 8 input bytes (bit r <- byte r).
+MSJ_HD void transpose_octet(uint32_t &lo, uint32_t &hi) {
+    uint32_t t;
+    t = (lo ^ (lo >> 7)) & 0x00AA00AAu;  lo ^= t ^ (t << 7);
+    t = (hi ^ (hi >> 7)) & 0x00AA00AAu;  hi ^= t ^ (t << 7);
+    t = (lo ^ (lo >> 14)) & 0x0000CCCCu; lo ^= t ^ (t << 14);
+    t = (hi ^ (hi >> 14)) & 0x0000CCCCu; hi ^= t ^ (t << 14);
+    // 4x4 nibble-block swap across the two dwords
+    uint32_t nlo = (lo & 0x0F0F0F0Fu) | ((hi << 4) & 0xF0F0F0F0u);
+    uint32_t nhi = ((lo >> 4) & 0x0F0F0F0Fu) | (hi & 0xF0F0F0F0u);
+    lo = nlo;
+    hi = nhi;
+}
+
+// 4x4 byte transpose: o[k] = bytes k of (a,b,c,d), a in the low byte.
+MSJ_HD void byte_transpose4(uint32_t a, uint32_t b, uint32_t c, uint32_t d, uint32_t &o0,
+                            uint32_t &o1, uint32_t &o2, uint32_t &o3) {
+    uint32_t ab_lo = perm(b, a, 0x05010400u);  // a0 b0 a1 b1
+    uint32_t ab_hi = perm(b, a, 0x07030602u);  // a2 b2 a3 b3
+    uint32_t cd_lo = perm(d, c, 0x05010400u);
+    uint32_t cd_hi = perm(d, c, 0x07030602u);
+    o0 = perm(cd_lo, ab_lo, 0x05040100u);  // a0 b0 c0 d0
+    o1 = perm(cd_lo, ab_lo, 0x07060302u);  // a1 b1 c1 d1
+    o2 = perm(cd_hi, ab_hi, 0x05040100u);
+    o3 = perm(cd_hi, ab_hi, 0x07060302u);
+}
+
+// 64 bytes (16 little-endian dwords) -> 8 bit-planes. plane k bit i = bit k of byte i.
+MSJ_HD void bitplanes(const uint32_t x[16], uint64_t p[8]) {
+    uint32_t tl[8], th[8];
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+        tl[j] = x[2 * j];
+        th[j] = x[2 * j + 1];
+        transpose_octet(tl[j], th[j]);
+    }
+    uint32_t plo[8], phi[8];
+    byte_transpose4(tl[0], tl[1], tl[2], tl[3], plo[0], plo[1], plo[2], plo[3]);
+    byte_transpose4(tl[4], tl[5], tl[6], tl[7], phi[0], phi[1], phi[2], phi[3]);
+    byte_transpose4(th[0], th[1], th[2], th[3], plo[4], plo[5], plo[6], plo[7]);
+    byte_transpose4(th[4], th[5], th[6], th[7], phi[4], phi[5], phi[6], phi[7]);
+#pragma unroll
+    for (int k = 0; k < 8; k++) p[k] = u64(plo[k], phi[k]);
+}
+
+// Character classes of one block, as masks.
+struct Classes {
+    uint64_t backslash;  // 0x5C            (stuff.mojo:6-9 eq["\\"])
+    uint64_t quote_chr;  // 0x22 raw, before escape resolution (eq['"'])
+    uint64_t op;         // {0C,1A,2C,3A,5B,5D,7B,7D}  (haswell.mojo:44-69, effective set)
+    uint64_t ws;         // {09,0A,0D,20}   (haswell.mojo:23-65)
+    uint64_t ctrl;       // byte <= 0x1F    (json_structural_indexer.mojo:135)
+};
+
+// valid: bit i set iff byte i is inside the input; bytes past the end behave as
+// the 0x20 padding the reference copies into its last block
+// (json_structural_indexer.mojo:103-107).
+MSJ_HD Classes classify(const uint64_t p[8], uint64_t valid) {
+    const uint64_t b0 = p[0], b1 = p[1], b2 = p[2], b3 = p[3];
+    const uint64_t b4 = p[4], b5 = p[5], b6 = p[6], b7 = p[7];
+    const uint64_t n7 = ~b7;
+    // low-nibble patterns
+    const uint64_t lo_C = b3 & b2 & ~b1 & ~b0;
+    const uint64_t lo_A = b3 & ~b2 & b1 & ~b0;
+    const uint64_t lo_B = b3 & ~b2 & b1 & b0;
+    const uint64_t lo_D = b3 & b2 & ~b1 & b0;
+    const uint64_t lo_9 = b3 & ~b2 & ~b1 & b0;
+    const uint64_t lo_0 = ~(b3 | b2 | b1 | b0);
+    const uint64_t lo_2 = ~b3 & ~b2 & b1 & ~b0;
+    // high-nibble patterns (all ASCII: b7 = 0)
+    const uint64_t n76 = n7 & ~b6;
+    const uint64_t h0 = n76 & ~b5 & ~b4;
+    const uint64_t h2 = n76 & b5 & ~b4;
+    const uint64_t h0or2 = n76 & ~b4;  // 0x0_, 0x2_
+    const uint64_t h1or3 = n76 & b4;   // 0x1_, 0x3_
+    const uint64_t h5or7 = n7 & b6 & b4;
+    const uint64_t h5 = h5or7 & ~b5;
+    Classes c;
+    c.backslash = h5 & lo_C & valid;
+    c.quote_chr = h2 & lo_2 & valid;
+    c.op = ((lo_C & h0or2) | (lo_A & h1or3) | ((lo_B | lo_D) & h5or7)) & valid;
+    c.ws = ((h0 & (lo_9 | lo_A | lo_D)) | (h2 & lo_0)) | ~valid;
+    c.ctrl = n76 & ~b5 & valid;
+    return c;
+}
+
+// Inclusive prefix XOR over 64 bits (stuff.mojo:21-28 prefix_xor, here 6
+// doubling steps instead of 64 popcounts).
+MSJ_HD uint64_t prefix_xor(uint64_t x) {
+    uint32_t lo = (uint32_t)x, hi = (uint32_t)(x >> 32);
+    lo ^= lo << 1;  hi ^= hi << 1;
+    lo ^= lo << 2;  hi ^= hi << 2;
+    lo ^= lo << 4;  hi ^= hi << 4;
+    lo ^= lo << 8;  hi ^= hi << 8;
+    lo ^= lo << 16; hi ^= hi << 16;
+    hi ^= (uint32_t)(-(int32_t)(lo >> 31));
+    return u64(lo, hi);
+}
+
+// JsonEscapeScanner.next (json_escape_scanner.mojo:18-45) for one block with a
+// known carry-in; returns the `escaped` mask, *escape_out = next_is_escaped.
+MSJ_HD uint64_t escaped_mask(uint64_t backslash, uint32_t next_is_escaped, uint32_t *escape_out) {
+    const uint64_t ODD = 0xAAAAAAAAAAAAAAAAull;
+    const uint64_t nie = next_is_escaped;
+    const uint64_t pe = backslash & ~nie;
+    const uint64_t t = (((pe << 1) | ODD) - pe) ^ ODD;
+    const uint64_t escaped = t ^ (backslash | nie);
+    const uint64_t escape = t & backslash;
+    *escape_out = (uint32_t)(escape >> 63);
+    return escaped;
+}
+
+// Length of the run of set bits at the top of m (bit 63 downwards), 0..64.
+MSJ_HD uint32_t top_run(uint64_t m) {
+    const uint64_t inv = ~m;
+    if (inv == 0) return 64;
+#if defined(__HIP_DEVICE_COMPILE__)
+    return (uint32_t)__clzll((long long)inv);
+#else
+    return (uint32_t)__builtin_clzll(inv);
+#endif
+}
+
+// ---------------------------------------------------------------------------
+// UTF-8 (strict, Unicode Table 3-7) on bit-planes.  The reference's checker is
+// an empty stub (json_structural_indexer.mojo:16-30); this implements what
+// upstream simdjson's checker accepts/rejects.
+//
+// Carry word from the previous block (bits of the planes at its top end):
+//   bit 0      : byte[-1] is a lead byte (2-, 3- or 4-byte)
+//   bits 1..2  : byte[-2], byte[-1] is a 3/4-byte lead        (bit1 = byte[-2])
+//   bits 3..5  : byte[-3..-1] is a 4-byte lead                (bit3 = byte[-3])
+//   bit 6 / 7 / 8 / 9 : byte[-1] is E0 / ED / F0 / F4
+struct Utf8Planes {
+    uint64_t lead234, lead34, lead4, isE0, isED, isF0, isF4;
+};
+
+MSJ_HD Utf8Planes utf8_planes(const uint64_t p[8]) {
+    const uint64_t b0 = p[0], b1 = p[1], b2 = p[2], b3 = p[3];
+    const uint64_t b4 = p[4], b5 = p[5], b6 = p[6], b7 = p[7];
+    const uint64_t hi2 = b7 & b6;
+    const uint64_t l3 = hi2 & b5 & ~b4;
+    const uint64_t l4 = hi2 & b5 & b4 & ~b3;
+    Utf8Planes u;
+    u.lead234 = hi2 & ~(b5 & b4 & b3);
+    u.lead34 = l3 | l4;
+    u.lead4 = l4;
+    u.isE0 = l3 & ~(b3 | b2 | b1 | b0);
+    u.isED = l3 & b3 & b2 & ~b1 & b0;
+    u.isF0 = l4 & ~(b2 | b1 | b0);
+    u.isF4 = l4 & b2 & ~(b1 | b0);
+    return u;
+}
+
+MSJ_HD uint32_t utf8_carry_out(const Utf8Planes &u) {
+    return (uint32_t)(u.lead234 >> 63) | ((uint32_t)(u.lead34 >> 62) << 1) |
+           ((uint32_t)(u.lead4 >> 61) << 3) | ((uint32_t)(u.isE0 >> 63) << 6) |
+           ((uint32_t)(u.isED >> 63) << 7) | ((uint32_t)(u.isF0 >> 63) << 8) |
+           ((uint32_t)(u.isF4 >> 63) << 9);
+}
+
+// Error mask of one block given the previous block's carry word.  Planes must
+// already be masked with `valid` (bytes past the end read as 0x00 = ASCII, so a
+// sequence truncated at EOF shows up as a missing continuation).
+MSJ_HD uint64_t utf8_errors(const uint64_t p[8], const Utf8Planes &u, uint32_t carry_in) {
+    const uint64_t b0 = p[0], b1 = p[1], b2 = p[2], b3 = p[3];
+    const uint64_t b4 = p[4], b5 = p[5], b6 = p[6], b7 = p[7];
+    const uint64_t cont = b7 & ~b6;
+    const uint64_t hi2 = b7 & b6;
+    const uint64_t l2 = hi2 & ~b5;
+    const uint64_t bad5 = hi2 & b5 & b4 & b3;  // F8..FF
+    const uint64_t c = carry_in;
+    const uint64_t exp1 = (u.lead234 << 1) | (c & 1);
+    const uint64_t exp2 = (u.lead34 << 2) | ((c >> 1) & 3);
+    const uint64_t exp3 = (u.lead4 << 3) | ((c >> 3) & 7);
+    const uint64_t expected = exp1 | exp2 | exp3;
+    const uint64_t pE0 = (u.isE0 << 1) | ((c >> 6) & 1);
+    const uint64_t pED = (u.isED << 1) | ((c >> 7) & 1);
+    const uint64_t pF0 = (u.isF0 << 1) | ((c >> 8) & 1);
+    const uint64_t pF4 = (u.isF4 << 1) | ((c >> 9) & 1);
+    uint64_t err = expected ^ cont;
+    err |= bad5;
+    err |= l2 & ~(b4 | b3 | b2 | b1);          // C0, C1
+    err |= u.lead4 & b2 & (b1 | b0);           // F5..F7
+    err |= pE0 & ~b5;                          // E0 80..9F  (overlong)
+    err |= pED & b5;                           // ED A0..BF  (surrogates)
+    err |= pF0 & ~b5 & ~b4;                    // F0 80..8F  (overlong)
+    err |= pF4 & (b5 | b4);                    // F4 90..BF  (> U+10FFFF)
+    (void)b0;
+    return err;
+}
+
+// ---------------------------------------------------------------------------
+// One whole block with explicit carries: the per-lane equivalent of
+// JsonScanner.next + JsonStructuralIndexer.next for one 64-byte sub-block
+// (json_scanner.mojo:64-70, json_string_scanner.mojo:55-69,
+//  json_structural_indexer.mojo:129-145).  Used directly by the CPU unit test;
+// the kernel inlines the same steps with the cross-lane carry resolution in
+// between.
+struct BlockCarry {
+    uint32_t next_is_escaped, in_string, prev_scalar;
+};
+struct BlockOut {
+    uint64_t structural;  // JsonBlock.structural_start (json_scanner.mojo:24-26)
+    uint64_t unescaped;   // ctrl & in_string (json_structural_indexer.mojo:143-145)
+};
+
+MSJ_HD BlockOut block_step(const uint32_t x[16], uint64_t valid, BlockCarry &cy) {
+    uint64_t p[8];
+    bitplanes(x, p);
+#pragma unroll
+    for (int k = 0; k < 8; k++) p[k] &= valid;
+    const Classes c = classify(p, valid);
+    uint32_t e_out;
+    const uint64_t escaped = escaped_mask(c.backslash, cy.next_is_escaped, &e_out);
+    const uint64_t quote = c.quote_chr & ~escaped;
+    const uint64_t in_string = prefix_xor(quote) ^ (uint64_t)(-(int64_t)cy.in_string);
+    const uint64_t scalar = ~(c.op | c.ws);
+    const uint64_t nonquote_scalar = scalar & ~quote;
+    const uint64_t follows = (nonquote_scalar << 1) | cy.prev_scalar;
+    const uint64_t potential = c.op | (scalar & ~follows);
+    BlockOut o;
+    o.structural = potential & ~(in_string ^ quote);
+    o.unescaped = c.ctrl & in_string;
+    cy.next_is_escaped = e_out;
+    cy.in_string = (uint32_t)(in_string >> 63);
+    cy.prev_scalar = (uint32_t)(nonquote_scalar >> 63);
+    return o;
+}
+
+}  // namespace msj

@@ -1,0 +1,44 @@
+// stage1_kernel.h -- launch interface between the C-ABI host code (api.cpp) and
+// the HIP kernel (stage1_kernel.hip).
+#pragma once
+#include <stdint.h>
+
+#include "../../include/msj_stage1.h"
+
+namespace msj {
+
+constexpr int kWaves = 4;                          // wave64 per workgroup
+constexpr int kThreads = kWaves * 64;              // 256 lanes, one 64-byte block each
+constexpr uint32_t kTileBytes = kThreads * 64u;    // 16 KiB of input per workgroup
+constexpr uint32_t kDescOffset = 8;                // ws[0] = tile ticket, ws[8..] = descriptors
+constexpr uint32_t kSpinLimit = 1u << 22;          // bounded look-back polling (internal_error on expiry)
+// largest segment one launch indexes with uint32 offsets (multiple of the tile)
+constexpr uint64_t kSegmentBytes = 0xFFFF0000ull;
+
+// kernel-internal flags (KernelArgs.flags)
+constexpr uint32_t kFlagStrictUtf8 = 1u;   // == MSJ_FLAG_STRICT_UTF8
+constexpr uint32_t kFlagNoUtf8 = 2u;       // == MSJ_FLAG_NO_UTF8
+constexpr uint32_t kFlagFinal = 4u;        // last segment of the stream: trailer + return code
+constexpr uint32_t kFlagHasPrefix = 8u;    // buf[-64..0) holds the preceding stream bytes
+constexpr uint32_t kFlagNoEmit = 16u;      // summary pass: no index writes
+
+struct KernelArgs {
+    const uint8_t *buf;       // segment base, 16-byte aligned, device memory
+    uint64_t len;             // segment length in bytes, 0 < len <= kSegmentBytes
+    uint32_t *idx;            // index array base (absolute positions: carry_in->count + ...)
+    uint64_t capacity;        // index array capacity in elements
+    uint64_t *ws;             // zeroed workspace: ticket + one descriptor per tile
+    const msj_carry *carry_in;
+    msj_carry *carry_out;
+    msj_segment *segment;     // optional: segment-table entry to fill
+    uint64_t segment_byte_base;
+    uint64_t trailer_len;     // value of the two `len` trailer words (FINAL only)
+    uint32_t ntiles;
+    uint32_t flags;
+};
+
+inline uint64_t workspace_words(uint32_t ntiles) { return (uint64_t)kDescOffset + ntiles; }
+
+}  // namespace msj
+
+extern "C" int msj_launch_stage1(const msj::KernelArgs *args, void *stream);

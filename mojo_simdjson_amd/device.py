@@ -1,0 +1,101 @@
+"""Device-resident entry points (what bench.py and the GPU parity tests drive).
+
+PyTorch is plumbing only: it owns device memory (tensors) and the HIP stream;
+every byte of the hot path runs in libmsj_stage1.so's HIP kernels through the C
+ABI (``msj_stage1_device`` / ``msj_stage1_shard_device``, include/msj_stage1.h).
+"""
+import ctypes
+
+import torch
+
+from . import _lib, errors
+
+CARRY_BYTES = 64
+SEGMENT_BYTES = 32
+
+
+def _ptr(t):
+    return ctypes.c_void_p(t.data_ptr())
+
+
+class Stage1Device:
+    """One ``msj_ctx`` bound to one GPU (one process per GPU)."""
+
+    def __init__(self, device_index=0):
+        self.lib = _lib.load()
+        if self.lib.msj_device_count() <= 0:
+            raise RuntimeError("no HIP device: mojo_simdjson_amd has no CPU fallback")
+        self.device_index = device_index
+        self.device = torch.device("cuda", device_index)
+        h = ctypes.c_void_p()
+        rc = self.lib.msj_ctx_create(device_index, ctypes.byref(h))
+        if rc != 0:
+            raise RuntimeError(f"msj_ctx_create failed: {rc}")
+        self.ctx = h
+
+    def close(self):
+        if self.ctx:
+            self.lib.msj_ctx_destroy(self.ctx)
+            self.ctx = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _stream(self):
+        return ctypes.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    def new_carry(self):
+        return torch.zeros(CARRY_BYTES, dtype=torch.uint8, device=self.device)
+
+    def make_carry(self, in_string=0, next_is_escaped=0, prev_scalar=0, count=0, nbytes=0):
+        c = _lib.MsjCarry()
+        c.in_string, c.next_is_escaped, c.prev_scalar = in_string, next_is_escaped, prev_scalar
+        c.count, c.bytes = count, nbytes
+        host = torch.frombuffer(bytearray(bytes(c)), dtype=torch.uint8)
+        return host.to(self.device)
+
+    def index(self, d_buf, d_idx, d_result, flags=0, length=None):
+        """Enqueue stage 1 over a device-resident buffer (asynchronous).
+
+        d_buf: uint8 CUDA tensor (16-byte aligned storage); d_idx: int32/uint32
+        CUDA tensor with room for n + 3 entries; d_result: 64-byte CUDA tensor
+        receiving the final ``msj_carry`` (count, code, utf8_error ...).
+        """
+        n = int(d_buf.numel() if length is None else length)
+        rc = self.lib.msj_stage1_device(self.ctx, _ptr(d_buf), n, _ptr(d_idx), d_idx.numel(),
+                                        _ptr(d_result), self._stream(), flags)
+        if rc < 0:
+            raise RuntimeError(f"msj_stage1_device failed: {rc}")
+        return rc
+
+    def shard(self, d_buf, length, d_idx, carry_in, carry_out, segments=None, has_prefix=False,
+              is_final=False, no_emit=False, trailer_len=0, flags=0):
+        nseg = ctypes.c_uint32(0)
+        rc = self.lib.msj_stage1_shard_device(
+            self.ctx, _ptr(d_buf), int(length),
+            _ptr(d_idx) if d_idx is not None else None,
+            d_idx.numel() if d_idx is not None else 0,
+            _ptr(carry_in), _ptr(carry_out),
+            _ptr(segments) if segments is not None else None,
+            (segments.numel() // SEGMENT_BYTES) if segments is not None else 0,
+            ctypes.byref(nseg), int(has_prefix), int(is_final), int(no_emit), int(trailer_len),
+            self._stream(), flags)
+        if rc < 0:
+            raise RuntimeError(f"msj_stage1_shard_device failed: {rc}")
+        return rc, nseg.value
+
+    def fetch(self, d_carry):
+        """Blocking read-back of a device ``msj_carry``."""
+        out = _lib.MsjCarry()
+        rc = self.lib.msj_carry_fetch(self.ctx, _ptr(d_carry), ctypes.byref(out), self._stream())
+        if rc != 0:
+            raise RuntimeError(f"msj_carry_fetch failed: {rc}")
+        return out
+
+
+def reference_code(carry, strict_utf8=False):
+    """Return code in the reference's precedence from a fetched final carry."""
+    return int(carry.code)

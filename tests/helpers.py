@@ -1,0 +1,79 @@
+"""Shared test plumbing.  The oracle (oracle/libmsj_oracle.so) is loaded HERE,
+in tests/, and nowhere in the product package."""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLDEN = os.path.join(ROOT, "tests", "golden", "jsons_for_test")
+ORACLE_SO = os.path.join(ROOT, "oracle", "libmsj_oracle.so")
+
+_ARGS = [ctypes.c_char_p, ctypes.c_uint64, ctypes.c_void_p, ctypes.c_uint64,
+         ctypes.POINTER(ctypes.c_uint64)]
+
+
+def load_oracle():
+    if not os.path.exists(ORACLE_SO):
+        subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle")])
+    lib = ctypes.CDLL(ORACLE_SO)
+    for name in ("msj_oracle_stage1", "msj_oracle_stage1_serial"):
+        fn = getattr(lib, name)
+        fn.restype = ctypes.c_int32
+        fn.argtypes = _ARGS
+    lib.msj_oracle_utf8.restype = ctypes.c_int32
+    lib.msj_oracle_utf8.argtypes = [ctypes.c_char_p, ctypes.c_uint64]
+    lib.msj_oracle_classify_byte.restype = ctypes.c_int
+    lib.msj_oracle_classify_byte.argtypes = [ctypes.c_uint8, ctypes.c_int]
+    return lib
+
+
+SENTINEL = 0xDEADBEEF
+
+
+def run_oracle(fn, data):
+    """-> (code, n or None, idx array incl. trailer or None)."""
+    data = bytes(data)
+    idx = np.full(len(data) + 3, SENTINEL, dtype=np.uint32)
+    n = ctypes.c_uint64(0xFFFFFFFFFFFFFFFF)
+    rc = fn(data, len(data), idx.ctypes.data, idx.size, ctypes.byref(n))
+    if n.value == 0xFFFFFFFFFFFFFFFF:
+        return rc, None, None
+    return rc, int(n.value), idx[: n.value + 3].copy()
+
+
+def read_fixture(path):
+    """tests/test_stage_1.mojo:85-89: line 0 = JSON text, line 1 = expected mask."""
+    with open(path, "rb") as f:
+        lines = f.read().split(b"\n")
+    return lines[0], lines[1]
+
+
+def mask_from_indices(indices, width):
+    """tests/test_stage_1.mojo:52-58."""
+    m = bytearray(b" " * width)
+    for i in indices:
+        m[int(i)] = ord("1")
+    return bytes(m)
+
+
+def golden_valid_files():
+    d = os.path.join(GOLDEN, "valid")
+    return sorted(os.path.join(d, f) for f in os.listdir(d) if f.endswith(".json"))
+
+
+def fuzz_inputs(seed, count, max_len=700):
+    """JSON-punctuation-heavy adversarial byte strings."""
+    import random
+
+    rng = random.Random(seed)
+    alpha = (b'\\\\\\"""[]{}:, \n\tabc019-\x0c\x1a\x00\x01\x1f\x20\xc3\xa9\xe4\xb8\xad'
+             b'\xf0\x9f\x98\x80tfn\x7f\x80\xff')
+    lens = [1, 2, 5, 63, 64, 65, 127, 128, 129, 191, 192, 193, 255, 256, 257, 300]
+    for it in range(count):
+        n = rng.choice(lens + [rng.randint(1, max_len)])
+        if it % 3 == 0:
+            yield bytes(rng.getrandbits(8) for _ in range(n))
+        else:
+            yield bytes(rng.choice(alpha) for _ in range(n))

@@ -1,0 +1,71 @@
+"""CPU checks of the drop-in boundary: the C-ABI library loads and exports every
+symbol include/msj_stage1.h declares; without a GPU the product fails loudly
+(no CPU fallback, and nothing in the package reaches for oracle/)."""
+import ctypes
+import os
+import re
+
+import pytest
+
+from tests import helpers
+
+HEADER = os.path.join(helpers.ROOT, "include", "msj_stage1.h")
+PKG = os.path.join(helpers.ROOT, "mojo_simdjson_amd")
+
+
+def declared_functions():
+    src = open(HEADER).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(msj_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_header_symbols_exported():
+    from mojo_simdjson_amd import _lib
+
+    lib = _lib.load()
+    names = declared_functions()
+    assert {"msj_stage1", "msj_stage1_device", "msj_stage1_shard_device", "msj_ctx_create",
+            "msj_ctx_destroy", "msj_carry_fetch", "msj_device_count"} <= set(names)
+    for n in names:
+        assert hasattr(lib, n), f"{n} declared in include/msj_stage1.h but not exported"
+    assert lib.msj_tile_bytes() == 16384
+    assert b"gfx950" in lib.msj_version()
+
+
+def test_struct_layouts():
+    from mojo_simdjson_amd import _lib
+
+    assert ctypes.sizeof(_lib.MsjCarry) == 64
+    assert _lib.MsjCarry.count.offset == 0 and _lib.MsjCarry.in_string.offset == 16
+    assert _lib.MsjCarry.code.offset == 40
+    assert ctypes.sizeof(_lib.MsjSegment) == 32
+
+
+def test_product_never_touches_oracle():
+    """The product package must not import, load, link or mention the test oracle."""
+    for root, _, files in os.walk(PKG):
+        for f in files:
+            if f.endswith((".py", ".cpp", ".hip", ".h", ".c")) or f == "Makefile":
+                text = open(os.path.join(root, f), errors="ignore").read().lower()
+                assert "oracle" not in text, os.path.join(root, f)
+
+
+def test_fails_loudly_without_gpu():
+    from mojo_simdjson_amd import DomParserImplementation, _lib, errors
+
+    lib = _lib.load()
+    if lib.msj_device_count() > 0:
+        pytest.skip("GPU present")
+    h = ctypes.c_void_p()
+    assert lib.msj_ctx_create(0, ctypes.byref(h)) == errors.ERR_NO_DEVICE
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        DomParserImplementation().stage1("[1, 2]")
+
+
+def test_error_values_match_reference():
+    from mojo_simdjson_amd import errors
+
+    # src/mojo_simdjson/errors.mojo:2-26
+    assert (errors.SUCCESS, errors.CAPACITY, errors.UTF8_ERROR, errors.EMPTY,
+            errors.UNESCAPED_CHARS, errors.UNCLOSED_STRING, errors.UNEXPECTED_ERROR) == \
+        (0, 1, 11, 13, 14, 15, 24)

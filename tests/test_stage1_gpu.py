@@ -1,0 +1,328 @@
+"""GPU parity tests: the HIP path, called through the C ABI, against the oracle.
+
+Bit-exact bar: index array, count, the three trailer words and the return code
+must equal the oracle's (oracle/stage1_oracle.c, pinned to the reference's
+golden fixtures by tests/test_oracle.py) on the same inputs.  The UTF-8 verdict
+(not part of reference parity: the reference's checker is a stub) is checked
+against CPython's strict decoder via the oracle's validator.
+"""
+import ctypes
+import json
+import os
+
+import numpy as np
+import pytest
+
+from tests import helpers
+
+pytestmark = pytest.mark.gpu
+
+TILE = 16384
+
+
+@pytest.fixture(scope="module")
+def torch_mod():
+    import torch
+
+    assert torch.cuda.is_available(), "no GPU visible"
+    return torch
+
+
+@pytest.fixture(scope="module")
+def dev(torch_mod):
+    from mojo_simdjson_amd.device import Stage1Device
+
+    d = Stage1Device(0)
+    yield d
+    d.close()
+
+
+def host_stage1(data, flags=0):
+    """Through the host-pointer C ABI (what the Mojo shim would call)."""
+    from mojo_simdjson_amd import DomParserImplementation
+
+    p = DomParserImplementation()
+    rc = p.stage1(bytes(data), flags)
+    return rc, p
+
+
+def assert_matches_oracle(oracle, data, where=""):
+    data = bytes(data)
+    want = helpers.run_oracle(oracle.msj_oracle_stage1, data)
+    rc, p = host_stage1(data)
+    assert rc == want[0], f"{where}: code {rc} != oracle {want[0]} (len {len(data)})"
+    if want[1] is not None:
+        n = want[1]
+        assert p.n_structural_indexes == n, f"{where}: n {p.n_structural_indexes} != {n}"
+        got = p.structural_indexes[: n + 3]
+        if not np.array_equal(got, want[2]):
+            bad = int(np.argmax(got != want[2]))
+            raise AssertionError(f"{where}: first index mismatch at {bad}: {got[bad]} != {want[2][bad]}")
+    assert p.utf8_verdict == oracle.msj_oracle_utf8(data, len(data)), f"{where}: utf8 verdict"
+
+
+def device_indices(torch, dev, d_buf, length, cap, flags=0):
+    d_idx = torch.full((cap,), -1, dtype=torch.int32, device=dev.device)
+    d_res = dev.new_carry()
+    dev.index(d_buf, d_idx, d_res, flags=flags, length=length)
+    res = dev.fetch(d_res)
+    return d_idx, res
+
+
+# ----------------------------------------------------------------------------
+# the reference's own test, tests/test_stage_1.mojo, through the host mirror
+def test_simple_json_reference_fixtures():
+    files = helpers.golden_valid_files()
+    assert len(files) > 5
+    for f in files:
+        js, mask = helpers.read_fixture(f)
+        rc, parser = host_stage1(js)
+        assert rc == 0, "unexpected error code"
+        n = parser.n_structural_indexes
+        idx = parser.structural_indexes
+        assert all(idx[i - 1] < idx[i] for i in range(1, n))
+        assert helpers.mask_from_indices(idx[:n], len(mask)) == mask, f
+        assert idx[n] == len(js) and idx[n + 1] == len(js) and idx[n + 2] == 0
+
+
+def test_extra_pins(oracle):
+    with open(os.path.join(helpers.ROOT, "tests", "golden", "extra_pins.json")) as f:
+        pins = json.load(f)
+    for p in pins:
+        d = bytes.fromhex(p["input_hex"])
+        rc, parser = host_stage1(d)
+        assert rc == p["code"], p["name"]
+        if p["indices"] is not None:
+            n = parser.n_structural_indexes
+            assert list(parser.structural_indexes[:n]) == p["indices"], p["name"]
+            assert list(parser.structural_indexes[n:n + 3]) == [len(d), len(d), 0], p["name"]
+        assert parser.utf8_verdict == p["utf8"], p["name"]
+
+
+def test_error_codes_and_empty():
+    from mojo_simdjson_amd import errors
+
+    assert host_stage1(b"")[0] == errors.EMPTY
+    assert host_stage1(b"  \n ")[0] == errors.EMPTY
+    assert host_stage1(b'"abc')[0] == errors.UNCLOSED_STRING
+    assert host_stage1(b'["a\nb"]')[0] == errors.UNESCAPED_CHARS
+    assert host_stage1(b'["a\x01b')[0] == errors.UNCLOSED_STRING
+    assert host_stage1(b'["\xff"]')[0] == errors.SUCCESS            # reference parity ignores utf8
+    assert host_stage1(b'["\xff"]', flags=1)[0] == errors.UTF8_ERROR  # strict flag
+    rc, p = host_stage1(b"[[[[")
+    assert rc == 0 and list(p.structural_indexes[:7]) == [0, 1, 2, 3, 4, 4, 0]
+
+
+def test_fuzz_small(oracle):
+    for i, d in enumerate(helpers.fuzz_inputs(4242, 1500)):
+        assert_matches_oracle(oracle, d, f"fuzz#{i}")
+
+
+def test_tile_boundaries(oracle):
+    """Lengths around the 64-byte block, the 4 KiB wave and the 16 KiB tile."""
+    import random
+
+    rng = random.Random(77)
+    alpha = b'\\\\"""[]{}:, \n\tab01-\x01\xc3\xa9tfn'
+    lens = [4095, 4096, 4097, TILE - 1, TILE, TILE + 1, TILE + 63, TILE + 64, TILE + 65,
+            2 * TILE - 1, 2 * TILE, 2 * TILE + 1, 5 * TILE + 777, 70 * TILE + 5]
+    for n in lens:
+        d = bytes(rng.choice(alpha) for _ in range(n))
+        assert_matches_oracle(oracle, d, f"rand len {n}")
+        body = (b'{"k":[1,2,"x\\"y",true,null,-3.5e2],"s":"a\\\\"} ' * (n // 40 + 2))[: n - 1] + b"7"
+        assert_matches_oracle(oracle, body, f"json len {n}")
+
+
+def test_backslash_runs_across_boundaries(oracle):
+    """H6: long backslash runs ending exactly at lane / wave / tile boundaries,
+    including >= 64 of them in front of a tile (descriptor fallback path)."""
+    for boundary in (64, 4096, TILE, 2 * TILE, 3 * TILE):
+        for run in (1, 2, 3, 61, 62, 63, 64, 65, 127, 128, 129, 200):
+            for shift in (-1, 0, 1):
+                pre = boundary + shift - run - 1
+                if pre < 1:
+                    continue
+                d = b'"' + b"a" * (pre - 1) + b"\\" * run + b'" , "x" ] ' + b"1" * 40
+                assert_matches_oracle(oracle, d, f"run {run} ending at {boundary + shift}")
+    # whole tiles of backslashes (escape carry must propagate through a tile)
+    for run in (TILE, TILE + 1, 2 * TILE, 2 * TILE + 1, 3 * TILE + 5):
+        for lead in (1, 2, 100):
+            d = b" " * (lead - 1) + b'"' + b"\\" * run + b'"  "' + b"b" * 10 + b'"'
+            assert_matches_oracle(oracle, d, f"tile run {run} lead {lead}")
+
+
+def test_strings_spanning_tiles(oracle):
+    """in_string carried through the look-back chain over many tiles; control
+    characters that are only an error on the in-string side."""
+    big = b'["' + b"s" * (5 * TILE + 123) + b'",' + b"\n" * 70 + b'"' + b"t" * (3 * TILE) + b'"]'
+    assert_matches_oracle(oracle, big, "long strings")
+    bad = b'["' + b"s" * (2 * TILE + 17) + b"\n" + b"s" * (TILE) + b'"]'
+    assert_matches_oracle(oracle, bad, "newline inside a long string")
+    unclosed = b'["' + b"s" * (4 * TILE)
+    assert_matches_oracle(oracle, unclosed, "unclosed long string")
+    many = (b'"a"' + b" " * 61) * (3 * TILE // 64)  # a quote pair in every lane
+    assert_matches_oracle(oracle, many, "quote pair per lane")
+    odd = (b'"' + b" " * 63) * (4 * TILE // 64)      # parity flips in every lane
+    assert_matches_oracle(oracle, odd, "one quote per lane")
+
+
+def test_density_extremes(oracle):
+    from mojo_simdjson_amd import synth
+
+    for kind in range(4):
+        d = synth.extreme(3 * TILE + 1000, kind).tobytes()
+        assert_matches_oracle(oracle, d, f"extreme kind {kind}")
+
+
+def test_utf8_negative_variants(oracle):
+    from mojo_simdjson_amd import synth
+
+    base = synth.workload("utf8", 6 * TILE).tobytes()
+    assert_matches_oracle(oracle, base, "utf8 workload")
+    n = len(base)
+    first_hi = next(i for i, c in enumerate(base) if c >= 0xE0)
+    for off in (first_hi, TILE - 1, TILE, 2 * TILE + 64, n - 2):
+        for val in (0xFF, 0xC0, 0x80):
+            d = bytearray(base)
+            d[off] = val
+            assert_matches_oracle(oracle, d, f"corrupt {val:#x} at {off}")
+    # sequences straddling block / wave / tile boundaries, and truncated at EOF
+    for boundary in (64, 4096, TILE, 2 * TILE):
+        for seq in (b"\xc3\xa9", b"\xe4\xb8\xad", b"\xf0\x9f\x98\x80", b"\xed\xa0\x80", b"\xf4\x90\x80\x80",
+                    b"\xe0\x80\x80", b"\xf0\x80\x80\x80", b"\xe4\xb8", b"\xf0\x9f\x98"):
+            for k in range(len(seq) + 1):
+                pre = boundary - k
+                d = b'"' + b"a" * (pre - 1) + seq + b'"' + b" " * 50
+                assert_matches_oracle(oracle, d, f"seq {seq.hex()} split {k} at {boundary}")
+                d2 = b'"' + b"a" * (pre - 1) + seq  # truncated document
+                assert_matches_oracle(oracle, d2, f"seq {seq.hex()} eof {k} at {boundary}")
+
+
+@pytest.mark.parametrize("name", ["minified", "utf8", "pretty2", "pretty8", "pretty_tab_crlf"])
+def test_workload_units_device_path(torch_mod, dev, oracle, name):
+    """8 MiB units of every bench workload through the device-resident API."""
+    torch = torch_mod
+    from mojo_simdjson_amd import synth
+
+    u = synth.workload(name, 8 << 20)
+    b = u.tobytes()
+    code, n, idx = helpers.run_oracle(oracle.msj_oracle_stage1, b)
+    assert code == 0
+    d_buf = torch.from_numpy(u).to(dev.device)
+    d_idx, res = device_indices(torch, dev, d_buf, len(b), len(b) + 3)
+    assert res.code == 0 and res.count == n and res.internal_error == 0
+    got = d_idx[: n + 3].cpu().numpy().view(np.uint32)
+    assert np.array_equal(got, idx)
+    assert res.utf8_error == 0 and res.in_string == 0
+    assert int(d_idx[n + 3].item()) == -1  # nothing written past the trailer
+
+
+def test_capacity_clip(torch_mod, dev, oracle):
+    torch = torch_mod
+    from mojo_simdjson_amd import synth
+
+    u = synth.workload("minified", 1 << 20)
+    b = u.tobytes()
+    _, n, idx = helpers.run_oracle(oracle.msj_oracle_stage1, b)
+    d_buf = torch.from_numpy(u).to(dev.device)
+    # exactly enough
+    d_idx, res = device_indices(torch, dev, d_buf, len(b), n + 3)
+    assert res.code == 0 and np.array_equal(d_idx.cpu().numpy().view(np.uint32), idx)
+    # too small: CAPACITY, and no write past the buffer (guard word intact)
+    cap = n // 2
+    d_idx = torch.full((cap + 64,), -1, dtype=torch.int32, device=dev.device)
+    d_res = dev.new_carry()
+    dev.lib.msj_stage1_device(dev.ctx, ctypes.c_void_p(d_buf.data_ptr()), len(b),
+                              ctypes.c_void_p(d_idx.data_ptr()), cap, ctypes.c_void_p(d_res.data_ptr()),
+                              dev._stream(), 0)
+    res = dev.fetch(d_res)
+    assert res.code == 1 and res.count == n
+    host = d_idx.cpu().numpy()
+    assert np.array_equal(host[:cap].view(np.uint32), idx[:cap])
+    assert (host[cap:] == -1).all()
+
+
+def test_shard_chain_equals_whole(torch_mod, dev, oracle):
+    """Cutting the stream at arbitrary (tile-aligned and unaligned-length) points and
+    chaining msj_stage1_shard_device through device-resident carries reproduces the
+    single-call result: the property the multi-GPU stitch relies on."""
+    torch = torch_mod
+    from mojo_simdjson_amd import synth
+
+    u = synth.workload("utf8", 3 << 20)
+    b = u.tobytes()
+    code, n, idx = helpers.run_oracle(oracle.msj_oracle_stage1, b)
+    assert code == 0
+    d_all = torch.from_numpy(u).to(dev.device)
+    cuts = [0, 5 * TILE, 5 * TILE + 64 * 1000, 100 * TILE + 16 * 777, len(b)]
+    d_idx = torch.full((n + 3,), -1, dtype=torch.int32, device=dev.device)
+    cin = dev.new_carry()
+    for k in range(len(cuts) - 1):
+        lo, hi = cuts[k], cuts[k + 1]
+        cout = dev.new_carry()
+        rc, nseg = dev.shard(d_all[lo:], hi - lo, d_idx, cin, cout, has_prefix=(k > 0),
+                             is_final=(k == len(cuts) - 2), trailer_len=len(b))
+        assert rc == 0 and nseg == 1
+        cin = cout
+    res = dev.fetch(cin)
+    assert res.code == 0 and res.count == n and res.bytes == len(b)
+    got = d_idx.cpu().numpy().view(np.uint32)
+    # shard-relative offsets: add each shard's byte base back before comparing
+    bases = np.zeros(n + 3, dtype=np.uint32)
+    counts = []
+    for k in range(len(cuts) - 1):
+        lo, hi = cuts[k], cuts[k + 1]
+        cnt = int(np.searchsorted(idx[:n], hi) - np.searchsorted(idx[:n], lo))
+        counts.append(cnt)
+    pos = 0
+    for k, cnt in enumerate(counts):
+        bases[pos:pos + cnt] = cuts[k]
+        pos += cnt
+    assert np.array_equal(got[:n] + bases[:n], idx[:n])
+    assert list(got[n:n + 3]) == [len(b), len(b), 0]
+
+
+def test_summary_pass_parity(torch_mod, dev, oracle):
+    """no_emit summary pass returns the shard's quote parity and writes nothing."""
+    torch = torch_mod
+    d = (b'{"a":"' + b"x" * (2 * TILE) + b'","b":[1,2,"q')  # ends inside a string
+    u = np.frombuffer(d, dtype=np.uint8)
+    d_buf = torch.from_numpy(u.copy()).to(dev.device)
+    cin, cout = dev.new_carry(), dev.new_carry()
+    dev.shard(d_buf, len(d), None, cin, cout, no_emit=True, flags=2)
+    res = dev.fetch(cout)
+    assert res.in_string == 1
+    want = helpers.run_oracle(oracle.msj_oracle_stage1_serial, d + b'"')
+    assert res.count == want[1]
+
+
+@pytest.mark.parametrize("name", ["minified", "pretty4"])
+def test_full_size_1gib_replication_property(torch_mod, dev, oracle, name):
+    """BASELINE.json configs 2/4 at full size.  The oracle indexes one ~64 MiB
+    unit; the 1 GiB buffer is that unit repeated, and because every unit ends
+    with all carries at zero the expected index array is unit_idx + k*unit_len
+    (checked on the device, not by shipping 4 GB to the host)."""
+    torch = torch_mod
+    from mojo_simdjson_amd import synth
+
+    u = synth.workload(name, 64 << 20)
+    b = u.tobytes()
+    code, n, idx = helpers.run_oracle(oracle.msj_oracle_stage1, b)
+    assert code == 0
+    reps = (1 << 30) // len(b)
+    d_unit = torch.from_numpy(u).to(dev.device)
+    d_buf = d_unit.repeat(reps)
+    total = d_buf.numel()
+    assert total % 128 != 0
+    cap = n * reps + 3
+    d_idx, res = device_indices(torch, dev, d_buf, total, cap)
+    assert res.code == 0 and res.count == n * reps and res.internal_error == 0
+    unit_idx = torch.from_numpy(idx[:n].astype(np.int64)).to(dev.device)
+    for k in range(reps):
+        got = d_idx[k * n:(k + 1) * n].to(torch.int64) & 0xFFFFFFFF
+        assert torch.equal(got, unit_idx + k * len(b)), f"repetition {k}"
+    tail = d_idx[n * reps:n * reps + 3].to(torch.int64) & 0xFFFFFFFF
+    assert tail.tolist() == [total, total, 0]
+    # size-independent properties: strictly increasing, every index on a plausible byte
+    v = d_idx[: n * reps].to(torch.int64) & 0xFFFFFFFF
+    assert bool((v[1:] > v[:-1]).all())
