@@ -48,11 +48,34 @@ class HipExtensionMissing(RuntimeError):
     pass
 
 
+def _share_torch_hip_runtime():
+    """Make libmsj_stage1.so bind to the HIP runtime PyTorch already uses.
+
+    The PyTorch wheel bundles its own libamdhip64.so / libhsa-runtime64.so
+    (ROCm 7.0) next to the system ROCm 7.2 that libmsj_stage1.so names in its
+    DT_NEEDED.  Two HIP runtimes in one process each open the device; whichever
+    comes second may see no GPU, and tensors allocated by one are unknown to the
+    other.  Promoting torch's runtime to the global symbol scope *before* our
+    library is opened makes every hip* symbol of libmsj_stage1.so resolve to
+    that one runtime (global scope is searched before a library's own
+    dependencies).  Without torch in the process (the Mojo shim case) nothing is
+    preloaded and the system runtime is used.
+    """
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        return
+    cand = os.path.join(os.path.dirname(torch.__file__), "lib", "libamdhip64.so")
+    if os.path.exists(cand):
+        ctypes.CDLL(cand, mode=ctypes.RTLD_GLOBAL)
+
+
 def load():
     """Load libmsj_stage1.so once; raise loudly if it has not been built."""
     global _lib
     if _lib is not None:
         return _lib
+    _share_torch_hip_runtime()
     if not os.path.exists(LIB_PATH):
         raise HipExtensionMissing(
             f"{LIB_PATH} not found: build the HIP extension first "
