@@ -135,7 +135,7 @@ int32_t msj_stage1_ctx(msj_ctx *ctx, const uint8_t *buf, uint64_t len, uint32_t 
 /*
  * msj_stage1_device -- device-resident form (what bench.py times).
  * d_buf: device pointer, 16-byte aligned, len < 2^32 bytes.
- * d_idx: device pointer to idx_capacity uint32 slots.
+ * d_idx: device pointer (16-byte aligned) to idx_capacity uint32 slots.
  * d_result: device pointer to one msj_carry; after the stream drains it holds
  *   count (= n), code (reference return code), utf8_error, ...
  * Enqueues on `stream` (hipStream_t as void*, NULL = default stream) and

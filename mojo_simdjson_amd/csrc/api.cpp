@@ -31,6 +31,7 @@ struct msj_ctx {
 
 namespace {
 
+uint64_t *g_stamps = nullptr;  // diagnostic builds (-DMSJ_STAMPS) only: msj_debug_set_stamps
 constexpr uint32_t kMaxChain = 64;  // segments per shard call (64 x ~4 GiB)
 
 bool hip_ok(hipError_t e) { return e == hipSuccess; }
@@ -59,6 +60,7 @@ int32_t enqueue_shard(msj_ctx *ctx, const uint8_t *d_buf, uint64_t len, uint32_t
     if (!ctx || !d_buf || !d_carry_in || !d_carry_out || len == 0) return MSJ_ERR_BAD_ARGUMENT;
     if ((reinterpret_cast<uintptr_t>(d_buf) & 15u) != 0) return MSJ_ERR_BAD_ARGUMENT;
     if (!no_emit && !d_idx) return MSJ_ERR_BAD_ARGUMENT;
+    if ((reinterpret_cast<uintptr_t>(d_idx) & 15u) != 0) return MSJ_ERR_BAD_ARGUMENT;  // 16-B stores
     const uint64_t nseg = (len + msj::kSegmentBytes - 1) / msj::kSegmentBytes;
     if (nseg > kMaxChain) return MSJ_CAPACITY;
     if (d_segments && nseg > max_segments) return MSJ_CAPACITY;
@@ -88,6 +90,7 @@ int32_t enqueue_shard(msj_ctx *ctx, const uint8_t *d_buf, uint64_t len, uint32_t
         if (is_final && s + 1 == nseg) a.flags |= msj::kFlagFinal;
         if (has_prefix || s > 0) a.flags |= msj::kFlagHasPrefix;
         if (no_emit) a.flags |= msj::kFlagNoEmit;
+        a.stamps = g_stamps;
         // ticket + descriptors must read as "not ready" at launch
         if (!hip_ok(hipMemsetAsync(ctx->ws, 0, msj::workspace_words(a.ntiles) * sizeof(uint64_t),
                                    stream)))
@@ -227,6 +230,10 @@ int32_t msj_stage1_ctx(msj_ctx *ctx, const uint8_t *buf, uint64_t len, uint32_t 
     *n_out = n;
     return res.code;
 }
+
+#ifdef MSJ_STAMPS
+void msj_debug_set_stamps(uint64_t *d_stamps) { g_stamps = d_stamps; }
+#endif
 
 int32_t msj_stage1(const uint8_t *buf, uint64_t len, uint32_t *idx_out, uint64_t idx_capacity,
                    uint64_t *n_out, int32_t *utf8_verdict_out, uint32_t flags) {

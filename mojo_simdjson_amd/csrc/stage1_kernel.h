@@ -10,7 +10,9 @@ namespace msj {
 constexpr int kWaves = 4;                          // wave64 per workgroup
 constexpr int kThreads = kWaves * 64;              // 256 lanes, one 64-byte block each
 constexpr uint32_t kTileBytes = kThreads * 64u;    // 16 KiB of input per workgroup
-constexpr uint32_t kDescOffset = 8;                // ws[0] = tile ticket, ws[8..] = descriptors
+constexpr uint32_t kDescOffset = 8;                // ws[0] = ticket, ws[8..] = agg[ntiles], pre[ntiles]
+constexpr uint32_t kStageWords = 4096;             // LDS staging of indices (16 KiB) per round
+constexpr int kResolveE = 8;                       // tiles folded per resolver lane per round
 constexpr uint32_t kSpinLimit = 1u << 22;          // bounded look-back polling (internal_error on expiry)
 // largest segment one launch indexes with uint32 offsets (multiple of the tile)
 constexpr uint64_t kSegmentBytes = 0xFFFF0000ull;
@@ -35,9 +37,10 @@ struct KernelArgs {
     uint64_t trailer_len;     // value of the two `len` trailer words (FINAL only)
     uint32_t ntiles;
     uint32_t flags;
+    uint64_t *stamps;         // diagnostic builds only (-DMSJ_STAMPS): 16 words per tile, else null
 };
 
-inline uint64_t workspace_words(uint32_t ntiles) { return (uint64_t)kDescOffset + ntiles; }
+inline uint64_t workspace_words(uint32_t ntiles) { return (uint64_t)kDescOffset + 2ull * ntiles; }
 
 }  // namespace msj
 

@@ -35,13 +35,18 @@
 namespace msj {
 
 // ---- tile descriptors -------------------------------------------------------
-// bits 63:62 status (0 = not ready, 1 = aggregate, 2 = inclusive)
-// aggregate : 61 parity, 60 err(s_in=0), 59 err(s_in=1), 58 e_out, 57 ps_out,
-//             56 utf8 err, 30:15 count(s_in=1), 14:0 count(s_in=0)
-// inclusive : 61 in_string after tile, 60 unescaped err so far, 58 e_out,
-//             57 ps_out, 56 utf8 err so far, 31:0 count so far (launch-relative)
+// One 64-bit word per tile in each of two arrays (the data is the flag: one
+// relaxed agent-scope 8-byte store, polled with relaxed agent-scope loads).
+// bits 63:62 status: 0 = not ready
+// agg[t] (written by the tile's workgroup), status 1:
+//   61 quote parity, 60 err(s_in=0), 59 err(s_in=1), 58 e_out, 57 ps_out,
+//   56 utf8 err, 55 utf8 sequence pending at tile end, 54 poisoned (timeout),
+//   30:15 count(s_in=1), 14:0 count(s_in=0)
+// pre[t] (written by the resolver), status 2 (3 = resolver gave up):
+//   61 in_string before the tile, 60 unescaped err before, 56 utf8 err before,
+//   31:0 structurals before the tile (launch-relative)
 constexpr uint64_t kAgg = 1ull << 62;
-constexpr uint64_t kInc = 2ull << 62;
+constexpr uint64_t kPre = 2ull << 62;
 
 __device__ __forceinline__ uint64_t ld_desc(const uint64_t *p) {
     return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -60,6 +65,16 @@ __device__ __forceinline__ uint32_t wave_sum(uint32_t v) {
     return v;
 }
 
+#ifdef MSJ_STAMPS
+// Diagnostic build only: phase timestamps per tile (never compiled into the product .so).
+#define MSJ_STAMP(k)                                                                      \
+    do {                                                                                  \
+        if (tid == 0 && a.stamps) a.stamps[(uint64_t)stamp_tile * 16 + (k)] = __builtin_amdgcn_s_memtime(); \
+    } while (0)
+#else
+#define MSJ_STAMP(k) do {} while (0)
+#endif
+
 struct Shared {
     uint32_t tile;
     uint32_t tile_e_in, tile_ps_in, tile_u8_in;
@@ -72,6 +87,7 @@ struct Shared {
     uint32_t s_in;
     uint32_t timeout;
     uint64_t base;           // absolute output position of the tile's first index
+    uint32_t stage[kStageWords] __attribute__((aligned(16)));  // index staging for coalesced stores
 };
 
 // Bounded poll of one descriptor until its status is non-zero.
@@ -89,20 +105,16 @@ __device__ __forceinline__ uint64_t wait_desc(const uint64_t *p, uint32_t *timeo
     return d;
 }
 
-__global__ __launch_bounds__(kThreads) void stage1_kernel(const KernelArgs a) {
-    __shared__ Shared sh;
+__device__ __forceinline__ void worker(const KernelArgs &a, Shared &sh, const uint32_t tile) {
     const uint32_t tid = threadIdx.x;
     const uint32_t lane = tid & 63u;
     const uint32_t wave = tid >> 6;
-
-    // ---- ordered tile id: predecessors have all started (no look-back deadlock)
-    if (tid == 0) {
-        sh.tile = atomicAdd(reinterpret_cast<unsigned int *>(a.ws), 1u);
-        sh.timeout = 0;
-    }
-    __syncthreads();
-    const uint32_t tile = sh.tile;
-    uint64_t *desc = a.ws + kDescOffset;
+#ifdef MSJ_STAMPS
+    const uint32_t stamp_tile = tile;
+#endif
+    MSJ_STAMP(1);
+    uint64_t *agg = a.ws + kDescOffset;
+    const uint64_t *pre = a.ws + kDescOffset + a.ntiles;
     const uint64_t len = a.len;
     const uint64_t tile_start = (uint64_t)tile * kTileBytes;
     const uint64_t blk_off = tile_start + (uint64_t)tid * 64u;
@@ -186,7 +198,7 @@ __global__ __launch_bounds__(kThreads) void stage1_kernel(const KernelArgs a) {
                 // >= 62 consecutive backslashes in front of the tile: take the exact
                 // carries the predecessor publishes with its descriptor.
                 uint32_t to = 0;
-                const uint64_t d = wait_desc(&desc[tile - 1], &to);
+                const uint64_t d = wait_desc(&agg[tile - 1], &to);
                 if (to && lane == 0) sh.timeout = 1;
                 e_in = (uint32_t)(d >> 58) & 1u;
                 ps_in = (uint32_t)(d >> 57) & 1u;
@@ -199,6 +211,7 @@ __global__ __launch_bounds__(kThreads) void stage1_kernel(const KernelArgs a) {
         }
     }
 
+    MSJ_STAMP(2);
     // ---- bit-planes and character classes (lane_math.h)
     uint64_t p[8];
     bitplanes(x, p);
@@ -219,7 +232,9 @@ __global__ __launch_bounds__(kThreads) void stage1_kernel(const KernelArgs a) {
         const uint32_t c1 = (uint32_t)(((add_a & add_b) | ((add_a | add_b) & ~s1)) >> 63);
         if (lane == 0) sh.esc[wave] = c0 | (c1 << 1);
     }
+    MSJ_STAMP(3);
     __syncthreads();  // B1: tile carries + per-wave escape transfer published
+    MSJ_STAMP(4);
 
     uint32_t wave_e_in = sh.tile_e_in;
     for (uint32_t w = 0; w < wave; w++) wave_e_in = (sh.esc[w] >> wave_e_in) & 1u;
@@ -255,6 +270,7 @@ __global__ __launch_bounds__(kThreads) void stage1_kernel(const KernelArgs a) {
         sh.par[wave] = (uint32_t)__popcll(PM) & 1u;
     }
     __syncthreads();  // B2: wave parities / prev_scalar / utf8 carries published
+    MSJ_STAMP(5);
 
     uint32_t wave_par = 0;
     for (uint32_t w = 0; w < wave; w++) wave_par ^= sh.par[w];
@@ -291,6 +307,7 @@ __global__ __launch_bounds__(kThreads) void stage1_kernel(const KernelArgs a) {
         }
     }
     __syncthreads();  // B3: wave totals published
+    MSJ_STAMP(6);
 
     uint32_t wave_off = 0, tile_cnt = 0, tile_flg = 0, tile_par = 0;
 #pragma unroll
@@ -302,189 +319,268 @@ __global__ __launch_bounds__(kThreads) void stage1_kernel(const KernelArgs a) {
     }
     const uint32_t tile_c0 = tile_cnt & 0xFFFFu, tile_c1 = tile_cnt >> 16;
 
-    // ---- wave 0: publish aggregate, decoupled look-back, publish inclusive
+    // ---- wave 0: publish the tile aggregate, then wait for the resolver's prefix
     if (wave == 0) {
         uint32_t tile_e_out = sh.tile_e_in;
         for (uint32_t w = 0; w < kWaves; w++) tile_e_out = (sh.esc[w] >> tile_e_out) & 1u;
         const uint32_t tile_ps_out = sh.ps[kWaves - 1];
-        const uint64_t common = ((uint64_t)tile_e_out << 58) | ((uint64_t)tile_ps_out << 57);
-        uint32_t s_in, err_in = 0, u8_in = 0, timeout = 0;
-        uint64_t base_rel = 0;
-        if (tile == 0) {
-            s_in = a.carry_in->in_string & 1u;
-        } else {
-            if (lane == 0) {
-                st_desc(&desc[tile], kAgg | ((uint64_t)tile_par << 61) |
-                                         ((uint64_t)(tile_flg & 1u) << 60) |
-                                         ((uint64_t)((tile_flg >> 1) & 1u) << 59) | common |
-                                         ((uint64_t)((tile_flg >> 2) & 1u) << 56) |
-                                         ((uint64_t)tile_c1 << 15) | (uint64_t)tile_c0);
-            }
-            // accumulated aggregate of the tiles between the window and me
-            uint32_t accP = 0, accE0 = 0, accE1 = 0, accU = 0;
-            uint64_t accC0 = 0, accC1 = 0;
-            int64_t j = (int64_t)tile - 1;
-            const uint32_t virt_s = a.carry_in->in_string & 1u;
-            for (;;) {
-                const int64_t my = j - (int64_t)lane;
-                uint64_t d = kInc | ((uint64_t)virt_s << 61);  // before the launch: carry_in
-                uint64_t incm, rdym, need;
-                uint32_t spins = 0;
-                for (;;) {
-                    if (my >= 0) d = ld_desc(&desc[my]);
-                    const uint32_t st = (uint32_t)(d >> 62);
-                    rdym = __ballot(st != 0u);
-                    incm = __ballot(st == 2u);
-                    // lanes nearer than the nearest inclusive must all be ready
-                    need = incm ? ((incm & (0ull - incm)) - 1ull) : ~0ull;
-                    if ((rdym & need) == need) break;
-                    if (++spins > kSpinLimit) {
-                        timeout = 1;
-                        break;
-                    }
-                    __builtin_amdgcn_s_sleep(1);
-                }
-                if (timeout) {
-                    s_in = 0;
-                    break;
-                }
-                const uint32_t f = incm ? (uint32_t)__builtin_ctzll(incm) : 64u;
-                const bool is_agg = lane < f;
-                const uint32_t pbit = is_agg ? (uint32_t)(d >> 61) & 1u : 0u;
-                const uint64_t PW = __ballot(pbit != 0u);
-                // parity of the aggregates farther than me (applied before me)
-                const uint32_t far_par = (lane >= 63u) ? 0u : ((uint32_t)__popcll(PW >> (lane + 1u)) & 1u);
-                const uint32_t c0 = (uint32_t)d & 0x7FFFu, c1 = (uint32_t)(d >> 15) & 0xFFFFu;
-                const uint32_t e0 = (uint32_t)(d >> 60) & 1u, e1 = (uint32_t)(d >> 59) & 1u;
-                const uint64_t U = __ballot((lane <= f) && ((d >> 56) & 1u));
-                const uint32_t win_par = (uint32_t)__popcll(PW) & 1u;
-                if (f < 64u) {
-                    const uint64_t dinc = __shfl(d, (int)f);
-                    const uint32_t sb = (uint32_t)(dinc >> 61) & 1u;
-                    const uint32_t in_k = sb ^ far_par;
-                    const uint32_t sum = wave_sum(is_agg ? (in_k ? c1 : c0) : 0u);
-                    const uint64_t E = __ballot(is_agg && (in_k ? e1 : e0));
-                    const uint32_t s1 = sb ^ win_par;  // state entering the accumulated part
-                    s_in = s1 ^ accP;
-                    base_rel = (uint64_t)(uint32_t)dinc + sum + (s1 ? accC1 : accC0);
-                    err_in = ((uint32_t)(dinc >> 60) & 1u) | (E ? 1u : 0u) | (s1 ? accE1 : accE0);
-                    u8_in = (U ? 1u : 0u) | accU;
-                    break;
-                }
-                // no inclusive among these 64: fold them into the accumulated aggregate
-                const uint32_t in0 = far_par, in1 = far_par ^ 1u;
-                const uint32_t sum0 = wave_sum(in0 ? c1 : c0);
-                const uint32_t sum1 = wave_sum(in1 ? c1 : c0);
-                const uint64_t E0 = __ballot(in0 ? e1 : e0), E1 = __ballot(in1 ? e1 : e0);
-                const uint64_t nC0 = sum0 + (win_par ? accC1 : accC0);
-                const uint64_t nC1 = sum1 + (win_par ? accC0 : accC1);
-                const uint32_t nE0 = (E0 ? 1u : 0u) | (win_par ? accE1 : accE0);
-                const uint32_t nE1 = (E1 ? 1u : 0u) | (win_par ? accE0 : accE1);
-                accC0 = nC0;
-                accC1 = nC1;
-                accE0 = nE0;
-                accE1 = nE1;
-                accP ^= win_par;
-                accU |= (U ? 1u : 0u);
-                j -= 64;
-            }
-        }
-        const uint32_t my_cnt = s_in ? tile_c1 : tile_c0;
-        const uint32_t s_out = s_in ^ tile_par;
-        const uint32_t err_out = err_in | ((s_in ? (tile_flg >> 1) : tile_flg) & 1u);
-        const uint32_t u8_out = u8_in | ((tile_flg >> 2) & 1u);
-        const uint64_t cnt_out = base_rel + my_cnt;
+        const uint32_t pend = (sh.u8c[kWaves - 1] & 0x3Fu) ? 1u : 0u;
         if (lane == 0) {
-            st_desc(&desc[tile], kInc | ((uint64_t)s_out << 61) | ((uint64_t)err_out << 60) |
-                                     common | ((uint64_t)u8_out << 56) | (cnt_out & 0xFFFFFFFFull));
-            sh.s_in = s_in;
-            sh.base = a.carry_in->count + base_rel;
-            if (timeout) sh.timeout = 1;
-
-            if (tile == a.ntiles - 1) {
-                // ---- finish(): json_structural_indexer.mojo:147-186
-                const msj_carry cin = *a.carry_in;
-                msj_carry out;
-                const uint64_t n = cin.count + cnt_out;
-                out.count = n;
-                out.bytes = cin.bytes + len;
-                out.in_string = s_out;
-                out.next_is_escaped = tile_e_out;
-                out.prev_scalar = tile_ps_out;
-                out.unescaped_error = (cin.unescaped_error | err_out) ? 1u : 0u;
-                uint32_t u8e = cin.utf8_error | u8_out;
-                // a multi-byte sequence cut exactly at the end of the last full tile
-                if ((a.flags & kFlagFinal) && do_utf8 && (len % kTileBytes) == 0 &&
-                    (sh.u8c[kWaves - 1] & 0x3Fu))
-                    u8e = 1;
-                out.utf8_error = u8e ? 1u : 0u;
-                out.internal_error = cin.internal_error | sh.timeout;
-                int32_t code = MSJ_SUCCESS;
-                if (a.flags & kFlagFinal) {
-                    if (out.internal_error) {
-                        code = MSJ_UNEXPECTED_ERROR;
-                    } else if (s_out) {
-                        code = MSJ_UNCLOSED_STRING;  // :151-155
-                    } else if (out.unescaped_error) {
-                        code = MSJ_UNESCAPED_CHARS;  // :157-158
-                    } else if (n + 3 > a.capacity) {
-                        code = MSJ_CAPACITY;
-                    } else {
-                        if (!(a.flags & kFlagNoEmit)) {
-                            a.idx[n] = (uint32_t)a.trailer_len;      // :167-169
-                            a.idx[n + 1] = (uint32_t)a.trailer_len;  // :170-172
-                            a.idx[n + 2] = 0;                        // :173
-                        }
-                        if (n == 0)
-                            code = MSJ_EMPTY;  // :176-177
-                        else if ((a.flags & kFlagStrictUtf8) && out.utf8_error)
-                            code = MSJ_UTF8_ERROR;
-                    }
-                }
-                out.code = code;
-                for (int k = 0; k < 5; k++) out.reserved[k] = 0;
-                *a.carry_out = out;
-                if (a.segment) {
-                    a.segment->byte_base = a.segment_byte_base;
-                    a.segment->byte_len = len;
-                    a.segment->index_begin = cin.count;
-                    a.segment->count = cnt_out;
-                }
-            }
+            st_desc(&agg[tile], kAgg | ((uint64_t)tile_par << 61) |
+                                    ((uint64_t)(tile_flg & 1u) << 60) |
+                                    ((uint64_t)((tile_flg >> 1) & 1u) << 59) |
+                                    ((uint64_t)tile_e_out << 58) | ((uint64_t)tile_ps_out << 57) |
+                                    ((uint64_t)((tile_flg >> 2) & 1u) << 56) |
+                                    ((uint64_t)pend << 55) | ((uint64_t)sh.timeout << 54) |
+                                    ((uint64_t)tile_c1 << 15) | (uint64_t)tile_c0);
+        }
+        MSJ_STAMP(7);
+        uint32_t to = 0;
+        const uint64_t d = wait_desc(&pre[tile], &to);
+        if (lane == 0) {
+            sh.s_in = (uint32_t)(d >> 61) & 1u;
+            sh.base = a.carry_in->count + (uint64_t)(uint32_t)d;
+            if (to || (d >> 62) == 3u) sh.timeout = 1;
         }
     }
+    MSJ_STAMP(8);
     __syncthreads();  // B4: s_in / base known to every wave
+    MSJ_STAMP(9);
 
-    // ---- BitIndexer.write (json_structural_indexer.mojo:46-58): ascending offsets
-    if (!(a.flags & kFlagNoEmit)) {
+    // ---- BitIndexer.write (json_structural_indexer.mojo:46-58): the ascending offsets
+    //      are staged in LDS at their tile-relative position and written out as
+    //      aligned 16-byte stores (one L2 request per 64 B instead of one per index).
+    if (!(a.flags & kFlagNoEmit) && !sh.timeout) {
         const uint32_t s_in = sh.s_in;
-        uint64_t T = s_in ? T1 : T0;
+        const uint64_t T = s_in ? T1 : T0;
         const uint32_t excl = inc - pk;
         const uint32_t lane_off =
             s_in ? ((excl >> 16) + (wave_off >> 16)) : ((excl & 0xFFFFu) + (wave_off & 0xFFFFu));
-        uint64_t pos = sh.base + lane_off;
-        const uint32_t v0 = (uint32_t)blk_off;
         const uint32_t my_cnt = s_in ? tile_c1 : tile_c0;
-        if (sh.base + my_cnt <= a.capacity) {
-            while (T) {
-                a.idx[pos++] = v0 + (uint32_t)__builtin_ctzll(T);
-                T &= T - 1;
+        const uint64_t base = sh.base;
+        const bool fits = base + my_cnt <= a.capacity;
+        const uint32_t shift = (uint32_t)(base & 3u);  // stage[j] <-> idx[base - shift + j]
+        const uint32_t vend = shift + my_cnt;
+        const uint32_t v0 = (uint32_t)blk_off;
+        uint32_t vpos = shift + lane_off;
+        uint32_t tlo = (uint32_t)T, thi = (uint32_t)(T >> 32);
+        for (uint32_t r0 = 0; r0 < vend; r0 += kStageWords) {
+            const uint32_t r1 = r0 + kStageWords;
+            while (tlo && vpos < r1) {
+                sh.stage[vpos - r0] = v0 + (uint32_t)__builtin_ctz(tlo);
+                tlo &= tlo - 1;
+                vpos++;
             }
-        } else {
-            while (T) {
-                if (pos < a.capacity) a.idx[pos] = v0 + (uint32_t)__builtin_ctzll(T);
-                pos++;
-                T &= T - 1;
+            if (!tlo) {
+                while (thi && vpos < r1) {
+                    sh.stage[vpos - r0] = v0 + 32u + (uint32_t)__builtin_ctz(thi);
+                    thi &= thi - 1;
+                    vpos++;
+                }
             }
+            __syncthreads();
+            const uint32_t lim = vend < r1 ? vend : r1;
+            const uint64_t gbase = base - shift + r0;
+            for (uint32_t q = tid; 4u * q < lim - r0; q += kThreads) {
+                const uint32_t vq = r0 + 4u * q;
+                const uint4 val = *reinterpret_cast<const uint4 *>(&sh.stage[4u * q]);
+                const uint64_t g = gbase + 4u * q;
+                if (fits && vq >= shift && vq + 4u <= lim) {
+                    *reinterpret_cast<uint4 *>(&a.idx[g]) = val;
+                } else {
+                    const uint32_t vv[4] = {val.x, val.y, val.z, val.w};
+#pragma unroll
+                    for (uint32_t j = 0; j < 4; j++) {
+                        const uint32_t v = vq + j;
+                        if (v >= shift && v < lim && g + j < a.capacity) a.idx[g + j] = vv[j];
+                    }
+                }
+            }
+            if (r1 < vend) __syncthreads();
         }
     }
+    MSJ_STAMP(10);
+}
+
+// ---- resolver: one wave turns tile aggregates into tile prefixes, in order ----
+// Monoid: a tile's aggregate is (parity p, count c[q], error e[q]) for incoming
+// in-string state q; composing left to right gives every tile its incoming
+// state and the number of structurals before it.  Up to 64*kResolveE tiles are
+// folded per round: each lane folds kResolveE consecutive aggregates serially
+// (for both values of q), the lanes are combined with a ballot (parity) and a
+// shuffle scan (counts), then every lane walks its tiles again writing their
+// prefix words.  finish() (json_structural_indexer.mojo:147-186) runs here too.
+__device__ void resolver(const KernelArgs &a, const uint32_t lane) {
+    const uint64_t *agg = a.ws + kDescOffset;
+    uint64_t *pre = a.ws + kDescOffset + a.ntiles;
+    const uint32_t ntiles = a.ntiles;
+    const msj_carry cin = *a.carry_in;
+    uint32_t s = cin.in_string & 1u, err = 0, u8 = 0, poison = 0;
+    uint32_t cnt = 0;  // launch-relative, < 2^32 because len < 2^32
+    uint32_t next = 0, idle = 0;
+    bool timeout = false;
+    const uint64_t below = (1ull << lane) - 1ull;
+    while (next < ntiles) {
+        uint64_t d[kResolveE];
+        const uint32_t first = next + lane * kResolveE;
+#pragma unroll
+        for (int e = 0; e < kResolveE; e++) d[e] = (first + e < ntiles) ? ld_desc(&agg[first + e]) : 0ull;
+        uint32_t rl = 0;
+        bool run = true;
+#pragma unroll
+        for (int e = 0; e < kResolveE; e++) {
+            run = run && ((d[e] >> 62) != 0ull);
+            rl += run ? 1u : 0u;
+        }
+        const uint64_t notfull = __ballot(rl < (uint32_t)kResolveE);
+        const uint32_t fl = notfull ? (uint32_t)__builtin_ctzll(notfull) : 64u;
+        const uint32_t act = (lane < fl) ? (uint32_t)kResolveE : ((lane == fl) ? rl : 0u);
+        const uint32_t m = (fl == 64u) ? 64u * kResolveE : fl * kResolveE + (uint32_t)__shfl((int)rl, (int)fl);
+        if (m == 0) {
+            if (++idle > kSpinLimit) {
+                timeout = true;
+                break;
+            }
+            __builtin_amdgcn_s_sleep(4);
+            continue;
+        }
+        idle = 0;
+        // lane aggregate under both incoming states
+        uint32_t s0 = 0, s1 = 1, c_0 = 0, c_1 = 0, e_0 = 0, e_1 = 0, lu = 0, lpoison = 0;
+#pragma unroll
+        for (int e = 0; e < kResolveE; e++) {
+            if ((uint32_t)e < act) {
+                const uint32_t p = (uint32_t)(d[e] >> 61) & 1u;
+                const uint32_t c0 = (uint32_t)d[e] & 0x7FFFu, c1 = (uint32_t)(d[e] >> 15) & 0xFFFFu;
+                const uint32_t e0 = (uint32_t)(d[e] >> 60) & 1u, e1 = (uint32_t)(d[e] >> 59) & 1u;
+                c_0 += s0 ? c1 : c0;
+                e_0 |= s0 ? e1 : e0;
+                s0 ^= p;
+                c_1 += s1 ? c1 : c0;
+                e_1 |= s1 ? e1 : e0;
+                s1 ^= p;
+                lu |= (uint32_t)(d[e] >> 56) & 1u;
+                lpoison |= (uint32_t)(d[e] >> 54) & 1u;
+            }
+        }
+        const uint64_t PM = __ballot((s0 & 1u) != 0u);  // lane parity (inactive lanes: 0)
+        const uint32_t in_l = s ^ ((uint32_t)__popcll(PM & below) & 1u);
+        const uint32_t mycnt = in_l ? c_1 : c_0;
+        uint32_t incl = mycnt;
+#pragma unroll
+        for (int dd = 1; dd < 64; dd <<= 1) {
+            const uint32_t t = __shfl_up(incl, dd);
+            if (lane >= (uint32_t)dd) incl += t;
+        }
+        const uint32_t total = (uint32_t)__shfl((int)incl, 63);
+        const uint64_t EM = __ballot((in_l ? e_1 : e_0) != 0u);
+        const uint64_t UM = __ballot(lu != 0u);
+        const uint64_t XM = __ballot(lpoison != 0u);
+        // walk my tiles again with the real state, publishing each tile's prefix
+        uint32_t cs = in_l, cb = cnt + (incl - mycnt);
+        uint32_t ce = err | ((EM & below) ? 1u : 0u);
+        uint32_t cu = u8 | ((UM & below) ? 1u : 0u);
+#pragma unroll
+        for (int e = 0; e < kResolveE; e++) {
+            if ((uint32_t)e < act) {
+                st_desc(&pre[first + e], kPre | ((uint64_t)cs << 61) | ((uint64_t)ce << 60) |
+                                             ((uint64_t)cu << 56) | (uint64_t)cb);
+                const uint32_t p = (uint32_t)(d[e] >> 61) & 1u;
+                const uint32_t c0 = (uint32_t)d[e] & 0x7FFFu, c1 = (uint32_t)(d[e] >> 15) & 0xFFFFu;
+                const uint32_t e0 = (uint32_t)(d[e] >> 60) & 1u, e1 = (uint32_t)(d[e] >> 59) & 1u;
+                cb += cs ? c1 : c0;
+                ce |= cs ? e1 : e0;
+                cu |= (uint32_t)(d[e] >> 56) & 1u;
+                cs ^= p;
+            }
+        }
+        s ^= (uint32_t)__popcll(PM) & 1u;
+        cnt += total;
+        err |= EM ? 1u : 0u;
+        u8 |= UM ? 1u : 0u;
+        poison |= XM ? 1u : 0u;
+        next += m;
+    }
+    if (timeout) {
+        // release every worker still waiting: status 3 = give up
+        for (uint32_t i = next + lane; i < ntiles; i += 64u) st_desc(&pre[i], 3ull << 62);
+    }
+    if (lane != 0) return;
+
+    // ---- finish(): json_structural_indexer.mojo:147-186
+    const uint64_t last = timeout ? 0ull : ld_desc(&agg[ntiles - 1]);
+    const bool do_utf8 = !(a.flags & kFlagNoUtf8);
+    msj_carry out;
+    const uint64_t n = cin.count + cnt;
+    out.count = n;
+    out.bytes = cin.bytes + a.len;
+    out.in_string = s;
+    out.next_is_escaped = (uint32_t)(last >> 58) & 1u;
+    out.prev_scalar = (uint32_t)(last >> 57) & 1u;
+    out.unescaped_error = (cin.unescaped_error | err) ? 1u : 0u;
+    uint32_t u8e = cin.utf8_error | u8;
+    // a multi-byte sequence cut exactly at the end of the last full tile
+    if ((a.flags & kFlagFinal) && do_utf8 && (a.len % kTileBytes) == 0 && ((last >> 55) & 1u)) u8e = 1;
+    out.utf8_error = u8e ? 1u : 0u;
+    out.internal_error = (cin.internal_error | poison | (timeout ? 1u : 0u)) ? 1u : 0u;
+    int32_t code = MSJ_SUCCESS;
+    if (a.flags & kFlagFinal) {
+        if (out.internal_error) {
+            code = MSJ_UNEXPECTED_ERROR;
+        } else if (s) {
+            code = MSJ_UNCLOSED_STRING;  // :151-155
+        } else if (out.unescaped_error) {
+            code = MSJ_UNESCAPED_CHARS;  // :157-158
+        } else if (n + 3 > a.capacity) {
+            code = MSJ_CAPACITY;
+        } else {
+            if (!(a.flags & kFlagNoEmit)) {
+                a.idx[n] = (uint32_t)a.trailer_len;      // :167-169
+                a.idx[n + 1] = (uint32_t)a.trailer_len;  // :170-172
+                a.idx[n + 2] = 0;                        // :173
+            }
+            if (n == 0)
+                code = MSJ_EMPTY;  // :176-177
+            else if ((a.flags & kFlagStrictUtf8) && out.utf8_error)
+                code = MSJ_UTF8_ERROR;
+        }
+    }
+    out.code = code;
+    for (int k = 0; k < 5; k++) out.reserved[k] = 0;
+    *a.carry_out = out;
+    if (a.segment) {
+        a.segment->byte_base = a.segment_byte_base;
+        a.segment->byte_len = a.len;
+        a.segment->index_begin = cin.count;
+        a.segment->count = cnt;
+    }
+}
+
+__global__ __launch_bounds__(kThreads) void stage1_kernel(const KernelArgs a) {
+    __shared__ Shared sh;
+    const uint32_t tid = threadIdx.x;
+    // ---- ordered ticket: ticket 0 is the resolver, ticket t+1 works on tile t.  A
+    //      workgroup only holds a ticket once it is running, so everything a
+    //      waiter depends on (earlier tiles, the resolver) is resident or done.
+    if (tid == 0) {
+        sh.tile = atomicAdd(reinterpret_cast<unsigned int *>(a.ws), 1u);
+        sh.timeout = 0;
+    }
+    __syncthreads();
+    const uint32_t ticket = sh.tile;
+    if (ticket == 0) {
+        if (tid < 64u) resolver(a, tid);
+        return;
+    }
+    worker(a, sh, ticket - 1u);
 }
 
 }  // namespace msj
 
 extern "C" int msj_launch_stage1(const msj::KernelArgs *args, void *stream) {
     const msj::KernelArgs a = *args;
-    hipLaunchKernelGGL(msj::stage1_kernel, dim3(a.ntiles), dim3(msj::kThreads), 0,
+    // one workgroup per tile plus the resolver (ticket 0)
+    hipLaunchKernelGGL(msj::stage1_kernel, dim3(a.ntiles + 1u), dim3(msj::kThreads), 0,
                        static_cast<hipStream_t>(stream), a);
     return (int)hipGetLastError();
 }

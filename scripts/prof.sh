@@ -1,0 +1,25 @@
+#!/bin/bash
+# rocprofv3 passes for the bench workload (run on the GPU box via gpurun).
+#   scripts/prof.sh <tag> [bench args...]
+# Writes CSVs under gpurun_out/prof/<tag>/ ; copy the summaries you keep to profiles/.
+# Counter passes are separate from --kernel-trace --stats (gpurun refuses mixed
+# trace domains with --pmc), and FETCH_SIZE / WRITE_SIZE need separate passes
+# (TCC slots, MI355X_MICROARCH.md "rocprofv3 PMC slots").
+set -o pipefail
+TAG=${1:-run}; shift
+cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
+OUT=gpurun_out/prof/$TAG
+mkdir -p "$OUT"
+ARGS="--steps 5 --warmup 1 --no-cpu-baseline $*"
+timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/kt" -- python3 bench.py $ARGS > "$OUT/kt.log" 2>&1 || { echo "kernel-trace pass failed"; tail -5 "$OUT/kt.log"; exit 1; }
+i=0
+for PMC in "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU" \
+           "SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_LDS SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_INST_CYCLES_SALU" \
+           "FETCH_SIZE GRBM_GUI_ACTIVE" \
+           "WRITE_SIZE GRBM_GUI_ACTIVE" \
+           "TCC_HIT_sum TCC_MISS_sum" \
+           "TCP_TCC_READ_REQ_sum TCP_TCC_WRITE_REQ_sum TCP_TOTAL_ACCESSES_sum"; do
+  i=$((i+1))
+  timeout -k 10 200 rocprofv3 --pmc $PMC --output-format csv -d "$OUT/pmc$i" -- python3 bench.py $ARGS > "$OUT/pmc$i.log" 2>&1 || { echo "pmc pass $i ($PMC) failed"; tail -3 "$OUT/pmc$i.log"; }
+done
+python3 scripts/prof_summary.py "$OUT" | tee "$OUT/summary.txt"

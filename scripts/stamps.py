@@ -1,0 +1,61 @@
+#!/usr/bin/env python3
+"""Diagnostic: where a tile spends its cycles (per-phase s_memtime stamps).
+
+Uses the -DMSJ_STAMPS build (make -C mojo_simdjson_amd/csrc stamps), loaded
+directly with ctypes -- the product library never contains stamps.  Shares, not
+absolute times, are what to read (the stamps themselves perturb the kernel).
+"""
+import ctypes
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from mojo_simdjson_amd import _lib, synth  # noqa: E402
+
+PHASES = ["loads", "planes+classify", "wait B1", "strings -> B2", "counts -> B3",
+          "publish agg", "wait prefix (wave0)", "wait B4", "emit (LDS staged)"]
+
+
+def main():
+    workload = sys.argv[1] if len(sys.argv) > 1 else "minified"
+    _lib._share_torch_hip_runtime()
+    lib = ctypes.CDLL(os.path.join(ROOT, "mojo_simdjson_amd", "libmsj_stage1_stamps.so"))
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(0)
+    u = synth.workload(workload, 64 << 20)
+    d_unit = torch.from_numpy(u).to(dev)
+    d_buf = d_unit.repeat((1 << 30) // u.size)
+    n = d_buf.numel()
+    ntiles = (n + 16383) // 16384
+    stamps = torch.zeros(ntiles * 16, dtype=torch.int64, device=dev)
+    d_idx = torch.empty(int(n * 0.75), dtype=torch.int32, device=dev)
+    d_res = torch.zeros(64, dtype=torch.uint8, device=dev)
+    h = ctypes.c_void_p()
+    assert lib.msj_ctx_create(0, ctypes.byref(h)) == 0
+    lib.msj_debug_set_stamps(ctypes.c_void_p(stamps.data_ptr()))
+    lib.msj_stage1_device.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint64, ctypes.c_void_p,
+                                      ctypes.c_uint64, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint32]
+    for _ in range(3):
+        rc = lib.msj_stage1_device(h, d_buf.data_ptr(), n, d_idx.data_ptr(), d_idx.numel(),
+                                   d_res.data_ptr(), None, 0)
+        assert rc == 0
+        torch.cuda.synchronize()
+    s = stamps.cpu().numpy().reshape(ntiles, 16)[:, 1:11].astype(np.int64)
+    d = np.diff(s, axis=1)
+    life = s[:, 9] - s[:, 0]
+    print(f"workload {workload}: {ntiles} tiles; tile lifetime median {np.median(life):.0f} ticks, "
+          f"p90 {np.percentile(life, 90):.0f}")
+    span = s[:, 9].max() - s[:, 0].min()
+    print(f"kernel span {span} ticks; sum of lifetimes / span = {life.sum() / span:.1f} tiles in flight")
+    for k, name in enumerate(PHASES):
+        print(f"  {name:20s} median {np.median(d[:, k]):9.0f}  mean {d[:, k].mean():9.0f}  "
+              f"share {100 * d[:, k].sum() / life.sum():5.1f} %")
+    lib.msj_ctx_destroy(h)
+
+
+if __name__ == "__main__":
+    main()
