@@ -27,6 +27,7 @@ struct msj_ctx {
     uint32_t *d_idx = nullptr;
     uint64_t d_idx_words = 0;
     msj_carry *d_result = nullptr;
+    uint32_t grid = 0;            // persistent workgroups per launch (CUs x resident blocks per CU)
 };
 
 namespace {
@@ -95,7 +96,7 @@ int32_t enqueue_shard(msj_ctx *ctx, const uint8_t *d_buf, uint64_t len, uint32_t
         if (!hip_ok(hipMemsetAsync(ctx->ws, 0, msj::workspace_words(a.ntiles) * sizeof(uint64_t),
                                    stream)))
             return MSJ_ERR_HIP;
-        if (msj_launch_stage1(&a, stream) != 0) return MSJ_ERR_HIP;
+        if (msj_launch_stage1(&a, stream, ctx->grid) != 0) return MSJ_ERR_HIP;
     }
     if (n_segments_out) *n_segments_out = (uint32_t)nseg;
     return MSJ_SUCCESS;
@@ -128,6 +129,16 @@ int32_t msj_ctx_create(int32_t device, msj_ctx **out) {
     msj_ctx *ctx = new (std::nothrow) msj_ctx();
     if (!ctx) return MSJ_MEMALLOC;
     ctx->device = device;
+    {
+        // persistent grid: fill every CU to the kernel's occupancy
+        hipDeviceProp_t prop;
+        int per_cu = 0;
+        if (hip_ok(hipGetDeviceProperties(&prop, device)) && msj_stage1_occupancy(&per_cu) == 0 &&
+            per_cu > 0)
+            ctx->grid = (uint32_t)prop.multiProcessorCount * (uint32_t)per_cu;
+        else
+            ctx->grid = 1024;
+    }
     ctx->n_carries = kMaxChain + 2;
     if (!hip_ok(hipMalloc(reinterpret_cast<void **>(&ctx->carries),
                           ctx->n_carries * sizeof(msj_carry))) ||

@@ -12,7 +12,8 @@ constexpr int kThreads = kWaves * 64;              // 256 lanes, one 64-byte blo
 constexpr uint32_t kTileBytes = kThreads * 64u;    // 16 KiB of input per workgroup
 constexpr uint32_t kDescOffset = 8;                // ws[0] = ticket, ws[8..] = agg[ntiles], pre[ntiles]
 constexpr uint32_t kStageWords = 4096;             // LDS staging of indices (16 KiB) per round
-constexpr int kResolveE = 8;                       // tiles folded per resolver lane per round
+constexpr int kResolveE = 4;                       // tiles folded per resolver lane
+constexpr uint32_t kResolveChunk = 64u * kResolveE; // tiles per resolver chunk (one wave, one round)
 constexpr uint32_t kSpinLimit = 1u << 22;          // bounded look-back polling (internal_error on expiry)
 // largest segment one launch indexes with uint32 offsets (multiple of the tile)
 constexpr uint64_t kSegmentBytes = 0xFFFF0000ull;
@@ -44,4 +45,6 @@ inline uint64_t workspace_words(uint32_t ntiles) { return (uint64_t)kDescOffset 
 
 }  // namespace msj
 
-extern "C" int msj_launch_stage1(const msj::KernelArgs *args, void *stream);
+// grid = number of persistent workgroups (0 = one per tile); clamped to ntiles + 1.
+extern "C" int msj_launch_stage1(const msj::KernelArgs *args, void *stream, uint32_t grid);
+extern "C" int msj_stage1_occupancy(int *blocks_per_cu);

@@ -5,23 +5,32 @@
 //   (src/mojo_simdjson/generic/stage1/json_structural_indexer.mojo:81-186)
 // by one kernel launch over the whole buffer:
 //
-//   * a workgroup (4 wave64 = 256 lanes) owns one 16 KiB tile; every lane owns
-//     one 64-byte block = the unit of one JsonScanner.next call, and all masks
-//     are uint64 with the reference's bit order (lane_math.h);
+//   * persistent workgroups (4 wave64 = 256 lanes) draw 16 KiB tiles from an
+//     ordered ticket counter; every lane owns one 64-byte block = the unit of one
+//     JsonScanner.next call, and all masks are uint64 with the reference's bit
+//     order (lane_math.h);
 //   * the three 1-bit carries the reference threads through its loop
 //     (next_is_escaped json_escape_scanner.mojo:13, prev_in_string
 //     json_string_scanner.mojo:49, prev_scalar json_scanner.mojo:57) are
 //     resolved lane -> wave -> workgroup with __ballot + a 64-bit
 //     carry-lookahead add (escape), ballot/mbcnt prefix parity (in-string) and
-//     a one-lane shuffle (prev_scalar);
-//   * across tiles only the in-string bit and the running structural count
-//     are chained, with a decoupled look-back over 64-bit tile descriptors
-//     (one relaxed agent-scope 8-byte store / load per hop: the data is the
-//     flag); the escape / prev_scalar carries into a tile are derived locally
-//     from the 64 bytes in front of it;
+//     a one-lane shuffle (prev_scalar); the escape / prev_scalar carries into a
+//     tile are derived locally from the 64 bytes in front of it;
+//   * across tiles only the in-string bit and the running structural count are
+//     chained.  Each tile publishes a 64-bit aggregate (parity, count and error
+//     bit for both possible incoming in-string states); the workgroup holding
+//     ticket 0 does not index anything: it is the RESOLVER, whose four waves
+//     fold those aggregates in order (chunks of 256 tiles, pipelined across the
+//     waves, state handed over through LDS) and publish every tile's prefix.
+//     Workers poll one word.  All words are relaxed agent-scope 8-byte
+//     stores/loads: the data is the flag;
 //   * BitIndexer.write (json_structural_indexer.mojo:46-58) becomes a packed
-//     (count|count<<16) wave scan and a per-lane ctz loop that writes the
-//     ascending offsets straight to their final position.
+//     (count|count<<16) wave scan, a per-lane ctz loop into an LDS staging
+//     buffer at the index's tile-relative position, and aligned 16-byte stores;
+//   * software pipeline per workgroup: the ticket after next and the next
+//     tile's bytes are requested before the current tile is computed, and the
+//     index emission of tile i is deferred until tile i+1 has been computed, so
+//     ticket, HBM and prefix latencies overlap with compute.
 //
 // No MFMA (nothing here is a contraction); integer/bitwise work on u8 input,
 // u64 masks, u32 output.
@@ -35,16 +44,15 @@
 namespace msj {
 
 // ---- tile descriptors -------------------------------------------------------
-// One 64-bit word per tile in each of two arrays (the data is the flag: one
-// relaxed agent-scope 8-byte store, polled with relaxed agent-scope loads).
+// One 64-bit word per tile in each of two arrays.
 // bits 63:62 status: 0 = not ready
 // agg[t] (written by the tile's workgroup), status 1:
 //   61 quote parity, 60 err(s_in=0), 59 err(s_in=1), 58 e_out, 57 ps_out,
 //   56 utf8 err, 55 utf8 sequence pending at tile end, 54 poisoned (timeout),
 //   30:15 count(s_in=1), 14:0 count(s_in=0)
-// pre[t] (written by the resolver), status 2 (3 = resolver gave up):
+// pre[t] (written by the resolver), status 2:
 //   61 in_string before the tile, 60 unescaped err before, 56 utf8 err before,
-//   31:0 structurals before the tile (launch-relative)
+//   54 poisoned, 31:0 structurals before the tile (launch-relative)
 constexpr uint64_t kAgg = 1ull << 62;
 constexpr uint64_t kPre = 2ull << 62;
 
@@ -67,16 +75,17 @@ __device__ __forceinline__ uint32_t wave_sum(uint32_t v) {
 
 #ifdef MSJ_STAMPS
 // Diagnostic build only: phase timestamps per tile (never compiled into the product .so).
-#define MSJ_STAMP(k)                                                                      \
+#define MSJ_STAMP(t, k)                                                                   \
     do {                                                                                  \
-        if (tid == 0 && a.stamps) a.stamps[(uint64_t)stamp_tile * 16 + (k)] = __builtin_amdgcn_s_memtime(); \
+        if (threadIdx.x == 0 && a.stamps)                                                 \
+            a.stamps[(uint64_t)(t) * 16 + (k)] = __builtin_amdgcn_s_memtime();            \
     } while (0)
 #else
-#define MSJ_STAMP(k) do {} while (0)
+#define MSJ_STAMP(t, k) do {} while (0)
 #endif
 
 struct Shared {
-    uint32_t tile;
+    uint32_t tk[4];          // tickets: [0],[1] initial pair, [2] the one requested last
     uint32_t tile_e_in, tile_ps_in, tile_u8_in;
     uint32_t esc[kWaves];    // bit0 = escape carry-out if carry-in 0, bit1 = if carry-in 1
     uint32_t par[kWaves];    // quote parity of the wave
@@ -87,6 +96,8 @@ struct Shared {
     uint32_t s_in;
     uint32_t timeout;
     uint64_t base;           // absolute output position of the tile's first index
+    // resolver hand-off between its waves
+    uint32_t rs_seq, rs_s, rs_cnt, rs_err, rs_u8, rs_poison;
     uint32_t stage[kStageWords] __attribute__((aligned(16)));  // index staging for coalesced stores
 };
 
@@ -105,53 +116,68 @@ __device__ __forceinline__ uint64_t wait_desc(const uint64_t *p, uint32_t *timeo
     return d;
 }
 
-__device__ __forceinline__ void worker(const KernelArgs &a, Shared &sh, const uint32_t tile) {
+// The 64 bytes one lane owns, as loaded (4 x 16 B).
+struct Block {
+    uint4 q[4];
+    uint32_t wb;  // wave 0 only: byte [tile_start - 64 + lane] (the look-back window)
+};
+
+__device__ __forceinline__ void load_block(const KernelArgs &a, uint32_t tile, Block &b) {
+    const uint64_t blk_off = (uint64_t)tile * kTileBytes + (uint64_t)threadIdx.x * 64u;
+    const uint4 *src = reinterpret_cast<const uint4 *>(a.buf + blk_off);
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        if (blk_off + 16u * k < a.len)  // a 16-B piece that starts inside the input (buf is 16-B aligned)
+            b.q[k] = src[k];
+        else
+            b.q[k] = make_uint4(0, 0, 0, 0);
+    }
+    b.wb = 0;
+    if (threadIdx.x < 64u && ((tile > 0) || (a.flags & kFlagHasPrefix)))
+        b.wb = a.buf[(int64_t)tile * kTileBytes - 64 + (int64_t)threadIdx.x];
+}
+
+// What a computed tile keeps in registers until its indices are emitted.
+struct Pending {
+    uint64_t T0, T1;     // structural_start masks for tile s_in = 0 / 1
+    uint32_t inc, pk;    // packed inclusive wave scan / own packed count
+    uint32_t wave_off;   // packed counts of the waves before mine
+    uint32_t tile_cnt;   // packed tile totals
+    uint32_t tile;
+};
+
+// ---- one tile: masks, carries, counts; publishes the tile aggregate ------------
+__device__ __forceinline__ Pending compute_tile(const KernelArgs &a, Shared &sh, const uint32_t tile,
+                                                const Block &blk, const uint32_t next_ticket_reg) {
     const uint32_t tid = threadIdx.x;
     const uint32_t lane = tid & 63u;
     const uint32_t wave = tid >> 6;
-#ifdef MSJ_STAMPS
-    const uint32_t stamp_tile = tile;
-#endif
-    MSJ_STAMP(1);
     uint64_t *agg = a.ws + kDescOffset;
-    const uint64_t *pre = a.ws + kDescOffset + a.ntiles;
     const uint64_t len = a.len;
     const uint64_t tile_start = (uint64_t)tile * kTileBytes;
     const uint64_t blk_off = tile_start + (uint64_t)tid * 64u;
+    MSJ_STAMP(tile, 1);
 
-    // ---- load this lane's 64-byte block (4 x 16 B), bytes past the end masked
     uint32_t x[16];
-    uint64_t valid;
-    {
-        const uint4 *src = reinterpret_cast<const uint4 *>(a.buf + blk_off);
-        uint4 q[4];
 #pragma unroll
-        for (int k = 0; k < 4; k++) {
-            if (blk_off + 16u * k < len)
-                q[k] = src[k];
-            else
-                q[k] = make_uint4(0, 0, 0, 0);
-        }
-#pragma unroll
-        for (int k = 0; k < 4; k++) {
-            x[4 * k + 0] = q[k].x;
-            x[4 * k + 1] = q[k].y;
-            x[4 * k + 2] = q[k].z;
-            x[4 * k + 3] = q[k].w;
-        }
-        if (blk_off + 64u <= len)
-            valid = ~0ull;
-        else if (blk_off < len)
-            valid = (1ull << (len - blk_off)) - 1ull;
-        else
-            valid = 0ull;
+    for (int k = 0; k < 4; k++) {
+        x[4 * k + 0] = blk.q[k].x;
+        x[4 * k + 1] = blk.q[k].y;
+        x[4 * k + 2] = blk.q[k].z;
+        x[4 * k + 3] = blk.q[k].w;
     }
+    uint64_t valid;  // bytes past the end behave as the reference's 0x20 padding (:103-107)
+    if (blk_off + 64u <= len)
+        valid = ~0ull;
+    else if (blk_off < len)
+        valid = (1ull << (len - blk_off)) - 1ull;
+    else
+        valid = 0ull;
 
     // ---- wave 0: carries into the tile from the 64 bytes in front of it
     const bool have_window = (tile > 0) || (a.flags & kFlagHasPrefix);
     if (wave == 0) {
-        uint32_t wb = 0;
-        if (have_window) wb = a.buf[(int64_t)tile_start - 64 + (int64_t)lane];
+        const uint32_t wb = blk.wb;
         uint32_t e_in, ps_in, u8_in;
         // utf8 carry word of the window's last bytes (lane_math.h layout)
         {
@@ -188,15 +214,15 @@ __device__ __forceinline__ void worker(const KernelArgs &a, Shared &sh, const ui
             } else if (!((WQ >> 63) & 1u)) {
                 ps_in = 1u;
             } else {
-                // byte[-1] is '"': a real quote unless escaped by an odd run before it
-                const uint32_t r2 = top_run((WB << 1) | 1ull) - 0u;  // run ending at byte[-2]
-                // (WB<<1)|1 has bit0 forced: r2 == 64 means bits 1..63 all set
+                // byte[-1] is '"': a real quote unless escaped by an odd run before it.
+                // (WB<<1)|1 has bit 0 forced: a result of 64 means bits 1..63 are all set.
+                const uint32_t r2 = top_run((WB << 1) | 1ull);  // run ending at byte[-2]
                 if (r2 == 64u) resolved = false;
                 ps_in = r2 & 1u;
             }
             if (!resolved) {
                 // >= 62 consecutive backslashes in front of the tile: take the exact
-                // carries the predecessor publishes with its descriptor.
+                // carries the predecessor publishes with its aggregate.
                 uint32_t to = 0;
                 const uint64_t d = wait_desc(&agg[tile - 1], &to);
                 if (to && lane == 0) sh.timeout = 1;
@@ -211,7 +237,7 @@ __device__ __forceinline__ void worker(const KernelArgs &a, Shared &sh, const ui
         }
     }
 
-    MSJ_STAMP(2);
+    MSJ_STAMP(tile, 2);
     // ---- bit-planes and character classes (lane_math.h)
     uint64_t p[8];
     bitplanes(x, p);
@@ -232,12 +258,16 @@ __device__ __forceinline__ void worker(const KernelArgs &a, Shared &sh, const ui
         const uint32_t c1 = (uint32_t)(((add_a & add_b) | ((add_a | add_b) & ~s1)) >> 63);
         if (lane == 0) sh.esc[wave] = c0 | (c1 << 1);
     }
-    MSJ_STAMP(3);
+    MSJ_STAMP(tile, 3);
     __syncthreads();  // B1: tile carries + per-wave escape transfer published
-    MSJ_STAMP(4);
+    MSJ_STAMP(tile, 4);
 
     uint32_t wave_e_in = sh.tile_e_in;
     for (uint32_t w = 0; w < wave; w++) wave_e_in = (sh.esc[w] >> wave_e_in) & 1u;
+    // escape carry out of the whole tile (kept in a register: sh.esc is rewritten by
+    // the next tile before every wave has passed the last barrier of this one)
+    uint32_t tile_e_out = wave_e_in;
+    for (uint32_t w = wave; w < kWaves; w++) tile_e_out = (sh.esc[w] >> tile_e_out) & 1u;
     const uint64_t carries = (add_a + add_b + wave_e_in) ^ add_a ^ add_b;
     const uint32_t lane_e_in = (uint32_t)(carries >> lane) & 1u;
 
@@ -270,7 +300,7 @@ __device__ __forceinline__ void worker(const KernelArgs &a, Shared &sh, const ui
         sh.par[wave] = (uint32_t)__popcll(PM) & 1u;
     }
     __syncthreads();  // B2: wave parities / prev_scalar / utf8 carries published
-    MSJ_STAMP(5);
+    MSJ_STAMP(tile, 5);
 
     uint32_t wave_par = 0;
     for (uint32_t w = 0; w < wave; w++) wave_par ^= sh.par[w];
@@ -278,27 +308,31 @@ __device__ __forceinline__ void worker(const KernelArgs &a, Shared &sh, const ui
         prev_ps = (wave == 0) ? sh.tile_ps_in : sh.ps[wave - 1];
         prev_u8c = (wave == 0) ? sh.tile_u8_in : sh.u8c[wave - 1];
     }
+    const uint32_t tile_ps_out = sh.ps[kWaves - 1];
+    const uint32_t tile_pend = (sh.u8c[kWaves - 1] & 0x3Fu) ? 1u : 0u;
     const uint64_t lane_in = (uint64_t)(-(int64_t)(lane_par ^ wave_par));  // all-ones: inside a string
     // in_string / string_tail assuming the TILE starts outside a string
     const uint64_t in_string0 = S0 ^ lane_in;
     const uint64_t string_tail0 = in_string0 ^ quote;  // json_string_scanner.mojo:40-44
     const uint64_t follows = (nqs << 1) | prev_ps;     // json_scanner.mojo:76-79
     const uint64_t potential = cls.op | (scalar & ~follows);
-    const uint64_t T0 = potential & ~string_tail0;  // structural_start if tile s_in = 0
-    const uint64_t T1 = potential & string_tail0;   //                  if tile s_in = 1
+    Pending r;
+    r.T0 = potential & ~string_tail0;  // structural_start if tile s_in = 0
+    r.T1 = potential & string_tail0;   //                  if tile s_in = 1
     const bool err0 = (cls.ctrl & in_string0) != 0;   // json_structural_indexer.mojo:143-145
     const bool err1 = (cls.ctrl & ~in_string0) != 0;
     bool u8err = false;
     if (do_utf8) u8err = utf8_errors(p, u8p, prev_u8c) != 0;
 
     // ---- packed inclusive scan of the per-lane structural counts
-    const uint32_t pk = (uint32_t)__popcll(T0) | ((uint32_t)__popcll(T1) << 16);
-    uint32_t inc = pk;
+    r.pk = (uint32_t)__popcll(r.T0) | ((uint32_t)__popcll(r.T1) << 16);
+    uint32_t inc = r.pk;
 #pragma unroll
     for (int d = 1; d < 64; d <<= 1) {
         const uint32_t t = __shfl_up(inc, d);
         if (lane >= (uint32_t)d) inc += t;
     }
+    r.inc = inc;
     {
         const uint64_t me0 = __ballot(err0), me1 = __ballot(err1), mu8 = __ballot(u8err);
         if (lane == 63) {
@@ -306,8 +340,9 @@ __device__ __forceinline__ void worker(const KernelArgs &a, Shared &sh, const ui
             sh.flg[wave] = (me0 ? 1u : 0u) | (me1 ? 2u : 0u) | (mu8 ? 4u : 0u);
         }
     }
+    if (tid == 0) sh.tk[2] = next_ticket_reg;  // the ticket requested before this tile (arrived by now)
     __syncthreads();  // B3: wave totals published
-    MSJ_STAMP(6);
+    MSJ_STAMP(tile, 6);
 
     uint32_t wave_off = 0, tile_cnt = 0, tile_flg = 0, tile_par = 0;
 #pragma unroll
@@ -317,153 +352,170 @@ __device__ __forceinline__ void worker(const KernelArgs &a, Shared &sh, const ui
         tile_flg |= sh.flg[w];
         tile_par ^= sh.par[w];
     }
-    const uint32_t tile_c0 = tile_cnt & 0xFFFFu, tile_c1 = tile_cnt >> 16;
-
-    // ---- wave 0: publish the tile aggregate, then wait for the resolver's prefix
-    if (wave == 0) {
-        uint32_t tile_e_out = sh.tile_e_in;
-        for (uint32_t w = 0; w < kWaves; w++) tile_e_out = (sh.esc[w] >> tile_e_out) & 1u;
-        const uint32_t tile_ps_out = sh.ps[kWaves - 1];
-        const uint32_t pend = (sh.u8c[kWaves - 1] & 0x3Fu) ? 1u : 0u;
-        if (lane == 0) {
-            st_desc(&agg[tile], kAgg | ((uint64_t)tile_par << 61) |
-                                    ((uint64_t)(tile_flg & 1u) << 60) |
-                                    ((uint64_t)((tile_flg >> 1) & 1u) << 59) |
-                                    ((uint64_t)tile_e_out << 58) | ((uint64_t)tile_ps_out << 57) |
-                                    ((uint64_t)((tile_flg >> 2) & 1u) << 56) |
-                                    ((uint64_t)pend << 55) | ((uint64_t)sh.timeout << 54) |
-                                    ((uint64_t)tile_c1 << 15) | (uint64_t)tile_c0);
-        }
-        MSJ_STAMP(7);
-        uint32_t to = 0;
-        const uint64_t d = wait_desc(&pre[tile], &to);
-        if (lane == 0) {
-            sh.s_in = (uint32_t)(d >> 61) & 1u;
-            sh.base = a.carry_in->count + (uint64_t)(uint32_t)d;
-            if (to || (d >> 62) == 3u) sh.timeout = 1;
-        }
+    r.wave_off = wave_off;
+    r.tile_cnt = tile_cnt;
+    r.tile = tile;
+    if (tid == 0) {
+        st_desc(&agg[tile], kAgg | ((uint64_t)tile_par << 61) | ((uint64_t)(tile_flg & 1u) << 60) |
+                                ((uint64_t)((tile_flg >> 1) & 1u) << 59) |
+                                ((uint64_t)tile_e_out << 58) | ((uint64_t)tile_ps_out << 57) |
+                                ((uint64_t)((tile_flg >> 2) & 1u) << 56) |
+                                ((uint64_t)tile_pend << 55) | ((uint64_t)sh.timeout << 54) |
+                                ((uint64_t)(tile_cnt >> 16) << 15) | (uint64_t)(tile_cnt & 0xFFFFu));
     }
-    MSJ_STAMP(8);
-    __syncthreads();  // B4: s_in / base known to every wave
-    MSJ_STAMP(9);
-
-    // ---- BitIndexer.write (json_structural_indexer.mojo:46-58): the ascending offsets
-    //      are staged in LDS at their tile-relative position and written out as
-    //      aligned 16-byte stores (one L2 request per 64 B instead of one per index).
-    if (!(a.flags & kFlagNoEmit) && !sh.timeout) {
-        const uint32_t s_in = sh.s_in;
-        const uint64_t T = s_in ? T1 : T0;
-        const uint32_t excl = inc - pk;
-        const uint32_t lane_off =
-            s_in ? ((excl >> 16) + (wave_off >> 16)) : ((excl & 0xFFFFu) + (wave_off & 0xFFFFu));
-        const uint32_t my_cnt = s_in ? tile_c1 : tile_c0;
-        const uint64_t base = sh.base;
-        const bool fits = base + my_cnt <= a.capacity;
-        const uint32_t shift = (uint32_t)(base & 3u);  // stage[j] <-> idx[base - shift + j]
-        const uint32_t vend = shift + my_cnt;
-        const uint32_t v0 = (uint32_t)blk_off;
-        uint32_t vpos = shift + lane_off;
-        uint32_t tlo = (uint32_t)T, thi = (uint32_t)(T >> 32);
-        for (uint32_t r0 = 0; r0 < vend; r0 += kStageWords) {
-            const uint32_t r1 = r0 + kStageWords;
-            while (tlo && vpos < r1) {
-                sh.stage[vpos - r0] = v0 + (uint32_t)__builtin_ctz(tlo);
-                tlo &= tlo - 1;
-                vpos++;
-            }
-            if (!tlo) {
-                while (thi && vpos < r1) {
-                    sh.stage[vpos - r0] = v0 + 32u + (uint32_t)__builtin_ctz(thi);
-                    thi &= thi - 1;
-                    vpos++;
-                }
-            }
-            __syncthreads();
-            const uint32_t lim = vend < r1 ? vend : r1;
-            const uint64_t gbase = base - shift + r0;
-            for (uint32_t q = tid; 4u * q < lim - r0; q += kThreads) {
-                const uint32_t vq = r0 + 4u * q;
-                const uint4 val = *reinterpret_cast<const uint4 *>(&sh.stage[4u * q]);
-                const uint64_t g = gbase + 4u * q;
-                if (fits && vq >= shift && vq + 4u <= lim) {
-                    *reinterpret_cast<uint4 *>(&a.idx[g]) = val;
-                } else {
-                    const uint32_t vv[4] = {val.x, val.y, val.z, val.w};
-#pragma unroll
-                    for (uint32_t j = 0; j < 4; j++) {
-                        const uint32_t v = vq + j;
-                        if (v >= shift && v < lim && g + j < a.capacity) a.idx[g + j] = vv[j];
-                    }
-                }
-            }
-            if (r1 < vend) __syncthreads();
-        }
-    }
-    MSJ_STAMP(10);
+    MSJ_STAMP(tile, 7);
+    return r;
 }
 
-// ---- resolver: one wave turns tile aggregates into tile prefixes, in order ----
-// Monoid: a tile's aggregate is (parity p, count c[q], error e[q]) for incoming
-// in-string state q; composing left to right gives every tile its incoming
-// state and the number of structurals before it.  Up to 64*kResolveE tiles are
-// folded per round: each lane folds kResolveE consecutive aggregates serially
-// (for both values of q), the lanes are combined with a ballot (parity) and a
-// shuffle scan (counts), then every lane walks its tiles again writing their
-// prefix words.  finish() (json_structural_indexer.mojo:147-186) runs here too.
-__device__ void resolver(const KernelArgs &a, const uint32_t lane) {
+// ---- BitIndexer.write (json_structural_indexer.mojo:46-58) for one computed tile:
+//      wait for the tile's prefix, stage the ascending offsets in LDS at their
+//      tile-relative position, write them out as aligned 16-byte stores (one L2
+//      request per 64 B instead of one per index).
+__device__ __forceinline__ void emit_tile(const KernelArgs &a, Shared &sh, const Pending &r) {
+    const uint32_t tid = threadIdx.x;
+    const uint64_t *pre = a.ws + kDescOffset + a.ntiles;
+    MSJ_STAMP(r.tile, 8);
+    if (tid < 64u) {
+        uint32_t to = 0;
+        const uint64_t d = wait_desc(&pre[r.tile], &to);
+        if (tid == 0) {
+            sh.s_in = (uint32_t)(d >> 61) & 1u;
+            sh.base = a.carry_in->count + (uint64_t)(uint32_t)d;
+            if (to || ((d >> 54) & 1u)) sh.timeout = 1;
+        }
+    }
+    MSJ_STAMP(r.tile, 9);
+    __syncthreads();  // B4: s_in / base known to every wave
+    if ((a.flags & kFlagNoEmit) || sh.timeout) {
+        __syncthreads();  // keep sh.s_in / sh.base stable until everyone has read them
+        return;
+    }
+    const uint32_t s_in = sh.s_in;
+    const uint64_t base = sh.base;
+    const uint64_t T = s_in ? r.T1 : r.T0;
+    const uint32_t excl = r.inc - r.pk;
+    const uint32_t lane_off =
+        s_in ? ((excl >> 16) + (r.wave_off >> 16)) : ((excl & 0xFFFFu) + (r.wave_off & 0xFFFFu));
+    const uint32_t my_cnt = s_in ? (r.tile_cnt >> 16) : (r.tile_cnt & 0xFFFFu);
+    const bool fits = base + my_cnt <= a.capacity;
+    const uint32_t shift = (uint32_t)(base & 3u);  // stage[j] <-> idx[base - shift + j]
+    const uint32_t vend = shift + my_cnt;
+    const uint32_t v0 = (uint32_t)((uint64_t)r.tile * kTileBytes) + tid * 64u;
+    uint32_t vpos = shift + lane_off;
+    uint32_t tlo = (uint32_t)T, thi = (uint32_t)(T >> 32);
+    for (uint32_t r0 = 0; r0 < vend; r0 += kStageWords) {
+        const uint32_t r1 = r0 + kStageWords;
+        while (tlo && vpos < r1) {
+            sh.stage[vpos - r0] = v0 + (uint32_t)__builtin_ctz(tlo);
+            tlo &= tlo - 1;
+            vpos++;
+        }
+        if (!tlo) {
+            while (thi && vpos < r1) {
+                sh.stage[vpos - r0] = v0 + 32u + (uint32_t)__builtin_ctz(thi);
+                thi &= thi - 1;
+                vpos++;
+            }
+        }
+        __syncthreads();
+        const uint32_t lim = vend < r1 ? vend : r1;
+        const uint64_t gbase = base - shift + r0;
+        for (uint32_t q = tid; 4u * q < lim - r0; q += kThreads) {
+            const uint32_t vq = r0 + 4u * q;
+            const uint4 val = *reinterpret_cast<const uint4 *>(&sh.stage[4u * q]);
+            const uint64_t g = gbase + 4u * q;
+            if (fits && vq >= shift && vq + 4u <= lim) {
+                *reinterpret_cast<uint4 *>(&a.idx[g]) = val;
+            } else {
+                const uint32_t vv[4] = {val.x, val.y, val.z, val.w};
+#pragma unroll
+                for (uint32_t j = 0; j < 4; j++) {
+                    const uint32_t v = vq + j;
+                    if (v >= shift && v < lim && g + j < a.capacity) a.idx[g + j] = vv[j];
+                }
+            }
+        }
+        __syncthreads();  // stage is reused by the next round / next tile
+    }
+    if (vend == 0) __syncthreads();  // same barrier count on the empty path as on the timeout path
+    MSJ_STAMP(r.tile, 10);
+}
+
+// ---- resolver: the four waves of one workgroup turn tile aggregates into tile
+// prefixes, in order.  Monoid: a tile's aggregate is (parity p, count c[q], error
+// e[q]) for incoming in-string state q; composing left to right gives every tile
+// its incoming state and the number of structurals before it.  Wave w owns chunks
+// w, w+4, ... of kResolveChunk tiles: it polls its chunk until every aggregate is
+// there, folds kResolveE consecutive tiles per lane (for both q), then takes the
+// running state from LDS (published by the wave that owns the previous chunk),
+// combines the lanes with a ballot (parity) and a shuffle scan (counts), hands
+// the new state on, and only then writes its tiles' prefix words -- so the memory
+// latency of four chunks overlaps.  finish() (json_structural_indexer.mojo:147-186)
+// runs in the wave that owns the last chunk.
+__device__ void resolver(const KernelArgs &a, Shared &sh) {
+    const uint32_t tid = threadIdx.x;
+    const uint32_t lane = tid & 63u, wave = tid >> 6;
     const uint64_t *agg = a.ws + kDescOffset;
     uint64_t *pre = a.ws + kDescOffset + a.ntiles;
     const uint32_t ntiles = a.ntiles;
-    const msj_carry cin = *a.carry_in;
-    uint32_t s = cin.in_string & 1u, err = 0, u8 = 0, poison = 0;
-    uint32_t cnt = 0;  // launch-relative, < 2^32 because len < 2^32
-    uint32_t next = 0, idle = 0;
-    bool timeout = false;
+    const uint32_t nchunks = (ntiles + kResolveChunk - 1) / kResolveChunk;
+    if (tid == 0) {
+        sh.rs_seq = 0;
+        sh.rs_s = a.carry_in->in_string & 1u;
+        sh.rs_cnt = 0;
+        sh.rs_err = 0;
+        sh.rs_u8 = 0;
+        sh.rs_poison = 0;
+    }
+    __syncthreads();
     const uint64_t below = (1ull << lane) - 1ull;
-    while (next < ntiles) {
+    volatile uint32_t *seq = &sh.rs_seq;
+    for (uint32_t c = wave; c < nchunks; c += kWaves) {
+        const uint32_t first = c * kResolveChunk + lane * kResolveE;
         uint64_t d[kResolveE];
-        const uint32_t first = next + lane * kResolveE;
+        uint32_t spins = 0, poisoned = 0;
+        for (;;) {
+            bool all_ready = true;
 #pragma unroll
-        for (int e = 0; e < kResolveE; e++) d[e] = (first + e < ntiles) ? ld_desc(&agg[first + e]) : 0ull;
-        uint32_t rl = 0;
-        bool run = true;
-#pragma unroll
-        for (int e = 0; e < kResolveE; e++) {
-            run = run && ((d[e] >> 62) != 0ull);
-            rl += run ? 1u : 0u;
-        }
-        const uint64_t notfull = __ballot(rl < (uint32_t)kResolveE);
-        const uint32_t fl = notfull ? (uint32_t)__builtin_ctzll(notfull) : 64u;
-        const uint32_t act = (lane < fl) ? (uint32_t)kResolveE : ((lane == fl) ? rl : 0u);
-        const uint32_t m = (fl == 64u) ? 64u * kResolveE : fl * kResolveE + (uint32_t)__shfl((int)rl, (int)fl);
-        if (m == 0) {
-            if (++idle > kSpinLimit) {
-                timeout = true;
+            for (int e = 0; e < kResolveE; e++) {
+                d[e] = (first + e < ntiles) ? ld_desc(&agg[first + e]) : kAgg;  // past the end: identity
+                all_ready = all_ready && ((d[e] >> 62) != 0ull);
+            }
+            if (__all(all_ready)) break;
+            if (++spins > kSpinLimit) {
+                poisoned = 1;  // give up: missing aggregates count as identity, result is flagged
                 break;
             }
-            __builtin_amdgcn_s_sleep(4);
-            continue;
+            __builtin_amdgcn_s_sleep(2);
         }
-        idle = 0;
         // lane aggregate under both incoming states
-        uint32_t s0 = 0, s1 = 1, c_0 = 0, c_1 = 0, e_0 = 0, e_1 = 0, lu = 0, lpoison = 0;
+        uint32_t s0 = 0, s1 = 1, c_0 = 0, c_1 = 0, e_0 = 0, e_1 = 0, lu = 0, lpoison = poisoned;
 #pragma unroll
         for (int e = 0; e < kResolveE; e++) {
-            if ((uint32_t)e < act) {
-                const uint32_t p = (uint32_t)(d[e] >> 61) & 1u;
-                const uint32_t c0 = (uint32_t)d[e] & 0x7FFFu, c1 = (uint32_t)(d[e] >> 15) & 0xFFFFu;
-                const uint32_t e0 = (uint32_t)(d[e] >> 60) & 1u, e1 = (uint32_t)(d[e] >> 59) & 1u;
-                c_0 += s0 ? c1 : c0;
-                e_0 |= s0 ? e1 : e0;
-                s0 ^= p;
-                c_1 += s1 ? c1 : c0;
-                e_1 |= s1 ? e1 : e0;
-                s1 ^= p;
-                lu |= (uint32_t)(d[e] >> 56) & 1u;
-                lpoison |= (uint32_t)(d[e] >> 54) & 1u;
-            }
+            const uint64_t de = ((d[e] >> 62) != 0ull) ? d[e] : kAgg;
+            const uint32_t p = (uint32_t)(de >> 61) & 1u;
+            const uint32_t c0 = (uint32_t)de & 0x7FFFu, c1 = (uint32_t)(de >> 15) & 0xFFFFu;
+            const uint32_t e0 = (uint32_t)(de >> 60) & 1u, e1 = (uint32_t)(de >> 59) & 1u;
+            c_0 += s0 ? c1 : c0;
+            e_0 |= s0 ? e1 : e0;
+            s0 ^= p;
+            c_1 += s1 ? c1 : c0;
+            e_1 |= s1 ? e1 : e0;
+            s1 ^= p;
+            lu |= (uint32_t)(de >> 56) & 1u;
+            lpoison |= (uint32_t)(de >> 54) & 1u;
         }
-        const uint64_t PM = __ballot((s0 & 1u) != 0u);  // lane parity (inactive lanes: 0)
+        const uint64_t PM = __ballot((s0 & 1u) != 0u);  // lane parity
+        const uint64_t UM = __ballot(lu != 0u);
+        const uint64_t XM = __ballot(lpoison != 0u);
+        // ---- take the running state from the owner of the previous chunk
+        spins = 0;
+        while (*seq != c) {
+            __builtin_amdgcn_s_sleep(1);
+            if (++spins > kSpinLimit) break;  // cannot happen unless a sibling wave died
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        const uint32_t s = sh.rs_s, cnt = sh.rs_cnt, err = sh.rs_err, u8 = sh.rs_u8, poison = sh.rs_poison;
         const uint32_t in_l = s ^ ((uint32_t)__popcll(PM & below) & 1u);
         const uint32_t mycnt = in_l ? c_1 : c_0;
         uint32_t incl = mycnt;
@@ -474,113 +526,160 @@ __device__ void resolver(const KernelArgs &a, const uint32_t lane) {
         }
         const uint32_t total = (uint32_t)__shfl((int)incl, 63);
         const uint64_t EM = __ballot((in_l ? e_1 : e_0) != 0u);
-        const uint64_t UM = __ballot(lu != 0u);
-        const uint64_t XM = __ballot(lpoison != 0u);
-        // walk my tiles again with the real state, publishing each tile's prefix
+        const uint32_t s_new = s ^ ((uint32_t)__popcll(PM) & 1u);
+        const uint32_t cnt_new = cnt + total;
+        const uint32_t err_new = err | (EM ? 1u : 0u);
+        const uint32_t u8_new = u8 | (UM ? 1u : 0u);
+        const uint32_t poison_new = poison | (XM ? 1u : 0u);
+        if (lane == 0) {
+            sh.rs_s = s_new;
+            sh.rs_cnt = cnt_new;
+            sh.rs_err = err_new;
+            sh.rs_u8 = u8_new;
+            sh.rs_poison = poison_new;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            *seq = c + 1u;
+        }
+        // ---- walk my tiles again with the real state, publishing each tile's prefix
         uint32_t cs = in_l, cb = cnt + (incl - mycnt);
         uint32_t ce = err | ((EM & below) ? 1u : 0u);
         uint32_t cu = u8 | ((UM & below) ? 1u : 0u);
+        const uint64_t pz = (uint64_t)poison_new << 54;
 #pragma unroll
         for (int e = 0; e < kResolveE; e++) {
-            if ((uint32_t)e < act) {
+            if (first + e < ntiles) {
                 st_desc(&pre[first + e], kPre | ((uint64_t)cs << 61) | ((uint64_t)ce << 60) |
-                                             ((uint64_t)cu << 56) | (uint64_t)cb);
-                const uint32_t p = (uint32_t)(d[e] >> 61) & 1u;
-                const uint32_t c0 = (uint32_t)d[e] & 0x7FFFu, c1 = (uint32_t)(d[e] >> 15) & 0xFFFFu;
-                const uint32_t e0 = (uint32_t)(d[e] >> 60) & 1u, e1 = (uint32_t)(d[e] >> 59) & 1u;
+                                             ((uint64_t)cu << 56) | pz | (uint64_t)cb);
+                const uint64_t de = ((d[e] >> 62) != 0ull) ? d[e] : kAgg;
+                const uint32_t p = (uint32_t)(de >> 61) & 1u;
+                const uint32_t c0 = (uint32_t)de & 0x7FFFu, c1 = (uint32_t)(de >> 15) & 0xFFFFu;
+                const uint32_t e0 = (uint32_t)(de >> 60) & 1u, e1 = (uint32_t)(de >> 59) & 1u;
                 cb += cs ? c1 : c0;
                 ce |= cs ? e1 : e0;
-                cu |= (uint32_t)(d[e] >> 56) & 1u;
+                cu |= (uint32_t)(de >> 56) & 1u;
                 cs ^= p;
             }
         }
-        s ^= (uint32_t)__popcll(PM) & 1u;
-        cnt += total;
-        err |= EM ? 1u : 0u;
-        u8 |= UM ? 1u : 0u;
-        poison |= XM ? 1u : 0u;
-        next += m;
-    }
-    if (timeout) {
-        // release every worker still waiting: status 3 = give up
-        for (uint32_t i = next + lane; i < ntiles; i += 64u) st_desc(&pre[i], 3ull << 62);
-    }
-    if (lane != 0) return;
-
-    // ---- finish(): json_structural_indexer.mojo:147-186
-    const uint64_t last = timeout ? 0ull : ld_desc(&agg[ntiles - 1]);
-    const bool do_utf8 = !(a.flags & kFlagNoUtf8);
-    msj_carry out;
-    const uint64_t n = cin.count + cnt;
-    out.count = n;
-    out.bytes = cin.bytes + a.len;
-    out.in_string = s;
-    out.next_is_escaped = (uint32_t)(last >> 58) & 1u;
-    out.prev_scalar = (uint32_t)(last >> 57) & 1u;
-    out.unescaped_error = (cin.unescaped_error | err) ? 1u : 0u;
-    uint32_t u8e = cin.utf8_error | u8;
-    // a multi-byte sequence cut exactly at the end of the last full tile
-    if ((a.flags & kFlagFinal) && do_utf8 && (a.len % kTileBytes) == 0 && ((last >> 55) & 1u)) u8e = 1;
-    out.utf8_error = u8e ? 1u : 0u;
-    out.internal_error = (cin.internal_error | poison | (timeout ? 1u : 0u)) ? 1u : 0u;
-    int32_t code = MSJ_SUCCESS;
-    if (a.flags & kFlagFinal) {
-        if (out.internal_error) {
-            code = MSJ_UNEXPECTED_ERROR;
-        } else if (s) {
-            code = MSJ_UNCLOSED_STRING;  // :151-155
-        } else if (out.unescaped_error) {
-            code = MSJ_UNESCAPED_CHARS;  // :157-158
-        } else if (n + 3 > a.capacity) {
-            code = MSJ_CAPACITY;
-        } else {
-            if (!(a.flags & kFlagNoEmit)) {
-                a.idx[n] = (uint32_t)a.trailer_len;      // :167-169
-                a.idx[n + 1] = (uint32_t)a.trailer_len;  // :170-172
-                a.idx[n + 2] = 0;                        // :173
+        if (c + 1u == nchunks && lane == 0) {
+            // ---- finish(): json_structural_indexer.mojo:147-186
+            const msj_carry cin = *a.carry_in;
+            const uint64_t last = ld_desc(&agg[ntiles - 1]);
+            const bool do_utf8 = !(a.flags & kFlagNoUtf8);
+            msj_carry out;
+            const uint64_t n = cin.count + cnt_new;
+            out.count = n;
+            out.bytes = cin.bytes + a.len;
+            out.in_string = s_new;
+            out.next_is_escaped = (uint32_t)(last >> 58) & 1u;
+            out.prev_scalar = (uint32_t)(last >> 57) & 1u;
+            out.unescaped_error = (cin.unescaped_error | err_new) ? 1u : 0u;
+            uint32_t u8e = cin.utf8_error | u8_new;
+            // a multi-byte sequence cut exactly at the end of the last full tile
+            if ((a.flags & kFlagFinal) && do_utf8 && (a.len % kTileBytes) == 0 && ((last >> 55) & 1u))
+                u8e = 1;
+            out.utf8_error = u8e ? 1u : 0u;
+            out.internal_error = (cin.internal_error | poison_new) ? 1u : 0u;
+            int32_t code = MSJ_SUCCESS;
+            if (a.flags & kFlagFinal) {
+                if (out.internal_error) {
+                    code = MSJ_UNEXPECTED_ERROR;
+                } else if (s_new) {
+                    code = MSJ_UNCLOSED_STRING;  // :151-155
+                } else if (out.unescaped_error) {
+                    code = MSJ_UNESCAPED_CHARS;  // :157-158
+                } else if (n + 3 > a.capacity) {
+                    code = MSJ_CAPACITY;
+                } else {
+                    if (!(a.flags & kFlagNoEmit)) {
+                        a.idx[n] = (uint32_t)a.trailer_len;      // :167-169
+                        a.idx[n + 1] = (uint32_t)a.trailer_len;  // :170-172
+                        a.idx[n + 2] = 0;                        // :173
+                    }
+                    if (n == 0)
+                        code = MSJ_EMPTY;  // :176-177
+                    else if ((a.flags & kFlagStrictUtf8) && out.utf8_error)
+                        code = MSJ_UTF8_ERROR;
+                }
             }
-            if (n == 0)
-                code = MSJ_EMPTY;  // :176-177
-            else if ((a.flags & kFlagStrictUtf8) && out.utf8_error)
-                code = MSJ_UTF8_ERROR;
+            out.code = code;
+            for (int k = 0; k < 5; k++) out.reserved[k] = 0;
+            *a.carry_out = out;
+            if (a.segment) {
+                a.segment->byte_base = a.segment_byte_base;
+                a.segment->byte_len = a.len;
+                a.segment->index_begin = cin.count;
+                a.segment->count = cnt_new;
+            }
         }
-    }
-    out.code = code;
-    for (int k = 0; k < 5; k++) out.reserved[k] = 0;
-    *a.carry_out = out;
-    if (a.segment) {
-        a.segment->byte_base = a.segment_byte_base;
-        a.segment->byte_len = a.len;
-        a.segment->index_begin = cin.count;
-        a.segment->count = cnt;
     }
 }
 
 __global__ __launch_bounds__(kThreads) void stage1_kernel(const KernelArgs a) {
     __shared__ Shared sh;
     const uint32_t tid = threadIdx.x;
-    // ---- ordered ticket: ticket 0 is the resolver, ticket t+1 works on tile t.  A
-    //      workgroup only holds a ticket once it is running, so everything a
-    //      waiter depends on (earlier tiles, the resolver) is resident or done.
+    unsigned int *ticket_ctr = reinterpret_cast<unsigned int *>(a.ws);
+    // ---- ordered tickets: ticket 0 is the resolver, ticket t+1 works on tile t.  A
+    //      workgroup only holds tickets once it is running, and always handles its
+    //      tickets in increasing order, so everything a waiter depends on (the
+    //      aggregates of earlier tiles, the resolver) belongs to a running workgroup
+    //      that is not waiting on anything later: no deadlock whatever the dispatch
+    //      order or residency.
     if (tid == 0) {
-        sh.tile = atomicAdd(reinterpret_cast<unsigned int *>(a.ws), 1u);
+        const uint32_t t0 = atomicAdd(ticket_ctr, 1u);
+        sh.tk[0] = t0;
+        sh.tk[1] = (t0 != 0u) ? atomicAdd(ticket_ctr, 1u) : 0u;
         sh.timeout = 0;
     }
     __syncthreads();
-    const uint32_t ticket = sh.tile;
-    if (ticket == 0) {
-        if (tid < 64u) resolver(a, tid);
+    uint32_t t_cur = sh.tk[0];
+    if (t_cur == 0u) {
+        resolver(a, sh);
         return;
     }
-    worker(a, sh, ticket - 1u);
+    uint32_t t_next = sh.tk[1];
+    const uint32_t last_ticket = a.ntiles;  // ticket k works on tile k-1
+    if (t_cur > last_ticket) return;
+
+    Block cur;
+    load_block(a, t_cur - 1u, cur);
+    Pending pend;
+    bool have_pending = false;
+    while (t_cur <= last_ticket) {
+        // request the ticket after next, and the next tile's bytes, before computing
+        uint32_t t_nn_reg = 0;
+        if (tid == 0) t_nn_reg = atomicAdd(ticket_ctr, 1u);
+        Block nxt;
+        if (t_next <= last_ticket) {
+            load_block(a, t_next - 1u, nxt);
+        } else {
+#pragma unroll
+            for (int k = 0; k < 4; k++) nxt.q[k] = make_uint4(0, 0, 0, 0);
+            nxt.wb = 0;
+        }
+        const Pending now = compute_tile(a, sh, t_cur - 1u, cur, t_nn_reg);
+        const uint32_t t_nn = sh.tk[2];
+        if (have_pending) emit_tile(a, sh, pend);
+        pend = now;
+        have_pending = true;
+        cur = nxt;
+        t_cur = t_next;
+        t_next = t_nn;
+    }
+    if (have_pending) emit_tile(a, sh, pend);
 }
 
 }  // namespace msj
 
-extern "C" int msj_launch_stage1(const msj::KernelArgs *args, void *stream) {
+extern "C" int msj_launch_stage1(const msj::KernelArgs *args, void *stream, uint32_t grid) {
     const msj::KernelArgs a = *args;
-    // one workgroup per tile plus the resolver (ticket 0)
-    hipLaunchKernelGGL(msj::stage1_kernel, dim3(a.ntiles + 1u), dim3(msj::kThreads), 0,
+    // persistent workgroups: at most one per tile plus the resolver (ticket 0)
+    const uint32_t g = (grid == 0 || grid > a.ntiles + 1u) ? a.ntiles + 1u : grid;
+    hipLaunchKernelGGL(msj::stage1_kernel, dim3(g), dim3(msj::kThreads), 0,
                        static_cast<hipStream_t>(stream), a);
     return (int)hipGetLastError();
+}
+
+extern "C" int msj_stage1_occupancy(int *blocks_per_cu) {
+    return (int)hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks_per_cu, msj::stage1_kernel,
+                                                            msj::kThreads, 0);
 }

@@ -16,8 +16,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from mojo_simdjson_amd import _lib, synth  # noqa: E402
 
-PHASES = ["loads", "planes+classify", "wait B1", "strings -> B2", "counts -> B3",
-          "publish agg", "wait prefix (wave0)", "wait B4", "emit (LDS staged)"]
+PHASES = ["window carries", "planes+classify", "wait B1", "strings -> B2", "counts -> B3",
+          "publish agg", "deferred (next tile)", "wait prefix (wave0)", "emit (LDS staged)"]
 
 
 def main():
