@@ -122,20 +122,35 @@ struct Block {
     uint32_t wb;  // wave 0 only: byte [tile_start - 64 + lane] (the look-back window)
 };
 
+// Branch-free (so the compiler can leave all five loads in flight): pieces past
+// the end are redirected to the last 16-B piece that starts inside the input;
+// whatever they return is masked by `valid` in compute_tile.
 __device__ __forceinline__ void load_block(const KernelArgs &a, uint32_t tile, Block &b) {
     const uint64_t blk_off = (uint64_t)tile * kTileBytes + (uint64_t)threadIdx.x * 64u;
-    const uint4 *src = reinterpret_cast<const uint4 *>(a.buf + blk_off);
+    const uint64_t last_piece = (a.len - 1u) & ~15ull;  // buf is 16-B aligned
 #pragma unroll
     for (int k = 0; k < 4; k++) {
-        if (blk_off + 16u * k < a.len)  // a 16-B piece that starts inside the input (buf is 16-B aligned)
-            b.q[k] = src[k];
-        else
-            b.q[k] = make_uint4(0, 0, 0, 0);
+        const uint64_t off = blk_off + 16u * k;
+        b.q[k] = *reinterpret_cast<const uint4 *>(a.buf + (off < last_piece ? off : last_piece));
     }
-    b.wb = 0;
-    if (threadIdx.x < 64u && ((tile > 0) || (a.flags & kFlagHasPrefix)))
-        b.wb = a.buf[(int64_t)tile * kTileBytes - 64 + (int64_t)threadIdx.x];
+    const bool have_window = (tile > 0) || (a.flags & kFlagHasPrefix);
+    const uint64_t lane = threadIdx.x & 63u;
+    const int64_t woff = have_window ? (int64_t)((uint64_t)tile * kTileBytes) - 64 + (int64_t)lane
+                                     : (int64_t)(lane < a.len ? lane : a.len - 1u);
+    b.wb = a.buf[woff];
 }
+
+// Ticket draw whose result is consumed much later.  atomicAdd() would be expanded
+// into a wave-aggregated form whose result is needed (and waited for) at once;
+// the asm form returns into a VGPR that nothing reads until ticket_ready().
+__device__ __forceinline__ uint32_t ticket_request(unsigned int *ctr) {
+    uint32_t ret = 0;
+    const uint32_t one = 1;
+    if (threadIdx.x == 0)
+        asm volatile("global_atomic_add %0, %1, %2, off sc0" : "=v"(ret) : "v"(ctr), "v"(one) : "memory");
+    return ret;
+}
+__device__ __forceinline__ void ticket_ready() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 
 // What a computed tile keeps in registers until its indices are emitted.
 struct Pending {
@@ -147,8 +162,22 @@ struct Pending {
 };
 
 // ---- one tile: masks, carries, counts; publishes the tile aggregate ------------
+// Forces the wait for a prefetched block HERE (its loads were issued a whole
+// compute phase ago, so this costs nothing) instead of at its first use in the
+// next iteration, where the vmcnt(0) the compiler needs would also wait for the
+// index stores issued in between (the number of stores is data dependent, so a
+// counted vmcnt is impossible).
+__device__ __forceinline__ void touch_block(Block &b) {
+#pragma unroll
+    for (int k = 0; k < 4; k++)
+        asm volatile("" : "+v"(b.q[k].x), "+v"(b.q[k].y), "+v"(b.q[k].z), "+v"(b.q[k].w));
+    asm volatile("" : "+v"(b.wb));
+}
+
 __device__ __forceinline__ Pending compute_tile(const KernelArgs &a, Shared &sh, const uint32_t tile,
-                                                const Block &blk, const uint32_t next_ticket_reg) {
+                                                const Block &blk, Block &prefetched,
+                                                uint64_t &prefetched_pre,
+                                                const uint32_t next_ticket_reg) {
     const uint32_t tid = threadIdx.x;
     const uint32_t lane = tid & 63u;
     const uint32_t wave = tid >> 6;
@@ -340,7 +369,10 @@ __device__ __forceinline__ Pending compute_tile(const KernelArgs &a, Shared &sh,
             sh.flg[wave] = (me0 ? 1u : 0u) | (me1 ? 2u : 0u) | (mu8 ? 4u : 0u);
         }
     }
-    if (tid == 0) sh.tk[2] = next_ticket_reg;  // the ticket requested before this tile (arrived by now)
+    if (tid == 0) {
+        ticket_ready();  // requested before this tile was computed: arrived long ago
+        sh.tk[2] = next_ticket_reg;
+    }
     __syncthreads();  // B3: wave totals published
     MSJ_STAMP(tile, 6);
 
@@ -355,6 +387,12 @@ __device__ __forceinline__ Pending compute_tile(const KernelArgs &a, Shared &sh,
     r.wave_off = wave_off;
     r.tile_cnt = tile_cnt;
     r.tile = tile;
+    touch_block(prefetched);  // before any store of this iteration is issued
+    {
+        uint32_t lo = (uint32_t)prefetched_pre, hi = (uint32_t)(prefetched_pre >> 32);
+        asm volatile("" : "+v"(lo), "+v"(hi));
+        prefetched_pre = ((uint64_t)hi << 32) | lo;
+    }
     if (tid == 0) {
         st_desc(&agg[tile], kAgg | ((uint64_t)tile_par << 61) | ((uint64_t)(tile_flg & 1u) << 60) |
                                 ((uint64_t)((tile_flg >> 1) & 1u) << 59) |
@@ -371,16 +409,20 @@ __device__ __forceinline__ Pending compute_tile(const KernelArgs &a, Shared &sh,
 //      wait for the tile's prefix, stage the ascending offsets in LDS at their
 //      tile-relative position, write them out as aligned 16-byte stores (one L2
 //      request per 64 B instead of one per index).
-__device__ __forceinline__ void emit_tile(const KernelArgs &a, Shared &sh, const Pending &r) {
+__device__ __forceinline__ void emit_tile(const KernelArgs &a, Shared &sh, const Pending &r,
+                                          const uint64_t pre_word, const uint64_t count0) {
     const uint32_t tid = threadIdx.x;
     const uint64_t *pre = a.ws + kDescOffset + a.ntiles;
     MSJ_STAMP(r.tile, 8);
     if (tid < 64u) {
+        // pre_word was requested a whole compute phase ago; poll only if the
+        // resolver had not published this tile's prefix yet at that time.
         uint32_t to = 0;
-        const uint64_t d = wait_desc(&pre[r.tile], &to);
+        uint64_t d = pre_word;
+        if ((d >> 62) == 0ull) d = wait_desc(&pre[r.tile], &to);
         if (tid == 0) {
             sh.s_in = (uint32_t)(d >> 61) & 1u;
-            sh.base = a.carry_in->count + (uint64_t)(uint32_t)d;
+            sh.base = count0 + (uint64_t)(uint32_t)d;
             if (to || ((d >> 54) & 1u)) sh.timeout = 1;
         }
     }
@@ -642,30 +684,44 @@ __global__ __launch_bounds__(kThreads) void stage1_kernel(const KernelArgs a) {
 
     Block cur;
     load_block(a, t_cur - 1u, cur);
-    Pending pend;
-    bool have_pending = false;
+    touch_block(cur);  // loop invariant: `cur` has arrived (no vmcnt wait on it inside the loop)
+    // Two tiles stay pending: tile i-2 is emitted at the top of iteration i, so its
+    // prefix has had two compute phases to arrive, and its index stores are a whole
+    // compute phase old (i.e. complete) when the next wait on the load queue comes.
+    Pending older, newer;
+    uint32_t n_pending = 0;
+    const uint64_t count0 = a.carry_in->count;  // launch invariant: read once
+    const uint64_t *pre = a.ws + kDescOffset + a.ntiles;
+    uint64_t pre_older = 0;
     while (t_cur <= last_ticket) {
-        // request the ticket after next, and the next tile's bytes, before computing
-        uint32_t t_nn_reg = 0;
-        if (tid == 0) t_nn_reg = atomicAdd(ticket_ctr, 1u);
-        Block nxt;
-        if (t_next <= last_ticket) {
-            load_block(a, t_next - 1u, nxt);
-        } else {
-#pragma unroll
-            for (int k = 0; k < 4; k++) nxt.q[k] = make_uint4(0, 0, 0, 0);
-            nxt.wb = 0;
+        MSJ_STAMP(t_cur - 1u, 0);
+        if (n_pending == 2u) {
+            emit_tile(a, sh, older, pre_older, count0);
+            older = newer;
+            n_pending = 1u;
         }
-        const Pending now = compute_tile(a, sh, t_cur - 1u, cur, t_nn_reg);
+        // request the ticket after next, the next tile's bytes and the prefix of the
+        // tile that is emitted next, before computing
+        const uint32_t t_nn_reg = ticket_request(ticket_ctr);
+        Block nxt;  // past the last ticket: harmless re-read of the last tile (keeps this branch-free)
+        load_block(a, (t_next <= last_ticket ? t_next : last_ticket) - 1u, nxt);
+        pre_older = ld_desc(&pre[n_pending ? older.tile : t_cur - 1u]);
+        MSJ_STAMP(t_cur - 1u, 11);
+        const Pending now = compute_tile(a, sh, t_cur - 1u, cur, nxt, pre_older, t_nn_reg);
         const uint32_t t_nn = sh.tk[2];
-        if (have_pending) emit_tile(a, sh, pend);
-        pend = now;
-        have_pending = true;
+        if (n_pending == 0u) {
+            older = now;
+            pre_older = 0;  // the word read above was this tile's own (not published yet)
+        } else {
+            newer = now;
+        }
+        n_pending++;
         cur = nxt;
         t_cur = t_next;
         t_next = t_nn;
     }
-    if (have_pending) emit_tile(a, sh, pend);
+    if (n_pending >= 1u) emit_tile(a, sh, older, pre_older, count0);
+    if (n_pending == 2u) emit_tile(a, sh, newer, 0ull, count0);
 }
 
 }  // namespace msj

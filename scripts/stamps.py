@@ -44,7 +44,11 @@ def main():
                                    d_res.data_ptr(), None, 0)
         assert rc == 0
         torch.cuda.synchronize()
-    s = stamps.cpu().numpy().reshape(ntiles, 16)[:, 1:11].astype(np.int64)
+    raw = stamps.cpu().numpy().reshape(ntiles, 16).astype(np.int64)
+    ok = raw[:, 0] > 0
+    print(f"loop top -> prefetch issued : median {np.median((raw[:, 11] - raw[:, 0])[ok]):.0f}")
+    print(f"prefetch issued -> compute  : median {np.median((raw[:, 1] - raw[:, 11])[ok]):.0f}")
+    s = raw[:, 1:11]
     d = np.diff(s, axis=1)
     life = s[:, 9] - s[:, 0]
     print(f"workload {workload}: {ntiles} tiles; tile lifetime median {np.median(life):.0f} ticks, "
