@@ -7,14 +7,15 @@
 
 namespace msj {
 
-constexpr int kWaves = 4;                          // wave64 per workgroup
-constexpr int kThreads = kWaves * 64;              // 256 lanes, one 64-byte block each
-constexpr uint32_t kTileBytes = kThreads * 64u;    // 16 KiB of input per workgroup
-constexpr uint32_t kDescOffset = 8;                // ws[0] = ticket, ws[8..] = agg[ntiles], pre[ntiles]
-constexpr uint32_t kStageWords = 4096;             // LDS staging of indices (16 KiB) per round
-constexpr int kResolveE = 4;                       // tiles folded per resolver lane
+constexpr int kWaves = 4;                          // wave64 per workgroup (each an independent worker)
+constexpr int kThreads = kWaves * 64;
+constexpr uint32_t kTileBytes = 64u * 64u;         // 4 KiB of input per wave: 64 lanes x one 64-byte block
+constexpr uint32_t kDescOffset = 8;                // ws[0] = tile ticket, ws[1] = role ticket, ws[8..] = agg[], pre[]
+constexpr uint32_t kStageWords = 1024;             // per-wave LDS staging of indices (4 KiB) per round
+constexpr uint32_t kBatch = 2;                     // tiles per wave per ticket range = emission deferral depth
+constexpr int kResolveE = 8;                       // tiles folded per resolver lane
 constexpr uint32_t kResolveChunk = 64u * kResolveE; // tiles per resolver chunk (one wave, one round)
-constexpr uint32_t kSpinLimit = 1u << 22;          // bounded look-back polling (internal_error on expiry)
+constexpr uint32_t kSpinLimit = 1u << 18;          // bounded polling (internal_error on expiry, ~0.3 s)
 // largest segment one launch indexes with uint32 offsets (multiple of the tile)
 constexpr uint64_t kSegmentBytes = 0xFFFF0000ull;
 

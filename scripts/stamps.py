@@ -16,8 +16,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from mojo_simdjson_amd import _lib, synth  # noqa: E402
 
-PHASES = ["window carries", "planes+classify", "wait B1", "strings -> B2", "counts -> B3",
-          "publish agg", "deferred (next tile)", "wait prefix (wave0)", "emit (LDS staged)"]
+PHASES = ["window carries", "planes+classify+escape", "strings+scalars", "utf8", "count scan",
+          "waits+publish agg", "deferred (2 tiles)", "prefix word", "emit (LDS staged)"]
 
 
 def main():
@@ -30,7 +30,7 @@ def main():
     d_unit = torch.from_numpy(u).to(dev)
     d_buf = d_unit.repeat((1 << 30) // u.size)
     n = d_buf.numel()
-    ntiles = (n + 16383) // 16384
+    ntiles = (n + 4095) // 4096
     stamps = torch.zeros(ntiles * 16, dtype=torch.int64, device=dev)
     d_idx = torch.empty(int(n * 0.75), dtype=torch.int32, device=dev)
     d_res = torch.zeros(64, dtype=torch.uint8, device=dev)

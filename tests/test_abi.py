@@ -28,7 +28,7 @@ def test_header_symbols_exported():
             "msj_ctx_destroy", "msj_carry_fetch", "msj_device_count"} <= set(names)
     for n in names:
         assert hasattr(lib, n), f"{n} declared in include/msj_stage1.h but not exported"
-    assert lib.msj_tile_bytes() == 16384
+    assert lib.msj_tile_bytes() == 4096
     assert b"gfx950" in lib.msj_version()
 
 
