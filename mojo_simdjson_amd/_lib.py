@@ -8,7 +8,8 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libmsj_stage1.so")
+# MSJ_STAGE1_LIB: tuning aid (A/B of differently built kernels in one GPU session)
+LIB_PATH = os.environ.get("MSJ_STAGE1_LIB") or os.path.join(_HERE, "libmsj_stage1.so")
 GEN_LIB_PATH = os.path.join(_HERE, "libmsj_gen.so")
 
 

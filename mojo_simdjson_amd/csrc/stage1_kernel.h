@@ -13,7 +13,8 @@ constexpr uint32_t kTileBytes = 64u * 64u;         // 4 KiB of input per wave: 6
 constexpr uint32_t kDescOffset = 8;                // ws[0] = tile ticket, ws[1] = role ticket, ws[8..] = agg[], pre[]
 constexpr uint32_t kStageWords = 1024;             // per-wave LDS staging of indices (4 KiB) per round
 constexpr uint32_t kBatch = 2;                     // tiles per wave per ticket range = emission deferral depth
-constexpr int kResolveE = 8;                       // tiles folded per resolver lane
+constexpr uint32_t kRange = kWaves * kBatch;       // tiles per ticket range = per range aggregate
+constexpr int kResolveE = 4;                       // tiles folded per resolver lane
 constexpr uint32_t kResolveChunk = 64u * kResolveE; // tiles per resolver chunk (one wave, one round)
 constexpr uint32_t kSpinLimit = 1u << 18;          // bounded polling (internal_error on expiry, ~0.3 s)
 // largest segment one launch indexes with uint32 offsets (multiple of the tile)
@@ -42,7 +43,11 @@ struct KernelArgs {
     uint64_t *stamps;         // diagnostic builds only (-DMSJ_STAMPS): 16 words per tile, else null
 };
 
-inline uint64_t workspace_words(uint32_t ntiles) { return (uint64_t)kDescOffset + 2ull * ntiles; }
+// ws: [0] tile ticket, [1] role ticket, [8..] per-tile carry words, range aggregates, range prefixes
+inline uint64_t workspace_words(uint32_t ntiles) {
+    const uint64_t nranges = (ntiles + kRange - 1u) / kRange;
+    return (uint64_t)kDescOffset + ntiles + 2ull * nranges;
+}
 
 }  // namespace msj
 

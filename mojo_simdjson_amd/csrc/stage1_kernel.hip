@@ -78,16 +78,23 @@ __device__ __forceinline__ uint32_t bcast(uint32_t v, int src_lane) {
         if ((threadIdx.x & 63u) == 0 && a.stamps)                                         \
             a.stamps[(uint64_t)(t) * 16 + (k)] = __builtin_amdgcn_s_memtime();            \
     } while (0)
+#define MSJ_RSTAMP(t, k, cond)                                                            \
+    do {                                                                                  \
+        if ((cond) && a.stamps)                                                           \
+            a.stamps[(uint64_t)(t) * 16 + (k)] = __builtin_amdgcn_s_memrealtime();        \
+    } while (0)
 #else
 #define MSJ_STAMP(t, k) do {} while (0)
+#define MSJ_RSTAMP(t, k, cond) do {} while (0)
 #endif
 
 struct Shared {
     uint32_t role;
     uint32_t range_lo[2];    // worker workgroups: base tile of the next range (double buffered)
+    uint64_t tagg[2][kRange]; // worker workgroups: the range's tile aggregates, in tile order
     // resolver hand-off between its waves
     uint32_t rs_seq, rs_s, rs_cnt, rs_err, rs_u8, rs_poison;
-    uint32_t pad[3];
+    uint32_t pad[1];
     // per-wave index staging for coalesced stores
     uint32_t stage[kWaves][kStageWords] __attribute__((aligned(16)));
 };
@@ -169,6 +176,9 @@ struct Pending {
     uint32_t excl;       // packed exclusive wave scan of the per-lane counts
     uint32_t tile_cnt;   // packed tile totals
     uint32_t tile;
+    uint32_t in_cnt;     // structurals of the range before this tile: range state 0 | state 1 << 16
+    uint32_t in_s;       // tile's incoming in-string state: bit 0 for range state 0, bit 1 for state 1
+    uint32_t range_id;
 };
 
 // ---- one tile: masks, carries, counts; publishes the tile aggregate ------------
@@ -344,23 +354,17 @@ __device__ __forceinline__ Pending compute_tile(const KernelArgs &a, const uint3
 //      tile-relative position and written out as aligned 16-byte stores (one L2
 //      request per 64 B instead of one per index).  Wave-local: no barrier.
 __device__ __forceinline__ void emit_tile(const KernelArgs &a, uint32_t *stage, const uint32_t lane,
-                                          const Pending &r, const uint64_t pre_word,
+                                          const Pending &r, const uint64_t rpre_word,
                                           const uint64_t count0, uint32_t &timeout) {
-    const uint64_t *pre = a.ws + kDescOffset + a.ntiles;
     MSJ_STAMP(r.tile, 8);
-    // pre_word was requested a whole compute phase ago; poll only if the resolver
-    // had not published this tile's prefix yet at that time.
-    uint64_t d = pre_word;
-    if ((d >> 62) == 0ull) {
-        uint32_t to = 0;
-        d = wait_desc(&pre[r.tile], &to);
-        if (to) timeout = 1;
-    }
-    if ((d >> 54) & 1u) timeout = 1;
+    MSJ_RSTAMP(r.tile, 14, lane == 0);
+    // the range's prefix (resolver) + the tile's position inside the range (local fold)
+    const uint32_t q = (uint32_t)(rpre_word >> 61) & 1u;
+    const uint32_t s_in = (r.in_s >> q) & 1u;
+    const uint64_t base = count0 + (uint64_t)(uint32_t)rpre_word + (q ? (r.in_cnt >> 16) : (r.in_cnt & 0xFFFFu));
+    if ((rpre_word >> 54) & 1u) timeout = 1;
     MSJ_STAMP(r.tile, 9);
     if ((a.flags & kFlagNoEmit) || timeout) return;
-    const uint32_t s_in = (uint32_t)(d >> 61) & 1u;
-    const uint64_t base = count0 + (uint64_t)(uint32_t)d;
     const uint64_t T = s_in ? r.T1 : r.T0;
     const uint32_t lane_off = s_in ? (r.excl >> 16) : (r.excl & 0xFFFFu);
     const uint32_t my_cnt = s_in ? (r.tile_cnt >> 16) : (r.tile_cnt & 0xFFFFu);
@@ -428,13 +432,30 @@ __device__ __forceinline__ void emit_tile(const KernelArgs &a, uint32_t *stage, 
 // tile's prefix as soon as every earlier tile is in (partial progress).  The wave
 // holding the smallest not-yet-computed tile is therefore never waiting on anything
 // that needs a later tile, whatever the dispatch order or residency.
+// Range prefix for this wave: requested once per range, polled only if the resolver
+// had not published it yet.
+__device__ __forceinline__ uint64_t range_prefix(const uint64_t *rpre, uint32_t range_id, uint64_t word,
+                                                 uint32_t &timeout) {
+    if ((word >> 62) == 0ull) {
+        uint32_t to = 0;
+        word = wait_desc(&rpre[range_id], &to);
+        if (to) {
+            timeout = 1;
+            word = kPre | (1ull << 54);
+        }
+    }
+    return word;
+}
+
 __device__ __forceinline__ void worker_wave(const KernelArgs &a, Shared &sh, const uint32_t lane,
                                             const uint32_t wave) {
     unsigned int *ticket_ctr = reinterpret_cast<unsigned int *>(a.ws);
     uint32_t *stage = sh.stage[wave];
     const uint32_t tid = threadIdx.x;
     const uint32_t ntiles = a.ntiles;
-    constexpr uint32_t kRange = kWaves * kBatch;
+    const uint32_t nranges = (ntiles + kRange - 1u) / kRange;
+    uint64_t *ragg = a.ws + kDescOffset + ntiles;
+    const uint64_t *rpre = ragg + nranges;
     if (tid == 0) {
         sh.range_lo[0] = atomicAdd(ticket_ctr, kRange);
         sh.range_lo[1] = atomicAdd(ticket_ctr, kRange);
@@ -442,7 +463,6 @@ __device__ __forceinline__ void worker_wave(const KernelArgs &a, Shared &sh, con
     __syncthreads();
     uint32_t lo_cur = sh.range_lo[0], lo_next = sh.range_lo[1];
     const uint64_t count0 = a.carry_in->count;  // launch invariant: read once
-    const uint64_t *pre = a.ws + kDescOffset + ntiles;
     uint32_t timeout = 0;
 
     Block cur;
@@ -452,51 +472,106 @@ __device__ __forceinline__ void worker_wave(const KernelArgs &a, Shared &sh, con
     bool has[kBatch];
 #pragma unroll
     for (uint32_t j = 0; j < kBatch; j++) has[j] = false;
-    uint64_t pre_next = 0;  // prefix word of the tile emitted in the next iteration
+    uint64_t rp_word = 0;   // prefix word of the previous range (the one being emitted)
+    uint32_t prev_range = 0;
+    bool have_prev = false;
     uint32_t r = 0;
     while (lo_cur < ntiles) {  // uniform across the workgroup
         // range r+2, requested now, needed at the end of this range
         uint32_t req_reg = 0;
         if (tid == 0) req_reg = ticket_request(ticket_ctr, 0u, kRange);
+        // the previous range's prefix: its aggregate was published one barrier ago
+        rp_word = ld_desc(&rpre[have_prev ? prev_range : 0u]);
 #pragma unroll
         for (uint32_t j = 0; j < kBatch; j++) {
             const uint32_t t_cur = lo_cur + kWaves * j + wave;
             const uint32_t t_nxt = (j + 1u < kBatch) ? t_cur + kWaves : lo_next + wave;
-            MSJ_STAMP(t_cur < ntiles ? t_cur : ntiles - 1u, 0);
-            if (has[j]) emit_tile(a, stage, lane, pend[j], pre_next, count0, timeout);
-            has[j] = false;
-            // request the next tile's bytes and the prefix of the tile emitted next
+            const bool valid_tile = t_cur < ntiles;
+            MSJ_STAMP(valid_tile ? t_cur : ntiles - 1u, 0);
+            // request the next tile's bytes
             Block nxt;  // past the last tile: harmless re-read of the last tile (branch-free)
             load_block(a, t_nxt < ntiles ? t_nxt : ntiles - 1u, lane, nxt);
-            const uint32_t jn = (j + 1u) % kBatch;
-            pre_next = ld_desc(&pre[has[jn] ? pend[jn].tile : 0u]);
-            MSJ_STAMP(t_cur < ntiles ? t_cur : ntiles - 1u, 11);
-            uint64_t agg_word = 0;
-            if (t_cur < ntiles) {
-                pend[j] = compute_tile(a, t_cur, lane, cur, timeout, agg_word);
-                has[j] = true;
-            }
-            // everything requested above has had a whole compute phase to arrive; wait
-            // for it before this iteration's first store goes into the queue
+            MSJ_STAMP(valid_tile ? t_cur : ntiles - 1u, 11);
+            uint64_t agg_word = kAgg;  // a tile past the end: identity
+            Pending now;
+            if (valid_tile) now = compute_tile(a, t_cur, lane, cur, timeout, agg_word);
+            // everything requested above has had a whole compute phase to arrive; wait for
+            // it before this iteration's first store goes into the queue
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             touch_block(nxt);
-            touch_u64(pre_next);
-            if (!has[jn]) pre_next = 0;  // nothing pending in that slot: the word read was a dummy
-            if (lane == 0 && t_cur < ntiles) st_desc(&a.ws[kDescOffset + t_cur], agg_word);
-            MSJ_STAMP(t_cur < ntiles ? t_cur : ntiles - 1u, 7);
+            touch_u64(rp_word);
+            if (lane == 0) {
+                if (valid_tile) st_desc(&a.ws[kDescOffset + t_cur], agg_word);  // carries for t_cur + 1
+                sh.tagg[r & 1u][kWaves * j + wave] = agg_word;
+            }
+            MSJ_STAMP(valid_tile ? t_cur : ntiles - 1u, 7);
+            MSJ_RSTAMP(t_cur, 12, lane == 0 && valid_tile);
+            // emit the tile of the previous range that sits in this slot
+            if (has[j]) {
+                MSJ_STAMP(pend[j].tile, 15);
+                rp_word = range_prefix(rpre, prev_range, rp_word, timeout);
+                emit_tile(a, stage, lane, pend[j], rp_word, count0, timeout);
+            }
+            if (valid_tile) {
+                pend[j] = now;
+                pend[j].range_id = lo_cur / kRange;
+            }
+            has[j] = valid_tile;
             cur = nxt;
         }
         if (tid == 0) sh.range_lo[r & 1u] = req_reg;  // arrived: vmcnt(0) above
         __syncthreads();
+        // ---- fold the range's kRange tile aggregates in tile order (every wave does it:
+        //      it is a few dozen scalar operations) -> the range aggregate for the resolver,
+        //      and every tile's state / count inside the range for both range states
+        {
+            uint32_t s0 = 0, s1 = 1, c0s = 0, c1s = 0, e0s = 0, e1s = 0, u8s = 0, pzs = 0;
+#pragma unroll
+            for (uint32_t k = 0; k < kRange; k++) {
+                const uint64_t w = sh.tagg[r & 1u][k];
+                if (k % kWaves == wave) {
+                    const uint32_t j = k / kWaves;  // compile-time after unrolling
+#pragma unroll
+                    for (uint32_t jj = 0; jj < kBatch; jj++) {
+                        if (jj == j) {
+                            pend[jj].in_s = s0 | (s1 << 1);
+                            pend[jj].in_cnt = c0s | (c1s << 16);
+                        }
+                    }
+                }
+                const uint32_t p = (uint32_t)(w >> 61) & 1u;
+                const uint32_t c0 = (uint32_t)w & 0x7FFFu, c1 = (uint32_t)(w >> 15) & 0xFFFFu;
+                const uint32_t e0 = (uint32_t)(w >> 60) & 1u, e1 = (uint32_t)(w >> 59) & 1u;
+                c0s += s0 ? c1 : c0;
+                e0s |= s0 ? e1 : e0;
+                s0 ^= p;
+                c1s += s1 ? c1 : c0;
+                e1s |= s1 ? e1 : e0;
+                s1 ^= p;
+                u8s |= (uint32_t)(w >> 56) & 1u;
+                pzs |= (uint32_t)(w >> 54) & 1u;
+            }
+            if (tid == 0) {
+                st_desc(&ragg[lo_cur / kRange], kAgg | ((uint64_t)s0 << 61) | ((uint64_t)e0s << 60) |
+                                                    ((uint64_t)e1s << 59) | ((uint64_t)u8s << 56) |
+                                                    ((uint64_t)pzs << 54) | ((uint64_t)c1s << 16) |
+                                                    (uint64_t)c0s);
+            }
+        }
+        prev_range = lo_cur / kRange;
+        have_prev = true;
         lo_cur = lo_next;
         lo_next = sh.range_lo[r & 1u];
         r++;
     }
+    if (have_prev) {
+        uint64_t w = 0;
 #pragma unroll
-    for (uint32_t j = 0; j < kBatch; j++) {
-        if (has[j]) {
-            // the prefix word was only prefetched for the first one
-            emit_tile(a, stage, lane, pend[j], j == 0 ? pre_next : 0ull, count0, timeout);
+        for (uint32_t j = 0; j < kBatch; j++) {
+            if (has[j]) {
+                w = range_prefix(rpre, prev_range, w, timeout);
+                emit_tile(a, stage, lane, pend[j], w, count0, timeout);
+            }
         }
     }
 }
@@ -504,20 +579,44 @@ __device__ __forceinline__ void worker_wave(const KernelArgs &a, Shared &sh, con
 // ---- resolver: the four waves of one workgroup turn tile aggregates into tile
 // prefixes, in order.  Monoid: a tile's aggregate is (parity p, count c[q], error
 // e[q]) for incoming in-string state q; composing left to right gives every tile
-// its incoming state and the number of structurals before it.  Wave w owns chunks
-// w, w+4, ... of kResolveChunk tiles: it polls its chunk until every aggregate is
-// there, folds kResolveE consecutive tiles per lane (for both q), then takes the
-// running state from LDS (published by the wave that owns the previous chunk),
-// combines the lanes with a ballot (parity) and a shuffle scan (counts), hands
-// the new state on, and only then writes its tiles' prefix words -- so the memory
-// latency of four chunks overlaps.  finish() (json_structural_indexer.mojo:147-186)
-// runs in the wave that owns the last chunk.
+// its incoming state and the number of structurals before it.
+//
+// Wave w owns chunks w, w+4, ... of kResolveChunk = 64*kResolveE tiles.  Lane l
+// holds tiles e*64 + l of the chunk (e = 0..kResolveE-1), so every descriptor
+// load / store is one fully coalesced 512-byte access.  Per 64-tile sub-block the
+// wave precomputes, BEFORE the running state arrives: the parity of the lanes below
+// (ballot), the inclusive scan of the counts under sub-block state 0 and of
+// c[0]+c[1] (state 1 = difference), and the error masks for both states.  When the
+// owner of the previous chunk hands the running state over through LDS, the serial
+// section is kResolveE steps of scalar arithmetic; the state is handed on first and
+// the prefix words are written afterwards, so the memory latency of four chunks
+// overlaps.  If the chunk is not complete yet, the tiles whose predecessors are all
+// in still get their prefix (partial progress: needed for deadlock freedom, see
+// worker_wave).  finish() (json_structural_indexer.mojo:147-186) runs in the wave
+// that owns the last chunk.
+struct SubBlock {
+    uint32_t scanA;  // inclusive scan of the count under sub-block incoming state 0
+    uint32_t scanB;  // inclusive scan of c0 + c1
+    uint32_t a, b;   // own terms of the two scans
+    uint32_t bl;     // parity of the lanes below me in the sub-block
+};
+
+__device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v, uint32_t lane) {
+#pragma unroll
+    for (int dd = 1; dd < 64; dd <<= 1) {
+        const uint32_t t = __shfl_up(v, dd);
+        if (lane >= (uint32_t)dd) v += t;
+    }
+    return v;
+}
+
 __device__ void resolver(const KernelArgs &a, Shared &sh) {
     const uint32_t tid = threadIdx.x;
     const uint32_t lane = tid & 63u, wave = tid >> 6;
-    const uint64_t *agg = a.ws + kDescOffset;
-    uint64_t *pre = a.ws + kDescOffset + a.ntiles;
-    const uint32_t ntiles = a.ntiles;
+    // the resolver's "tiles" are the workers' ranges (kRange tiles each)
+    const uint32_t ntiles = (a.ntiles + kRange - 1u) / kRange;
+    const uint64_t *agg = a.ws + kDescOffset + a.ntiles;
+    uint64_t *pre = a.ws + kDescOffset + a.ntiles + ntiles;
     const uint32_t nchunks = (ntiles + kResolveChunk - 1) / kResolveChunk;
     if (tid == 0) {
         sh.rs_seq = 0;
@@ -532,61 +631,56 @@ __device__ void resolver(const KernelArgs &a, Shared &sh) {
     volatile uint32_t *seq = &sh.rs_seq;
     __builtin_amdgcn_s_setprio(3);  // the serial chain of the whole launch runs here
     for (uint32_t c = wave; c < nchunks; c += kWaves) {
-        const uint32_t first = c * kResolveChunk + lane * kResolveE;
+        const uint32_t base = c * kResolveChunk;
         uint64_t d[kResolveE];
 #pragma unroll
         for (int e = 0; e < kResolveE; e++) d[e] = 0;
         uint32_t spins = 0, published = 0, force = 0;
-        bool have_state = false, full = false;
+        bool have_state = false, full = false, agg_done = false;
         uint32_t s = 0, cnt = 0, err = 0, u8 = 0, poison = 0;
-        uint32_t s_new = 0, cnt_new = 0, err_new = 0, u8_new = 0, poison_new = 0;
-        uint32_t rl = 0, fl = 64u, m = 0;
-        // lane aggregate of my kResolveE tiles under both incoming states (full chunk)
-        uint32_t fs0 = 0, fc_0 = 0, fc_1 = 0, fe_0 = 0, fe_1 = 0;
-        uint64_t fPM = 0, fUM = 0, fXM = 0;
-        bool agg_done = false;
+        uint32_t m = 0;
+        SubBlock sb[kResolveE];
+        uint32_t par[kResolveE], tot0[kResolveE], totB[kResolveE];
+        uint64_t E0[kResolveE], E1[kResolveE], UM[kResolveE], XM[kResolveE];
         for (;;) {
             if (!full) {
-                // (re)load the aggregates that were not there yet; past the end: identity
-                rl = 0;
-                bool run = true;
+                // (re)load what was not there yet; m = leading tiles whose aggregates are in
+                m = kResolveChunk;
 #pragma unroll
-                for (int e = 0; e < kResolveE; e++) {
+                for (int e = kResolveE - 1; e >= 0; e--) {
+                    const uint32_t t = base + (uint32_t)e * 64u + lane;
                     if ((d[e] >> 62) == 0ull) {
-                        d[e] = (first + e < ntiles) ? ld_desc(&agg[first + e]) : kAgg;
+                        d[e] = (t < ntiles) ? ld_desc(&agg[t]) : kAgg;  // past the end: identity
                         if (force && (d[e] >> 62) == 0ull) d[e] = kAgg | (1ull << 54);  // gave up
                     }
-                    run = run && ((d[e] >> 62) != 0ull);
-                    rl += run ? 1u : 0u;
+                    const uint64_t nr = __ballot((d[e] >> 62) == 0ull);
+                    if (nr) m = (uint32_t)e * 64u + (uint32_t)__builtin_ctzll(nr);
                 }
-                // m = number of leading tiles of the chunk whose aggregates are all there
-                const uint64_t notfull = __ballot(rl < (uint32_t)kResolveE);
-                fl = notfull ? (uint32_t)__builtin_ctzll(notfull) : 64u;
-                m = (fl == 64u) ? kResolveChunk : fl * kResolveE + (uint32_t)__shfl((int)rl, (int)fl);
                 full = (m == kResolveChunk);
             }
             if (full && !agg_done) {
                 // everything that does not need the running state, done before it arrives
-                uint32_t s0 = 0, s1 = 1, lu = 0, lpoison = 0;
 #pragma unroll
                 for (int e = 0; e < kResolveE; e++) {
                     const uint64_t de = d[e];
                     const uint32_t p = (uint32_t)(de >> 61) & 1u;
-                    const uint32_t c0 = (uint32_t)de & 0x7FFFu, c1 = (uint32_t)(de >> 15) & 0xFFFFu;
+                    const uint32_t c0 = (uint32_t)de & 0xFFFFu, c1 = (uint32_t)(de >> 16) & 0xFFFFu;
                     const uint32_t e0 = (uint32_t)(de >> 60) & 1u, e1 = (uint32_t)(de >> 59) & 1u;
-                    fc_0 += s0 ? c1 : c0;
-                    fe_0 |= s0 ? e1 : e0;
-                    s0 ^= p;
-                    fc_1 += s1 ? c1 : c0;
-                    fe_1 |= s1 ? e1 : e0;
-                    s1 ^= p;
-                    lu |= (uint32_t)(de >> 56) & 1u;
-                    lpoison |= (uint32_t)(de >> 54) & 1u;
+                    const uint64_t PM = __ballot(p != 0u);
+                    const uint32_t bl = (uint32_t)__popcll(PM & below) & 1u;
+                    sb[e].bl = bl;
+                    sb[e].a = bl ? c1 : c0;
+                    sb[e].b = c0 + c1;
+                    sb[e].scanA = wave_incl_scan(sb[e].a, lane);
+                    sb[e].scanB = wave_incl_scan(sb[e].b, lane);
+                    tot0[e] = bcast(sb[e].scanA, 63);
+                    totB[e] = bcast(sb[e].scanB, 63);
+                    par[e] = (uint32_t)__popcll(PM) & 1u;
+                    E0[e] = __ballot((bl ? e1 : e0) != 0u);
+                    E1[e] = __ballot((bl ? e0 : e1) != 0u);
+                    UM[e] = __ballot(((de >> 56) & 1ull) != 0ull);
+                    XM[e] = __ballot(((de >> 54) & 1ull) != 0ull);
                 }
-                fs0 = s0;
-                fPM = __ballot((s0 & 1u) != 0u);
-                fUM = __ballot(lu != 0u);
-                fXM = __ballot(lpoison != 0u);
                 agg_done = true;
             }
             if (!have_state && *seq == c) {
@@ -600,112 +694,139 @@ __device__ void resolver(const KernelArgs &a, Shared &sh) {
                 have_state = true;
             }
             if (have_state && full) {
-                // ---- fast finish: the serial section of the whole launch
-                const uint32_t in_l = s ^ ((uint32_t)__popcll(fPM & below) & 1u);
-                const uint32_t mycnt = in_l ? fc_1 : fc_0;
-                uint32_t incl = mycnt;
+                // ---- the serial section of the whole launch: scalar steps only
+                uint32_t q[kResolveE], cb[kResolveE], eb[kResolveE], ub[kResolveE];
+                uint32_t cs = s, cc = cnt, ce = err, cu = u8, cx = poison;
 #pragma unroll
-                for (int dd = 1; dd < 64; dd <<= 1) {
-                    const uint32_t t = __shfl_up(incl, dd);
-                    if (lane >= (uint32_t)dd) incl += t;
+                for (int e = 0; e < kResolveE; e++) {
+                    q[e] = cs;
+                    cb[e] = cc;
+                    eb[e] = ce;
+                    ub[e] = cu;
+                    cc += cs ? (totB[e] - tot0[e]) : tot0[e];
+                    ce |= ((cs ? E1[e] : E0[e]) != 0ull) ? 1u : 0u;
+                    cu |= (UM[e] != 0ull) ? 1u : 0u;
+                    cx |= (XM[e] != 0ull) ? 1u : 0u;
+                    cs ^= par[e];
                 }
-                const uint64_t EM = __ballot((in_l ? fe_1 : fe_0) != 0u);
-                s_new = s ^ ((uint32_t)__popcll(fPM) & 1u);
-                cnt_new = cnt + bcast(incl, 63);
-                err_new = err | (EM ? 1u : 0u);
-                u8_new = u8 | (fUM ? 1u : 0u);
-                poison_new = poison | (fXM ? 1u : 0u);
                 if (lane == 0) {
                     // hand the running state to the owner of the next chunk first; this
                     // chunk's prefix words are written afterwards
-                    sh.rs_s = s_new;
-                    sh.rs_cnt = cnt_new;
-                    sh.rs_err = err_new;
-                    sh.rs_u8 = u8_new;
-                    sh.rs_poison = poison_new;
+                    sh.rs_s = cs;
+                    sh.rs_cnt = cc;
+                    sh.rs_err = ce;
+                    sh.rs_u8 = cu;
+                    sh.rs_poison = cx;
                     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
                     *seq = c + 1u;
                 }
-                uint32_t cs = in_l, cb = cnt + (incl - mycnt);
-                uint32_t ce = err | ((EM & below) ? 1u : 0u);
-                uint32_t cu = u8 | ((fUM & below) ? 1u : 0u);
-                const uint64_t pz = (uint64_t)(poison_new ? 1u : 0u) << 54;
+                const uint64_t pz = (uint64_t)(cx ? 1u : 0u) << 54;
 #pragma unroll
                 for (int e = 0; e < kResolveE; e++) {
-                    const uint32_t idx_in_chunk = lane * kResolveE + (uint32_t)e;
-                    if (idx_in_chunk >= published && first + e < ntiles) {
-                        st_desc(&pre[first + e], kPre | ((uint64_t)cs << 61) | ((uint64_t)ce << 60) |
-                                                     ((uint64_t)cu << 56) | pz | (uint64_t)cb);
+                    const uint32_t idx_in_chunk = (uint32_t)e * 64u + lane;
+                    const uint32_t t = base + idx_in_chunk;
+                    if (idx_in_chunk >= published && t < ntiles) {
+                        const uint32_t exclA = sb[e].scanA - sb[e].a, exclB = sb[e].scanB - sb[e].b;
+                        const uint32_t before = cb[e] + (q[e] ? (exclB - exclA) : exclA);
+                        const uint32_t s_in = q[e] ^ sb[e].bl;
+                        const uint32_t e_in = eb[e] | ((((q[e] ? E1[e] : E0[e]) & below) != 0ull) ? 1u : 0u);
+                        const uint32_t u_in = ub[e] | (((UM[e] & below) != 0ull) ? 1u : 0u);
+                        st_desc(&pre[t], kPre | ((uint64_t)s_in << 61) | ((uint64_t)e_in << 60) |
+                                             ((uint64_t)u_in << 56) | pz | (uint64_t)before);
+                        MSJ_RSTAMP(t, 13, true);
                     }
-                    const uint64_t de = d[e];
-                    const uint32_t p = (uint32_t)(de >> 61) & 1u;
-                    const uint32_t c0 = (uint32_t)de & 0x7FFFu, c1 = (uint32_t)(de >> 15) & 0xFFFFu;
-                    const uint32_t e0 = (uint32_t)(de >> 60) & 1u, e1 = (uint32_t)(de >> 59) & 1u;
-                    cb += cs ? c1 : c0;
-                    ce |= cs ? e1 : e0;
-                    cu |= (uint32_t)(de >> 56) & 1u;
-                    cs ^= p;
                 }
-                (void)fs0;
+                if (c + 1u == nchunks && lane == 0) {
+                    // ---- finish(): json_structural_indexer.mojo:147-186
+                    const msj_carry cin = *a.carry_in;
+                    const uint64_t last = ld_desc(&a.ws[kDescOffset + a.ntiles - 1u]);  // last TILE's carries
+                    const bool do_utf8 = !(a.flags & kFlagNoUtf8);
+                    msj_carry out;
+                    const uint64_t n = cin.count + cc;
+                    out.count = n;
+                    out.bytes = cin.bytes + a.len;
+                    out.in_string = cs;
+                    out.next_is_escaped = (uint32_t)(last >> 58) & 1u;
+                    out.prev_scalar = (uint32_t)(last >> 57) & 1u;
+                    out.unescaped_error = (cin.unescaped_error | ce) ? 1u : 0u;
+                    uint32_t u8e = cin.utf8_error | cu;
+                    // a multi-byte sequence cut exactly at the end of the last full tile
+                    if ((a.flags & kFlagFinal) && do_utf8 && (a.len % kTileBytes) == 0 &&
+                        ((last >> 55) & 1u))
+                        u8e = 1;
+                    out.utf8_error = u8e ? 1u : 0u;
+                    out.internal_error = (cin.internal_error | cx) ? 1u : 0u;
+                    int32_t code = MSJ_SUCCESS;
+                    if (a.flags & kFlagFinal) {
+                        if (out.internal_error) {
+                            code = MSJ_UNEXPECTED_ERROR;
+                        } else if (cs) {
+                            code = MSJ_UNCLOSED_STRING;  // :151-155
+                        } else if (out.unescaped_error) {
+                            code = MSJ_UNESCAPED_CHARS;  // :157-158
+                        } else if (n + 3 > a.capacity) {
+                            code = MSJ_CAPACITY;
+                        } else {
+                            if (!(a.flags & kFlagNoEmit)) {
+                                a.idx[n] = (uint32_t)a.trailer_len;      // :167-169
+                                a.idx[n + 1] = (uint32_t)a.trailer_len;  // :170-172
+                                a.idx[n + 2] = 0;                        // :173
+                            }
+                            if (n == 0)
+                                code = MSJ_EMPTY;  // :176-177
+                            else if ((a.flags & kFlagStrictUtf8) && out.utf8_error)
+                                code = MSJ_UTF8_ERROR;
+                        }
+                    }
+                    out.code = code;
+                    for (int k = 0; k < 5; k++) out.reserved[k] = 0;
+                    *a.carry_out = out;
+                    if (a.segment) {
+                        a.segment->byte_base = a.segment_byte_base;
+                        a.segment->byte_len = a.len;
+                        a.segment->index_begin = cin.count;
+                        a.segment->count = cc;
+                    }
+                }
                 break;
             }
             if (have_state && m > published) {
-                // PARTIAL PROGRESS (chunk not complete): every tile whose predecessors are
-                // all in gets its prefix now.  A worker may be waiting for a prefix while it
-                // still holds a later, not yet computed tile of this same chunk; with partial
-                // progress the smallest not-yet-computed tile can always proceed, which
-                // rules out deadlock.
-                const uint32_t act = (lane < fl) ? (uint32_t)kResolveE : ((lane == fl) ? rl : 0u);
-                uint32_t s0 = 0, s1 = 1, c_0 = 0, c_1 = 0, e_0 = 0, e_1 = 0, lu = 0, lpoison = 0;
+                // PARTIAL PROGRESS (chunk not complete): tiles [published, m) have all their
+                // predecessors in.  Same arithmetic restricted to the leading m tiles; only
+                // ever runs in the chunk at the frontier, while the launch is starved anyway.
+                uint32_t cs = s, cc = cnt, ce = err, cu = u8;
+                const uint32_t cx = poison;
 #pragma unroll
                 for (int e = 0; e < kResolveE; e++) {
-                    if ((uint32_t)e < act) {
-                        const uint64_t de = d[e];
+                    const uint32_t lo_e = (uint32_t)e * 64u;
+                    if (lo_e < m) {  // uniform
+                        const uint32_t nact = (m - lo_e) < 64u ? (m - lo_e) : 64u;
+                        const bool act = lane < nact;
+                        const uint64_t de = act ? d[e] : kAgg;
                         const uint32_t p = (uint32_t)(de >> 61) & 1u;
-                        const uint32_t c0 = (uint32_t)de & 0x7FFFu, c1 = (uint32_t)(de >> 15) & 0xFFFFu;
+                        const uint32_t c0 = (uint32_t)de & 0xFFFFu, c1 = (uint32_t)(de >> 16) & 0xFFFFu;
                         const uint32_t e0 = (uint32_t)(de >> 60) & 1u, e1 = (uint32_t)(de >> 59) & 1u;
-                        c_0 += s0 ? c1 : c0;
-                        e_0 |= s0 ? e1 : e0;
-                        s0 ^= p;
-                        c_1 += s1 ? c1 : c0;
-                        e_1 |= s1 ? e1 : e0;
-                        s1 ^= p;
-                        lu |= (uint32_t)(de >> 56) & 1u;
-                        lpoison |= (uint32_t)(de >> 54) & 1u;
-                    }
-                }
-                const uint64_t PM = __ballot((s0 & 1u) != 0u);  // lane parity (inactive lanes: 0)
-                const uint32_t in_l = s ^ ((uint32_t)__popcll(PM & below) & 1u);
-                const uint32_t mycnt = in_l ? c_1 : c_0;
-                uint32_t incl = mycnt;
-#pragma unroll
-                for (int dd = 1; dd < 64; dd <<= 1) {
-                    const uint32_t t = __shfl_up(incl, dd);
-                    if (lane >= (uint32_t)dd) incl += t;
-                }
-                const uint64_t EM = __ballot((in_l ? e_1 : e_0) != 0u);
-                const uint64_t UM = __ballot(lu != 0u);
-                const uint64_t XM = __ballot(lpoison != 0u);
-                uint32_t cs = in_l, cb = cnt + (incl - mycnt);
-                uint32_t ce = err | ((EM & below) ? 1u : 0u);
-                uint32_t cu = u8 | ((UM & below) ? 1u : 0u);
-                const uint64_t pz = (uint64_t)(poison | ((XM & below) ? 1u : 0u) | lpoison) << 54;
-#pragma unroll
-                for (int e = 0; e < kResolveE; e++) {
-                    if ((uint32_t)e < act) {
-                        const uint32_t idx_in_chunk = lane * kResolveE + (uint32_t)e;
-                        if (idx_in_chunk >= published && first + e < ntiles) {
-                            st_desc(&pre[first + e], kPre | ((uint64_t)cs << 61) | ((uint64_t)ce << 60) |
-                                                         ((uint64_t)cu << 56) | pz | (uint64_t)cb);
+                        const uint64_t PM = __ballot(p != 0u);
+                        const uint32_t in_l = cs ^ ((uint32_t)__popcll(PM & below) & 1u);
+                        const uint32_t mine = in_l ? c1 : c0;
+                        const uint32_t incl = wave_incl_scan(mine, lane);
+                        const uint64_t EM = __ballot((in_l ? e1 : e0) != 0u);
+                        const uint64_t U = __ballot(((de >> 56) & 1ull) != 0ull);
+                        const uint64_t X = __ballot(((de >> 54) & 1ull) != 0ull);
+                        const uint32_t t = base + lo_e + lane;
+                        if (act && lo_e + lane >= published && t < ntiles) {
+                            const uint32_t e_in = ce | (((EM & below) != 0ull) ? 1u : 0u);
+                            const uint32_t u_in = cu | (((U & below) != 0ull) ? 1u : 0u);
+                            const uint64_t pz = (uint64_t)((cx | (((X & below) != 0ull) ? 1u : 0u) |
+                                                            ((uint32_t)(de >> 54) & 1u))) << 54;
+                            st_desc(&pre[t], kPre | ((uint64_t)in_l << 61) | ((uint64_t)e_in << 60) |
+                                                 ((uint64_t)u_in << 56) | pz | (uint64_t)(cc + incl - mine));
+                            MSJ_RSTAMP(t, 13, true);
                         }
-                        const uint64_t de = d[e];
-                        const uint32_t p = (uint32_t)(de >> 61) & 1u;
-                        const uint32_t c0 = (uint32_t)de & 0x7FFFu, c1 = (uint32_t)(de >> 15) & 0xFFFFu;
-                        const uint32_t e0 = (uint32_t)(de >> 60) & 1u, e1 = (uint32_t)(de >> 59) & 1u;
-                        cb += cs ? c1 : c0;
-                        ce |= cs ? e1 : e0;
-                        cu |= (uint32_t)(de >> 56) & 1u;
-                        cs ^= p;
+                        cc += bcast(incl, 63);
+                        ce |= EM ? 1u : 0u;
+                        cu |= U ? 1u : 0u;
+                        cs ^= (uint32_t)__popcll(PM) & 1u;
                     }
                 }
                 published = m;
@@ -714,57 +835,6 @@ __device__ void resolver(const KernelArgs &a, Shared &sh) {
             if (++spins > kSpinLimit) force = 1;  // next round substitutes poisoned identities
             // full but no state yet: spin on the LDS word only (no global traffic)
             if (!full) __builtin_amdgcn_s_sleep(1);
-        }
-        if (c + 1u == nchunks && lane == 0) {
-            // ---- finish(): json_structural_indexer.mojo:147-186
-            const msj_carry cin = *a.carry_in;
-            const uint64_t last = ld_desc(&agg[ntiles - 1]);
-            const bool do_utf8 = !(a.flags & kFlagNoUtf8);
-            msj_carry out;
-            const uint64_t n = cin.count + cnt_new;
-            out.count = n;
-            out.bytes = cin.bytes + a.len;
-            out.in_string = s_new;
-            out.next_is_escaped = (uint32_t)(last >> 58) & 1u;
-            out.prev_scalar = (uint32_t)(last >> 57) & 1u;
-            out.unescaped_error = (cin.unescaped_error | err_new) ? 1u : 0u;
-            uint32_t u8e = cin.utf8_error | u8_new;
-            // a multi-byte sequence cut exactly at the end of the last full tile
-            if ((a.flags & kFlagFinal) && do_utf8 && (a.len % kTileBytes) == 0 && ((last >> 55) & 1u))
-                u8e = 1;
-            out.utf8_error = u8e ? 1u : 0u;
-            out.internal_error = (cin.internal_error | poison_new) ? 1u : 0u;
-            int32_t code = MSJ_SUCCESS;
-            if (a.flags & kFlagFinal) {
-                if (out.internal_error) {
-                    code = MSJ_UNEXPECTED_ERROR;
-                } else if (s_new) {
-                    code = MSJ_UNCLOSED_STRING;  // :151-155
-                } else if (out.unescaped_error) {
-                    code = MSJ_UNESCAPED_CHARS;  // :157-158
-                } else if (n + 3 > a.capacity) {
-                    code = MSJ_CAPACITY;
-                } else {
-                    if (!(a.flags & kFlagNoEmit)) {
-                        a.idx[n] = (uint32_t)a.trailer_len;      // :167-169
-                        a.idx[n + 1] = (uint32_t)a.trailer_len;  // :170-172
-                        a.idx[n + 2] = 0;                        // :173
-                    }
-                    if (n == 0)
-                        code = MSJ_EMPTY;  // :176-177
-                    else if ((a.flags & kFlagStrictUtf8) && out.utf8_error)
-                        code = MSJ_UTF8_ERROR;
-                }
-            }
-            out.code = code;
-            for (int k = 0; k < 5; k++) out.reserved[k] = 0;
-            *a.carry_out = out;
-            if (a.segment) {
-                a.segment->byte_base = a.segment_byte_base;
-                a.segment->byte_len = a.len;
-                a.segment->index_begin = cin.count;
-                a.segment->count = cnt_new;
-            }
         }
     }
 }

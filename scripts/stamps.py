@@ -48,6 +48,17 @@ def main():
     ok = raw[:, 0] > 0
     print(f"loop top -> prefetch issued : median {np.median((raw[:, 11] - raw[:, 0])[ok]):.0f}")
     print(f"prefetch issued -> compute  : median {np.median((raw[:, 1] - raw[:, 11])[ok]):.0f}")
+    okp = (raw[:, 15] > 0) & (raw[:, 8] > 0)
+    print(f"range-prefix wait (cycles): median {np.median((raw[:, 8] - raw[:, 15])[okp]):.0f} mean {np.mean((raw[:, 8] - raw[:, 15])[okp]):.0f}")
+    print(f"publish -> emit slot reached (cycles): median {np.median((raw[:, 15] - raw[:, 7])[okp]):.0f}")
+    rt = raw[:, 12:15]
+    okr = (rt[:, 0] > 0) & (rt[:, 1] > 0) & (rt[:, 2] > 0)
+    lat = (rt[:, 1] - rt[:, 0])[okr] * 10e-3  # 100 MHz ticks -> us
+    slack = (rt[:, 2] - rt[:, 1])[okr] * 10e-3
+    print(f"resolver latency publish->prefix: median {np.median(lat):.2f} us  p90 {np.percentile(lat, 90):.2f}  max {lat.max():.2f}  (n={okr.sum()})")
+    print(f"slack prefix->needed            : median {np.median(slack):.2f} us  p10 {np.percentile(slack, 10):.2f}  frac<0 {np.mean(slack < 0):.3f}")
+    span_rt = (rt[:, 2][okr].max() - rt[:, 0][okr].min()) * 10e-3
+    print(f"real-time span {span_rt:.1f} us")
     s = raw[:, 1:11]
     d = np.diff(s, axis=1)
     life = s[:, 9] - s[:, 0]
