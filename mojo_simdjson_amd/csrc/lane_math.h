@@ -45,21 +45,6 @@ MSJ_HD uint32_t perm(uint32_t s0, uint32_t s1, uint32_t sel) {
 
 MSJ_HD uint64_t u64(uint32_t lo, uint32_t hi) { return ((uint64_t)hi << 32) | lo; }
 
-// 8x8 bit-matrix transpose of one octet (8 bytes = lo,hi dwords): afterwards
-// byte k of {hi:lo} holds bit k of the 8 input bytes (bit r <- byte r).
-MSJ_HD void transpose_octet(uint32_t &lo, uint32_t &hi) {
-    uint32_t t;
-    t = (lo ^ (lo >> 7)) & 0x00AA00AAu;  lo ^= t ^ (t << 7);
-    t = (hi ^ (hi >> 7)) & 0x00AA00AAu;  hi ^= t ^ (t << 7);
-    t = (lo ^ (lo >> 14)) & 0x0000CCCCu; lo ^= t ^ (t << 14);
-    t = (hi ^ (hi >> 14)) & 0x0000CCCCu; hi ^= t ^ (t << 14);
-    // 4x4 nibble-block swap across the two dwords
-    uint32_t nlo = (lo & 0x0F0F0F0Fu) | ((hi << 4) & 0xF0F0F0F0u);
-    uint32_t nhi = ((lo >> 4) & 0x0F0F0F0Fu) | (hi & 0xF0F0F0F0u);
-    lo = nlo;
-    hi = nhi;
-}
-
 // 4x4 byte transpose: o[k] = bytes k of (a,b,c,d), a in the low byte.
 MSJ_HD void byte_transpose4(uint32_t a, uint32_t b, uint32_t c, uint32_t d, uint32_t &o0,
                             uint32_t &o1, uint32_t &o2, uint32_t &o3) {
@@ -73,22 +58,60 @@ MSJ_HD void byte_transpose4(uint32_t a, uint32_t b, uint32_t c, uint32_t d, uint
     o3 = perm(cd_hi, ab_hi, 0x07060302u);
 }
 
-// 64 bytes (16 little-endian dwords) -> 8 bit-planes. plane k bit i = bit k of byte i.
+// Exchange, between two registers, the bits whose in-register position has bit
+// log2(SH) set (in x) / clear (in y): afterwards x holds, for every position with
+// that bit clear, its own bit, and at the position + SH the bit y had at the
+// position; y symmetrically.  Two shift + two bit-select operations per pair.
+template <uint32_t SH, uint32_t M0>
+MSJ_HD void delta_swap(uint32_t &x, uint32_t &y) {
+    const uint32_t nx = (x & M0) | ((y << SH) & ~M0);
+    const uint32_t ny = ((x >> SH) & M0) | (y & ~M0);
+    x = nx;
+    y = ny;
+}
+
+// 64 bytes (16 little-endian dwords) -> 8 bit-planes: plane k bit i = bit k of byte i.
+//
+// Address view: input bit (dword d = d3 d2 d1 d0, byte j = j1 j0, bit k = k2 k1 k0) must
+// end up in plane (k2 k1 k0), half d3, at bit position (d2 d1 d0 j1 j0).  Step 1 moves
+// (d2 d1) into the byte address with 4x4 byte transposes (v_perm, 2 ops per register);
+// step 2 exchanges the three bit-address bits k2, k1, k0 with the register-index bits
+// d0, j1, j0 by three rounds of register-pair delta swaps (2 ops per register each):
+// 128 operations for 64 bytes.
 MSJ_HD void bitplanes(const uint32_t x[16], uint64_t p[8]) {
-    uint32_t tl[8], th[8];
+    // y[h][n][d0]: byte m of it = byte n of x[8h + 2m + d0]
+    uint32_t y[2][4][2];
 #pragma unroll
-    for (int j = 0; j < 8; j++) {
-        tl[j] = x[2 * j];
-        th[j] = x[2 * j + 1];
-        transpose_octet(tl[j], th[j]);
+    for (int h = 0; h < 2; h++)
+#pragma unroll
+        for (int d0 = 0; d0 < 2; d0++)
+            byte_transpose4(x[8 * h + 0 + d0], x[8 * h + 2 + d0], x[8 * h + 4 + d0], x[8 * h + 6 + d0],
+                            y[h][0][d0], y[h][1][d0], y[h][2][d0], y[h][3][d0]);
+    // k2 <-> d0  (distance 4): afterwards index [h][n][k2]
+#pragma unroll
+    for (int h = 0; h < 2; h++)
+#pragma unroll
+        for (int n = 0; n < 4; n++) delta_swap<4, 0x0F0F0F0Fu>(y[h][n][0], y[h][n][1]);
+    // k1 <-> j1  (distance 2): n = 2*j1 + j0; afterwards the j1 slot holds k1
+#pragma unroll
+    for (int h = 0; h < 2; h++)
+#pragma unroll
+        for (int j0 = 0; j0 < 2; j0++)
+#pragma unroll
+            for (int k2 = 0; k2 < 2; k2++) delta_swap<2, 0x33333333u>(y[h][j0][k2], y[h][2 + j0][k2]);
+    // k0 <-> j0  (distance 1): afterwards the j0 slot holds k0
+#pragma unroll
+    for (int h = 0; h < 2; h++)
+#pragma unroll
+        for (int k1 = 0; k1 < 2; k1++)
+#pragma unroll
+            for (int k2 = 0; k2 < 2; k2++) delta_swap<1, 0x55555555u>(y[h][2 * k1][k2], y[h][2 * k1 + 1][k2]);
+    // y[h][2*k1 + k0][k2] = plane (k2 k1 k0), bytes 32h .. 32h+31
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+        const int k2 = (k >> 2) & 1, k1 = (k >> 1) & 1, k0 = k & 1;
+        p[k] = u64(y[0][2 * k1 + k0][k2], y[1][2 * k1 + k0][k2]);
     }
-    uint32_t plo[8], phi[8];
-    byte_transpose4(tl[0], tl[1], tl[2], tl[3], plo[0], plo[1], plo[2], plo[3]);
-    byte_transpose4(tl[4], tl[5], tl[6], tl[7], phi[0], phi[1], phi[2], phi[3]);
-    byte_transpose4(th[0], th[1], th[2], th[3], plo[4], plo[5], plo[6], plo[7]);
-    byte_transpose4(th[4], th[5], th[6], th[7], phi[4], phi[5], phi[6], phi[7]);
-#pragma unroll
-    for (int k = 0; k < 8; k++) p[k] = u64(plo[k], phi[k]);
 }
 
 // Character classes of one block, as masks.

@@ -125,16 +125,18 @@ struct Block {
 // the end are redirected to the last 16-B piece that starts inside the input;
 // whatever they return is masked by `valid` in compute_tile.
 __device__ __forceinline__ void load_block(const KernelArgs &a, uint32_t tile, uint32_t lane, Block &b) {
-    const uint64_t blk_off = (uint64_t)tile * kTileBytes + (uint64_t)lane * 64u;
-    const uint64_t last_piece = (a.len - 1u) & ~15ull;  // buf is 16-B aligned
+    // one launch covers < 2^32 bytes (kSegmentBytes), so offsets fit 32 bits
+    const uint32_t len32 = (uint32_t)a.len;
+    const uint32_t blk_off = tile * kTileBytes + lane * 64u;
+    const uint32_t last_piece = (len32 - 1u) & ~15u;  // buf is 16-B aligned
 #pragma unroll
     for (int k = 0; k < 4; k++) {
-        const uint64_t off = blk_off + 16u * k;
+        const uint32_t off = blk_off + 16u * k;
         b.q[k] = *reinterpret_cast<const uint4 *>(a.buf + (off < last_piece ? off : last_piece));
     }
     const bool have_window = (tile > 0) || (a.flags & kFlagHasPrefix);
-    const int64_t woff = have_window ? (int64_t)((uint64_t)tile * kTileBytes) - 64 + (int64_t)lane
-                                     : (int64_t)(lane < a.len ? lane : a.len - 1u);
+    const int64_t woff = have_window ? (int64_t)(tile * kTileBytes) - 64 + (int64_t)lane
+                                     : (int64_t)(lane < len32 ? lane : len32 - 1u);
     b.wb = a.buf[woff];
 }
 
@@ -186,9 +188,8 @@ __device__ __forceinline__ Pending compute_tile(const KernelArgs &a, const uint3
                                                 const uint32_t lane, const Block &blk,
                                                 uint32_t &timeout, uint64_t &agg_word) {
     uint64_t *agg = a.ws + kDescOffset;
-    const uint64_t len = a.len;
-    const uint64_t tile_start = (uint64_t)tile * kTileBytes;
-    const uint64_t blk_off = tile_start + (uint64_t)lane * 64u;
+    const uint32_t len = (uint32_t)a.len;  // < 2^32 per launch
+    const uint32_t blk_off = tile * kTileBytes + lane * 64u;
     MSJ_STAMP(tile, 1);
 
     uint32_t x[16];
@@ -200,20 +201,22 @@ __device__ __forceinline__ Pending compute_tile(const KernelArgs &a, const uint3
         x[4 * k + 3] = blk.q[k].w;
     }
     uint64_t valid;  // bytes past the end behave as the reference's 0x20 padding (:103-107)
-    if (blk_off + 64u <= len)
-        valid = ~0ull;
-    else if (blk_off < len)
-        valid = (1ull << (len - blk_off)) - 1ull;
-    else
+    if (blk_off >= len)
         valid = 0ull;
+    else if (len - blk_off >= 64u)
+        valid = ~0ull;
+    else
+        valid = (1ull << (len - blk_off)) - 1ull;
 
     // ---- carries into the tile from the 64 bytes in front of it (wave-uniform)
     const bool have_window = (tile > 0) || (a.flags & kFlagHasPrefix);
     uint32_t tile_e_in, tile_ps_in, tile_u8_in;
     {
         const uint32_t wb = blk.wb;
-        // utf8 carry word of the window's last bytes (lane_math.h layout)
-        {
+        // utf8 carry word of the window's last bytes (lane_math.h layout); only the last
+        // three bytes matter, and only if they are not ASCII
+        tile_u8_in = 0;
+        if (have_window && (__ballot(wb >= 0x80u) >> 61) != 0ull) {
             const bool l234 = (wb >= 0xC0u) && (wb < 0xF8u);
             const bool l34 = (wb >= 0xE0u) && (wb < 0xF8u);
             const bool l4 = (wb >= 0xF0u) && (wb < 0xF8u);
@@ -224,7 +227,6 @@ __device__ __forceinline__ Pending compute_tile(const KernelArgs &a, const uint3
                          ((uint32_t)(m4 >> 61) << 3) | ((uint32_t)(mE0 >> 63) << 6) |
                          ((uint32_t)(mED >> 63) << 7) | ((uint32_t)(mF0 >> 63) << 8) |
                          ((uint32_t)(mF4 >> 63) << 9);
-            if (!have_window) tile_u8_in = 0;
         }
         if (tile == 0) {
             // exact state at the first byte of this launch
@@ -318,7 +320,7 @@ __device__ __forceinline__ Pending compute_tile(const KernelArgs &a, const uint3
     // ---- utf8
     uint32_t tile_pend = 0;
     bool u8err = false;
-    if (!(a.flags & kFlagNoUtf8)) {
+    if (!(a.flags & kFlagNoUtf8) && (tile_u8_in != 0u || __ballot(p[7] != 0ull) != 0ull)) {
         const Utf8Planes u8p = utf8_planes(p);
         const uint32_t my_u8c = utf8_carry_out(u8p);
         uint32_t prev_u8c = __shfl_up(my_u8c, 1);
@@ -374,6 +376,52 @@ __device__ __forceinline__ void emit_tile(const KernelArgs &a, uint32_t *stage, 
     const uint32_t v0 = (uint32_t)((uint64_t)r.tile * kTileBytes) + lane * 64u;
     uint32_t vpos = shift + lane_off;
     uint32_t tlo = (uint32_t)T, thi = (uint32_t)(T >> 32);
+    if (vend <= kStageWords) {
+        // ---- common case: the whole tile fits one staging round.  Straight-line bit
+        //      extraction (fully unrolled, LDS offsets are immediates, lanes drop out as
+        //      their mask runs empty) instead of a data-dependent loop.
+        uint32_t *dst = stage + vpos;
+        const uint32_t nlo = (uint32_t)__builtin_popcount(tlo);
+#pragma unroll
+        for (int k = 0; k < 32; k++) {
+            if (tlo == 0u) break;
+            dst[k] = v0 + (uint32_t)__builtin_ctz(tlo);
+            tlo &= tlo - 1u;
+        }
+        dst += nlo;
+        const uint32_t v1 = v0 + 32u;
+#pragma unroll
+        for (int k = 0; k < 32; k++) {
+            if (thi == 0u) break;
+            dst[k] = v1 + (uint32_t)__builtin_ctz(thi);
+            thi &= thi - 1u;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        const uint64_t gbase = base - shift;
+        for (uint32_t q = lane; 4u * q < vend; q += 64u) {
+            const uint32_t vq = 4u * q;
+            const uint4 val = *reinterpret_cast<const uint4 *>(&stage[vq]);
+            const uint64_t g = gbase + vq;
+            if (fits && vq >= shift && vq + 4u <= vend) {
+                *reinterpret_cast<uint4 *>(&a.idx[g]) = val;
+            } else {
+                const uint32_t vv[4] = {val.x, val.y, val.z, val.w};
+#pragma unroll
+                for (uint32_t j = 0; j < 4; j++) {
+                    const uint32_t v = vq + j;
+                    if (v >= shift && v < vend && g + j < a.capacity) a.idx[g + j] = vv[j];
+                }
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();  // stage is reused by the next tile
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        MSJ_STAMP(r.tile, 10);
+        return;
+    }
+    // ---- dense tile (more than kStageWords indices): general multi-round path
     for (uint32_t r0 = 0; r0 < vend; r0 += kStageWords) {
         const uint32_t r1 = r0 + kStageWords;
         while (tlo && vpos < r1) {
