@@ -14,6 +14,7 @@ constexpr uint32_t kDescOffset = 8;                // ws[0] = tile ticket, ws[1]
 constexpr uint32_t kStageWords = 1024;             // per-wave LDS staging of indices (4 KiB) per round
 constexpr uint32_t kBatch = 2;                     // tiles per wave per ticket range = emission deferral depth
 constexpr uint32_t kRange = kWaves * kBatch;       // tiles per ticket range = per range aggregate
+constexpr uint32_t kPendSlots = 2 * kBatch;        // emission is deferred by two ranges
 constexpr int kResolveE = 4;                       // tiles folded per resolver lane
 constexpr uint32_t kResolveChunk = 64u * kResolveE; // tiles per resolver chunk (one wave, one round)
 constexpr uint32_t kSpinLimit = 1u << 18;          // bounded polling (internal_error on expiry, ~0.3 s)

@@ -97,6 +97,11 @@ struct Shared {
     uint32_t pad[1];
     // per-wave index staging for coalesced stores
     uint32_t stage[kWaves][kStageWords] __attribute__((aligned(16)));
+    // computed-but-not-yet-emitted tiles (two ranges deep), per wave and slot:
+    // per lane T0|T1 masks and the packed exclusive count scan; per slot a few words
+    uint4 pend_masks[kWaves][kPendSlots][64];
+    uint32_t pend_excl[kWaves][kPendSlots][64];
+    uint32_t pend_meta[kWaves][kPendSlots][4];  // tile (~0 = empty), tile_cnt, in_cnt, in_s
 };
 
 // Bounded poll of one descriptor until its status is non-zero.
@@ -180,7 +185,6 @@ struct Pending {
     uint32_t tile;
     uint32_t in_cnt;     // structurals of the range before this tile: range state 0 | state 1 << 16
     uint32_t in_s;       // tile's incoming in-string state: bit 0 for range state 0, bit 1 for state 1
-    uint32_t range_id;
 };
 
 // ---- one tile: masks, carries, counts; publishes the tile aggregate ------------
@@ -508,6 +512,7 @@ __device__ __forceinline__ void worker_wave(const KernelArgs &a, Shared &sh, con
         sh.range_lo[0] = atomicAdd(ticket_ctr, kRange);
         sh.range_lo[1] = atomicAdd(ticket_ctr, kRange);
     }
+    if (lane < kPendSlots) sh.pend_meta[wave][lane][0] = 0xFFFFFFFFu;  // all slots empty
     __syncthreads();
     uint32_t lo_cur = sh.range_lo[0], lo_next = sh.range_lo[1];
     const uint64_t count0 = a.carry_in->count;  // launch invariant: read once
@@ -516,25 +521,26 @@ __device__ __forceinline__ void worker_wave(const KernelArgs &a, Shared &sh, con
     Block cur;
     load_block(a, lo_cur + wave < ntiles ? lo_cur + wave : ntiles - 1u, lane, cur);
     touch_block(cur);  // loop invariant: `cur` has arrived (no vmcnt wait on it inside the loop)
-    Pending pend[kBatch];
-    bool has[kBatch];
-#pragma unroll
-    for (uint32_t j = 0; j < kBatch; j++) has[j] = false;
-    uint64_t rp_word = 0;   // prefix word of the previous range (the one being emitted)
-    uint32_t prev_range = 0;
-    bool have_prev = false;
+    // Emission is deferred by TWO ranges: the tile computed in slot (r & 1, j) replaces,
+    // and first emits, the tile of range r-2 kept in that slot (in LDS).  Its range
+    // prefix has had a whole range of compute time to arrive, which absorbs both the
+    // resolver's latency and the skew between workgroups.
+    uint32_t range_of[2] = {0u, 0u};
+    bool have_range[2] = {false, false};
     uint32_t r = 0;
     while (lo_cur < ntiles) {  // uniform across the workgroup
+        const uint32_t par = r & 1u;
         // range r+2, requested now, needed at the end of this range
         uint32_t req_reg = 0;
         if (tid == 0) req_reg = ticket_request(ticket_ctr, 0u, kRange);
-        // the previous range's prefix: its aggregate was published one barrier ago
-        rp_word = ld_desc(&rpre[have_prev ? prev_range : 0u]);
+        // prefix of range r-2 (published two barriers ago)
+        uint64_t rp_word = ld_desc(&rpre[have_range[par] ? range_of[par] : 0u]);
 #pragma unroll
         for (uint32_t j = 0; j < kBatch; j++) {
             const uint32_t t_cur = lo_cur + kWaves * j + wave;
             const uint32_t t_nxt = (j + 1u < kBatch) ? t_cur + kWaves : lo_next + wave;
             const bool valid_tile = t_cur < ntiles;
+            const uint32_t slot = par * kBatch + j;
             MSJ_STAMP(valid_tile ? t_cur : ntiles - 1u, 0);
             // request the next tile's bytes
             Block nxt;  // past the last tile: harmless re-read of the last tile (branch-free)
@@ -542,6 +548,10 @@ __device__ __forceinline__ void worker_wave(const KernelArgs &a, Shared &sh, con
             MSJ_STAMP(valid_tile ? t_cur : ntiles - 1u, 11);
             uint64_t agg_word = kAgg;  // a tile past the end: identity
             Pending now;
+            now.T0 = 0;
+            now.T1 = 0;
+            now.excl = 0;
+            now.tile_cnt = 0;
             if (valid_tile) now = compute_tile(a, t_cur, lane, cur, timeout, agg_word);
             // everything requested above has had a whole compute phase to arrive; wait for
             // it before this iteration's first store goes into the queue
@@ -550,24 +560,36 @@ __device__ __forceinline__ void worker_wave(const KernelArgs &a, Shared &sh, con
             touch_u64(rp_word);
             if (lane == 0) {
                 if (valid_tile) st_desc(&a.ws[kDescOffset + t_cur], agg_word);  // carries for t_cur + 1
-                sh.tagg[r & 1u][kWaves * j + wave] = agg_word;
+                sh.tagg[par][kWaves * j + wave] = agg_word;
             }
             MSJ_STAMP(valid_tile ? t_cur : ntiles - 1u, 7);
             MSJ_RSTAMP(t_cur, 12, lane == 0 && valid_tile);
-            // emit the tile of the previous range that sits in this slot
-            if (has[j]) {
-                MSJ_STAMP(pend[j].tile, 15);
-                rp_word = range_prefix(rpre, prev_range, rp_word, timeout);
-                emit_tile(a, stage, lane, pend[j], rp_word, count0, timeout);
+            // emit the tile of range r-2 that sits in this slot, then take the slot
+            const uint32_t old_tile = sh.pend_meta[wave][slot][0];
+            if (old_tile != 0xFFFFFFFFu) {  // uniform
+                Pending old;
+                const uint4 m = sh.pend_masks[wave][slot][lane];
+                old.T0 = u64(m.x, m.y);
+                old.T1 = u64(m.z, m.w);
+                old.excl = sh.pend_excl[wave][slot][lane];
+                old.tile = old_tile;
+                old.tile_cnt = sh.pend_meta[wave][slot][1];
+                old.in_cnt = sh.pend_meta[wave][slot][2];
+                old.in_s = sh.pend_meta[wave][slot][3];
+                MSJ_STAMP(old_tile, 15);
+                rp_word = range_prefix(rpre, range_of[par], rp_word, timeout);
+                emit_tile(a, stage, lane, old, rp_word, count0, timeout);
             }
-            if (valid_tile) {
-                pend[j] = now;
-                pend[j].range_id = lo_cur / kRange;
+            sh.pend_masks[wave][slot][lane] =
+                make_uint4((uint32_t)now.T0, (uint32_t)(now.T0 >> 32), (uint32_t)now.T1, (uint32_t)(now.T1 >> 32));
+            sh.pend_excl[wave][slot][lane] = now.excl;
+            if (lane == 0) {
+                sh.pend_meta[wave][slot][0] = valid_tile ? t_cur : 0xFFFFFFFFu;
+                sh.pend_meta[wave][slot][1] = now.tile_cnt;
             }
-            has[j] = valid_tile;
             cur = nxt;
         }
-        if (tid == 0) sh.range_lo[r & 1u] = req_reg;  // arrived: vmcnt(0) above
+        if (tid == 0) sh.range_lo[par] = req_reg;  // arrived: vmcnt(0) above
         __syncthreads();
         // ---- fold the range's kRange tile aggregates in tile order (every wave does it:
         //      it is a few dozen scalar operations) -> the range aggregate for the resolver,
@@ -576,16 +598,10 @@ __device__ __forceinline__ void worker_wave(const KernelArgs &a, Shared &sh, con
             uint32_t s0 = 0, s1 = 1, c0s = 0, c1s = 0, e0s = 0, e1s = 0, u8s = 0, pzs = 0;
 #pragma unroll
             for (uint32_t k = 0; k < kRange; k++) {
-                const uint64_t w = sh.tagg[r & 1u][k];
-                if (k % kWaves == wave) {
-                    const uint32_t j = k / kWaves;  // compile-time after unrolling
-#pragma unroll
-                    for (uint32_t jj = 0; jj < kBatch; jj++) {
-                        if (jj == j) {
-                            pend[jj].in_s = s0 | (s1 << 1);
-                            pend[jj].in_cnt = c0s | (c1s << 16);
-                        }
-                    }
+                const uint64_t w = sh.tagg[par][k];
+                if (k % kWaves == wave && lane == 0) {
+                    sh.pend_meta[wave][par * kBatch + k / kWaves][2] = c0s | (c1s << 16);
+                    sh.pend_meta[wave][par * kBatch + k / kWaves][3] = s0 | (s1 << 1);
                 }
                 const uint32_t p = (uint32_t)(w >> 61) & 1u;
                 const uint32_t c0 = (uint32_t)w & 0x7FFFu, c1 = (uint32_t)(w >> 15) & 0xFFFFu;
@@ -606,19 +622,34 @@ __device__ __forceinline__ void worker_wave(const KernelArgs &a, Shared &sh, con
                                                     (uint64_t)c0s);
             }
         }
-        prev_range = lo_cur / kRange;
-        have_prev = true;
+        range_of[par] = lo_cur / kRange;
+        have_range[par] = true;
         lo_cur = lo_next;
-        lo_next = sh.range_lo[r & 1u];
+        lo_next = sh.range_lo[par];
         r++;
     }
-    if (have_prev) {
+    // ---- drain: the older range first
+#pragma unroll
+    for (uint32_t step = 0; step < 2; step++) {
+        const uint32_t par = (r + step) & 1u;
+        if (!have_range[par]) continue;
         uint64_t w = 0;
 #pragma unroll
         for (uint32_t j = 0; j < kBatch; j++) {
-            if (has[j]) {
-                w = range_prefix(rpre, prev_range, w, timeout);
-                emit_tile(a, stage, lane, pend[j], w, count0, timeout);
+            const uint32_t slot = par * kBatch + j;
+            const uint32_t old_tile = sh.pend_meta[wave][slot][0];
+            if (old_tile != 0xFFFFFFFFu) {
+                Pending old;
+                const uint4 m = sh.pend_masks[wave][slot][lane];
+                old.T0 = u64(m.x, m.y);
+                old.T1 = u64(m.z, m.w);
+                old.excl = sh.pend_excl[wave][slot][lane];
+                old.tile = old_tile;
+                old.tile_cnt = sh.pend_meta[wave][slot][1];
+                old.in_cnt = sh.pend_meta[wave][slot][2];
+                old.in_s = sh.pend_meta[wave][slot][3];
+                w = range_prefix(rpre, range_of[par], w, timeout);
+                emit_tile(a, stage, lane, old, w, count0, timeout);
             }
         }
     }
@@ -887,7 +918,7 @@ __device__ void resolver(const KernelArgs &a, Shared &sh) {
     }
 }
 
-__global__ __launch_bounds__(kThreads) void stage1_kernel(const KernelArgs a) {
+__global__ __launch_bounds__(kThreads, 4) void stage1_kernel(const KernelArgs a) {
     __shared__ Shared sh;
     const uint32_t tid = threadIdx.x;
     // The first workgroup to get here becomes the resolver (it is running, so the

@@ -51,6 +51,14 @@ def main():
     okp = (raw[:, 15] > 0) & (raw[:, 8] > 0)
     print(f"range-prefix wait (cycles): median {np.median((raw[:, 8] - raw[:, 15])[okp]):.0f} mean {np.mean((raw[:, 8] - raw[:, 15])[okp]):.0f}")
     print(f"publish -> emit slot reached (cycles): median {np.median((raw[:, 15] - raw[:, 7])[okp]):.0f}")
+    w = (raw[:, 8] - raw[:, 15])[okp]
+    print("range-prefix wait percentiles (cycles):", {q: int(np.percentile(w, q)) for q in (50, 75, 90, 95, 99, 99.9)})
+    print(f"sum of waits / sum of lifetimes: {w.clip(0, 10**9).sum() / max(1, (raw[:, 10] - raw[:, 1])[okp].clip(0, 10**9).sum()):.3f}")
+    tt = raw[:, 14][okp]; tt = (tt - tt.min()) * 10e-3
+    for lo in range(0, int(tt.max()) + 1, 100):
+        sel = (tt >= lo) & (tt < lo + 100)
+        if sel.any():
+            print(f"  t=[{lo:5d},{lo+100:5d}) us: tiles {sel.sum():6d} median wait {np.median(w[sel]):8.0f} mean {w[sel].clip(0,10**9).mean():10.0f}")
     rt = raw[:, 12:15]
     okr = (rt[:, 0] > 0) & (rt[:, 1] > 0) & (rt[:, 2] > 0)
     lat = (rt[:, 1] - rt[:, 0])[okr] * 10e-3  # 100 MHz ticks -> us
