@@ -30,7 +30,7 @@ from mojo_simdjson_amd.device import Stage1Device  # noqa: E402
 
 HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
 UNIT_BYTES = 64 << 20
-TILE = 16384
+TILE = 16384  # shard bases are multiples of this (a multiple of the kernel's 4 KiB tile)
 
 
 def build_stream_shard(d_unit, unit_len, start, length, device):
@@ -108,16 +108,23 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
+    # one process per GPU; MSJ_BENCH_BACKEND=gloo lets several ranks share one GPU to
+    # rehearse the N>1 path on a one-GPU box (never used for reported numbers)
+    backend = os.environ.get("MSJ_BENCH_BACKEND", "nccl")
+    dev_index = local_rank % max(1, torch.cuda.device_count())
+    torch.cuda.set_device(dev_index)
+    device = torch.device("cuda", dev_index)
     dist = None
     if world > 1:
         import torch.distributed as dist_mod
 
         dist = dist_mod
-        dist.init_process_group("nccl", device_id=device)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=device)
+        else:
+            dist.init_process_group(backend)
 
-    dev = Stage1Device(local_rank)
+    dev = Stage1Device(dev_index)
     flags = 2 if args.no_utf8 else 0
 
     # ---- synthetic stream: one generated unit, repeated (identical on every rank)
@@ -193,7 +200,7 @@ def main():
     if unit_n is not None:
         assert total_count == unit_n * (total_len // unit_len), (total_count, unit_n)
 
-    t = torch.tensor([dt], dtype=torch.float64, device=device)
+    t = torch.tensor([dt], dtype=torch.float64, device=device if backend == "nccl" else "cpu")
     if dist is not None:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     dt_max = float(t.item())
@@ -202,10 +209,11 @@ def main():
         ms_per_step = dt_max / args.steps * 1e3
         value = total_len * args.steps / dt_max / 1e9
         local_count = int(res.count) if world > 1 else total_count
-        # dominant kernel: stage1_kernel, one launch per step on this rank's stream;
-        # HIP-event time over the timed region / steps (includes the per-launch
-        # descriptor memset, ~0.5 MiB).  N>1 runs a summary launch + an emit launch.
-        launches = 1 if world == 1 else 2
+        # dominant kernel: stage1_kernel, one launch per step on this rank's stream
+        # (N>1: one launch per shard unless a speculation was refuted); HIP-event time
+        # over the timed region / steps, which also covers the small per-launch
+        # descriptor memset and, for N>1, the host side of the all-gather.
+        launches = 1
         alg_bytes = shard_len + 4 * local_count
         k_ms = ev_ms / args.steps / launches
         achieved = alg_bytes / (k_ms * 1e-3) / 1e9

@@ -83,6 +83,10 @@ __device__ __forceinline__ uint32_t bcast(uint32_t v, int src_lane) {
         if ((cond) && a.stamps)                                                           \
             a.stamps[(uint64_t)(t) * 16 + (k)] = __builtin_amdgcn_s_memrealtime();        \
     } while (0)
+#elif defined(MSJ_MARKS)
+// Analysis build only (make marks): section markers in the .s, for per-section instruction counts.
+#define MSJ_STAMP(t, k) asm volatile("; MSJ_MARK " #k)
+#define MSJ_RSTAMP(t, k, cond) do {} while (0)
 #else
 #define MSJ_STAMP(t, k) do {} while (0)
 #define MSJ_RSTAMP(t, k, cond) do {} while (0)

@@ -125,3 +125,28 @@ def test_gloo_world2_exchange():
         assert res[0][1:] == (0, 0, 0)
         e, s, ps = serial_state(data[:cut])
         assert res[1][1:] == (e, ps, s), (data, cut)
+
+
+def test_guess_and_verify_chain():
+    """The speculation is only a guess; verify_chain must accept exactly the right ones."""
+    rng = random.Random(4)
+    doc = (b'{"a":"x y","b":[1,2,"q:\\"z\\"",true],"c":"k:"}' * 40)
+    right = wrong = 0
+    for _ in range(400):
+        cut = rng.randint(70, len(doc) - 70)
+        halo, head = doc[cut - 64:cut], doc[cut:cut + 4096]
+        e, s, ps = serial_state(doc[:cut])
+        hc = sharded.halo_carry(halo)
+        assert hc == (e, ps)
+        g = sharded.guess_in_string(halo, head, e)
+        right += g == s
+        wrong += g != s
+        # rank 1 used guess g: the chain check must flag it iff g != s
+        e1, s1, ps1 = serial_state(doc)
+        e0, s0, ps0 = serial_state(doc[:cut])
+        rep = [dict(s_used=0, e_used=0, ps_used=0, s_out=s0, e_out=e0, ps_out=ps0),
+               dict(s_used=g, e_used=e, ps_used=ps, s_out=s1 ^ s ^ g, e_out=e1, ps_out=ps1)]
+        first_wrong, true_in = sharded.verify_chain(rep)
+        assert (first_wrong == 2) == (g == s)
+        assert true_in[1] == (s, e, ps)
+    assert right > 300 and wrong > 0  # good but not perfect: the re-run path matters

@@ -326,3 +326,93 @@ def test_full_size_1gib_replication_property(torch_mod, dev, oracle, name):
     # size-independent properties: strictly increasing, every index on a plausible byte
     v = d_idx[: n * reps].to(torch.int64) & 0xFFFFFFFF
     assert bool((v[1:] > v[:-1]).all())
+
+
+def _sharded_dataset(name):
+    from mojo_simdjson_amd import synth
+
+    if name == "guesswrong":
+        # the cut falls inside a string whose closing quote follows a ':' -> the in_string
+        # speculation of rank 1 is wrong and it must run again with the exact carry
+        return b'["' + b"a" * (6 * 16384) + b':",1,2,"zz"]'
+    u = synth.workload(name, 3 << 20)
+    data = u.tobytes() * 2
+    if name == "minified":  # extra tail with escapes
+        data = data[:-1] + b',"k":"' + b"\\\\" * 40 + b'\\"x"}'
+    return data
+
+
+_SHARDED_SETS = ("utf8", "minified", "guesswrong")
+
+
+def _sharded_worker(rank, world, port, q):
+    """Two ranks sharing cuda:0 (gloo for the tiny collective): the same code path the
+    8-GPU bench runs over RCCL, checked against the oracle on the whole stream."""
+    import torch
+    import torch.distributed as dist
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from mojo_simdjson_amd.device import Stage1Device
+        from mojo_simdjson_amd.sharded import ShardedStage1
+
+        dev = Stage1Device(0)
+        results = []
+        for name in _SHARDED_SETS:
+            data = _sharded_dataset(name)
+            total = len(data)
+            shard_nominal = -(-total // world)
+            shard_nominal = -(-shard_nominal // 16384) * 16384
+            start = rank * shard_nominal
+            end = min(total, start + shard_nominal)
+            halo = 64 if rank > 0 else 0
+            arr = np.frombuffer(data[start - halo:end], dtype=np.uint8).copy()
+            d_alloc = torch.from_numpy(arr).to(dev.device)
+            d_shard = d_alloc[halo:]
+            d_idx = torch.full(((end - start) + 3,), -1, dtype=torch.int32, device=dev.device)
+            sh = ShardedStage1(dev, rank, world)
+            code, total_count, c = sh.run(d_shard, end - start, d_idx, total, has_prefix=(rank > 0))
+            got = d_idx[: int(c.count) + (3 if rank == world - 1 else 0)].cpu().numpy().view(np.uint32)
+            results.append((name, code, total_count, int(c.count), start, got.tobytes(), sh.reruns))
+        q.put((rank, results))
+        dev.close()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_sharded_two_ranks_one_gpu(oracle):
+    import socket
+
+    import torch.multiprocessing as mp
+
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_sharded_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    out = dict(q.get(timeout=300) for _ in range(2))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for i, name in enumerate(_SHARDED_SETS):
+        data = _sharded_dataset(name)
+        code, n, idx = helpers.run_oracle(oracle.msj_oracle_stage1, data)
+        assert code == 0
+        merged = []
+        for rank in range(2):
+            rname, rcode, total_count, cnt, start, raw, reruns = out[rank][i]
+            assert rname == name and rcode == code and total_count == n
+            if name == "guesswrong" and rank == 1:
+                assert reruns == 1  # the refuted speculation was repaired by exactly one re-run
+            vals = np.frombuffer(raw, dtype=np.uint32).astype(np.int64)
+            if rank == 1:
+                assert list(vals[-3:]) == [len(data), len(data), 0]
+                vals = vals[:-3]
+            merged.append(vals + start)  # shard-relative offsets -> stream offsets
+        merged = np.concatenate(merged)
+        assert np.array_equal(merged, idx[:n].astype(np.int64)), name
