@@ -70,6 +70,14 @@ __device__ __forceinline__ uint32_t lanes_below(uint64_t m) {
 __device__ __forceinline__ uint32_t bcast(uint32_t v, int src_lane) {
     return (uint32_t)__builtin_amdgcn_readlane((int)v, src_lane);
 }
+// A value every lane holds identically (loaded from one address): move it to an SGPR so
+// that everything derived from it is scalar code.
+__device__ __forceinline__ uint32_t uniform32(uint32_t v) {
+    return (uint32_t)__builtin_amdgcn_readfirstlane((int)v);
+}
+__device__ __forceinline__ uint64_t uniform64(uint64_t v) {
+    return ((uint64_t)uniform32((uint32_t)(v >> 32)) << 32) | uniform32((uint32_t)v);
+}
 
 #ifdef MSJ_STAMPS
 // Diagnostic build only: phase timestamps per tile (never compiled into the product .so).
@@ -179,6 +187,35 @@ __device__ __forceinline__ uint32_t ticket_request(unsigned int *ctr, uint32_t l
 __device__ __forceinline__ uint32_t ticket_value(uint32_t reg) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     return bcast(reg, 0);
+}
+
+// BitIndexer.write_index (json_structural_indexer.mojo:39-44) for one 32-bit half mask:
+// writes (value_base | bit position) of every set bit, ascending, to consecutive LDS words.
+// Straight-line: 32 steps, lanes drop out through EXEC as their mask runs empty (v_cmpx),
+// the wave leaves as soon as no lane is left; the LDS offsets are immediates.  (The
+// compiler's version of this loop spends ~8 scalar instructions per step on exec-mask
+// bookkeeping.)
+__device__ __forceinline__ void scatter_bits32(uint32_t t, uint32_t lds_byte_addr, uint32_t value_base) {
+    uint32_t tmp1, tmp2;
+    uint64_t save;
+    asm volatile(
+        "s_mov_b64 %[save], exec\n"
+        ".set msj_sb_off, 0\n"
+        ".rept 32\n"
+        "v_cmpx_ne_u32_e32 vcc, 0, %[t]\n"
+        "s_cbranch_execz 1f\n"
+        "v_ffbl_b32_e32 %[a], %[t]\n"
+        "v_or_b32_e32 %[a], %[a], %[vb]\n"
+        "ds_write_b32 %[addr], %[a] offset:msj_sb_off\n"
+        "v_add_u32_e32 %[b], -1, %[t]\n"
+        "v_and_b32_e32 %[t], %[b], %[t]\n"
+        ".set msj_sb_off, msj_sb_off+4\n"
+        ".endr\n"
+        "1:\n"
+        "s_mov_b64 exec, %[save]\n"
+        : [t] "+v"(t), [a] "=&v"(tmp1), [b] "=&v"(tmp2), [save] "=&s"(save)
+        : [addr] "v"(lds_byte_addr), [vb] "v"(value_base)
+        : "vcc", "memory");
 }
 
 // What a computed tile keeps in registers until its indices are emitted.
@@ -368,7 +405,8 @@ __device__ __forceinline__ void emit_tile(const KernelArgs &a, uint32_t *stage, 
                                           const uint64_t count0, uint32_t &timeout) {
     MSJ_STAMP(r.tile, 8);
     MSJ_RSTAMP(r.tile, 14, lane == 0);
-    // the range's prefix (resolver) + the tile's position inside the range (local fold)
+    // the range's prefix (resolver) + the tile's position inside the range (local fold);
+    // all of it is wave-uniform: tell the compiler (readfirstlane) so it stays scalar
     const uint32_t q = (uint32_t)(rpre_word >> 61) & 1u;
     const uint32_t s_in = (r.in_s >> q) & 1u;
     const uint64_t base = count0 + (uint64_t)(uint32_t)rpre_word + (q ? (r.in_cnt >> 16) : (r.in_cnt & 0xFFFFu));
@@ -388,22 +426,12 @@ __device__ __forceinline__ void emit_tile(const KernelArgs &a, uint32_t *stage, 
         // ---- common case: the whole tile fits one staging round.  Straight-line bit
         //      extraction (fully unrolled, LDS offsets are immediates, lanes drop out as
         //      their mask runs empty) instead of a data-dependent loop.
-        uint32_t *dst = stage + vpos;
+        // v0 is a multiple of 64, so value_base | bit == value_base + bit
+        const uint32_t lds0 = (uint32_t)(uintptr_t)(stage + vpos);  // LDS byte address
         const uint32_t nlo = (uint32_t)__builtin_popcount(tlo);
-#pragma unroll
-        for (int k = 0; k < 32; k++) {
-            if (tlo == 0u) break;
-            dst[k] = v0 + (uint32_t)__builtin_ctz(tlo);
-            tlo &= tlo - 1u;
-        }
-        dst += nlo;
-        const uint32_t v1 = v0 + 32u;
-#pragma unroll
-        for (int k = 0; k < 32; k++) {
-            if (thi == 0u) break;
-            dst[k] = v1 + (uint32_t)__builtin_ctz(thi);
-            thi &= thi - 1u;
-        }
+        scatter_bits32(tlo, lds0, v0);
+        scatter_bits32(thi, lds0 + 4u * nlo, v0 | 32u);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -519,7 +547,7 @@ __device__ __forceinline__ void worker_wave(const KernelArgs &a, Shared &sh, con
     if (lane < kPendSlots) sh.pend_meta[wave][lane][0] = 0xFFFFFFFFu;  // all slots empty
     __syncthreads();
     uint32_t lo_cur = sh.range_lo[0], lo_next = sh.range_lo[1];
-    const uint64_t count0 = a.carry_in->count;  // launch invariant: read once
+    const uint64_t count0 = uniform64(a.carry_in->count);  // launch invariant: read once
     uint32_t timeout = 0;
 
     Block cur;
@@ -569,7 +597,7 @@ __device__ __forceinline__ void worker_wave(const KernelArgs &a, Shared &sh, con
             MSJ_STAMP(valid_tile ? t_cur : ntiles - 1u, 7);
             MSJ_RSTAMP(t_cur, 12, lane == 0 && valid_tile);
             // emit the tile of range r-2 that sits in this slot, then take the slot
-            const uint32_t old_tile = sh.pend_meta[wave][slot][0];
+            const uint32_t old_tile = uniform32(sh.pend_meta[wave][slot][0]);
             if (old_tile != 0xFFFFFFFFu) {  // uniform
                 Pending old;
                 const uint4 m = sh.pend_masks[wave][slot][lane];
@@ -577,11 +605,12 @@ __device__ __forceinline__ void worker_wave(const KernelArgs &a, Shared &sh, con
                 old.T1 = u64(m.z, m.w);
                 old.excl = sh.pend_excl[wave][slot][lane];
                 old.tile = old_tile;
-                old.tile_cnt = sh.pend_meta[wave][slot][1];
-                old.in_cnt = sh.pend_meta[wave][slot][2];
-                old.in_s = sh.pend_meta[wave][slot][3];
+                old.tile_cnt = uniform32(sh.pend_meta[wave][slot][1]);
+                old.in_cnt = uniform32(sh.pend_meta[wave][slot][2]);
+                old.in_s = uniform32(sh.pend_meta[wave][slot][3]);
                 MSJ_STAMP(old_tile, 15);
                 rp_word = range_prefix(rpre, range_of[par], rp_word, timeout);
+                rp_word = uniform64(rp_word);
                 emit_tile(a, stage, lane, old, rp_word, count0, timeout);
             }
             sh.pend_masks[wave][slot][lane] =
