@@ -70,6 +70,22 @@ __device__ __forceinline__ uint32_t lanes_below(uint64_t m) {
 __device__ __forceinline__ uint32_t bcast(uint32_t v, int src_lane) {
     return (uint32_t)__builtin_amdgcn_readlane((int)v, src_lane);
 }
+// Wave-wide inclusive add scan and one-lane shift on the DPP path (gfx9 row_shr /
+// row_bcast / wave_shr): 6 resp. 1 VALU operations, no LDS round trip.
+__device__ __forceinline__ uint32_t dpp_add_scan(uint32_t v) {
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xF, 0xF, false);  // row_shr:1
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xF, 0xF, false);  // row_shr:2
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xF, 0xF, false);  // row_shr:4
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xF, 0xF, false);  // row_shr:8
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xA, 0xF, false);  // row_bcast:15
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xC, 0xF, false);  // row_bcast:31
+    return v;
+}
+// lane l gets v of lane l-1; lane 0 gets `first`
+__device__ __forceinline__ uint32_t dpp_shift_up1(uint32_t v, uint32_t first) {
+    return (uint32_t)__builtin_amdgcn_update_dpp((int)first, (int)v, 0x138, 0xF, 0xF, false);  // wave_shr:1
+}
+
 // A value every lane holds identically (loaded from one address): move it to an SGPR so
 // that everything derived from it is scalar code.
 __device__ __forceinline__ uint32_t uniform32(uint32_t v) {
@@ -253,25 +269,22 @@ __device__ __forceinline__ Pending compute_tile(const KernelArgs &a, const uint3
     else
         valid = (1ull << (len - blk_off)) - 1ull;
 
-    // ---- carries into the tile from the 64 bytes in front of it (wave-uniform)
+    // ---- carries into the tile from the 64 bytes in front of it (wave-uniform; apart from
+    //      one compare + ballot for the backslash run this is scalar code on byte[-1..-3])
     const bool have_window = (tile > 0) || (a.flags & kFlagHasPrefix);
-    uint32_t tile_e_in, tile_ps_in, tile_u8_in;
+    uint32_t tile_e_in, tile_ps_in, tile_u8_in = 0;
     {
         const uint32_t wb = blk.wb;
-        // utf8 carry word of the window's last bytes (lane_math.h layout); only the last
-        // three bytes matter, and only if they are not ASCII
-        tile_u8_in = 0;
-        if (have_window && (__ballot(wb >= 0x80u) >> 61) != 0ull) {
-            const bool l234 = (wb >= 0xC0u) && (wb < 0xF8u);
-            const bool l34 = (wb >= 0xE0u) && (wb < 0xF8u);
-            const bool l4 = (wb >= 0xF0u) && (wb < 0xF8u);
-            const uint64_t m234 = __ballot(l234), m34 = __ballot(l34), m4 = __ballot(l4);
-            const uint64_t mE0 = __ballot(wb == 0xE0u), mED = __ballot(wb == 0xEDu);
-            const uint64_t mF0 = __ballot(wb == 0xF0u), mF4 = __ballot(wb == 0xF4u);
-            tile_u8_in = (uint32_t)(m234 >> 63) | ((uint32_t)(m34 >> 62) << 1) |
-                         ((uint32_t)(m4 >> 61) << 3) | ((uint32_t)(mE0 >> 63) << 6) |
-                         ((uint32_t)(mED >> 63) << 7) | ((uint32_t)(mF0 >> 63) << 8) |
-                         ((uint32_t)(mF4 >> 63) << 9);
+        const uint32_t b1 = bcast(wb, 63), b2 = bcast(wb, 62), b3 = bcast(wb, 61);  // byte[-1], [-2], [-3]
+        if (have_window && ((b1 | b2 | b3) & 0x80u)) {
+            // utf8 carry word of the window's last bytes (lane_math.h layout)
+            const uint32_t l1 = (b1 >= 0xC0u && b1 < 0xF8u), l1_34 = (b1 >= 0xE0u && b1 < 0xF8u);
+            const uint32_t l1_4 = (b1 >= 0xF0u && b1 < 0xF8u);
+            const uint32_t l2_34 = (b2 >= 0xE0u && b2 < 0xF8u), l2_4 = (b2 >= 0xF0u && b2 < 0xF8u);
+            const uint32_t l3_4 = (b3 >= 0xF0u && b3 < 0xF8u);
+            tile_u8_in = l1 | (l2_34 << 1) | (l1_34 << 2) | (l3_4 << 3) | (l2_4 << 4) | (l1_4 << 5) |
+                         ((uint32_t)(b1 == 0xE0u) << 6) | ((uint32_t)(b1 == 0xEDu) << 7) |
+                         ((uint32_t)(b1 == 0xF0u) << 8) | ((uint32_t)(b1 == 0xF4u) << 9);
         }
         if (tile == 0) {
             // exact state at the first byte of this launch
@@ -279,19 +292,17 @@ __device__ __forceinline__ Pending compute_tile(const KernelArgs &a, const uint3
             tile_ps_in = a.carry_in->prev_scalar & 1u;
         } else {
             const uint64_t WB = __ballot(wb == 0x5Cu);
-            const uint64_t WQ = __ballot(wb == 0x22u);
-            const bool nonscalar = (wb == 0x20u) | (wb == 0x09u) | (wb == 0x0Au) | (wb == 0x0Du) |
-                                   (wb == 0x0Cu) | (wb == 0x1Au) | (wb == 0x2Cu) | (wb == 0x3Au) |
-                                   (wb == 0x5Bu) | (wb == 0x5Du) | (wb == 0x7Bu) | (wb == 0x7Du);
-            const uint64_t WNS = __ballot(nonscalar);
             const uint32_t r = top_run(WB);  // backslashes ending at byte[-1]
             bool resolved = (r != 64u);
             tile_e_in = r & 1u;
+            const bool nonscalar = (b1 == 0x20u) | (b1 == 0x09u) | (b1 == 0x0Au) | (b1 == 0x0Du) |
+                                   (b1 == 0x0Cu) | (b1 == 0x1Au) | (b1 == 0x2Cu) | (b1 == 0x3Au) |
+                                   (b1 == 0x5Bu) | (b1 == 0x5Du) | (b1 == 0x7Bu) | (b1 == 0x7Du);
             if (r >= 1u) {
                 tile_ps_in = 1u;  // byte[-1] is a backslash: a non-quote scalar
-            } else if ((WNS >> 63) & 1u) {
+            } else if (nonscalar) {
                 tile_ps_in = 0u;
-            } else if (!((WQ >> 63) & 1u)) {
+            } else if (b1 != 0x22u) {
                 tile_ps_in = 1u;
             } else {
                 // byte[-1] is '"': a real quote unless escaped by an odd run before it.
@@ -316,9 +327,14 @@ __device__ __forceinline__ Pending compute_tile(const KernelArgs &a, const uint3
     // ---- bit-planes and character classes (lane_math.h)
     uint64_t p[8];
     bitplanes(x, p);
+    Classes cls;
+    if (tile * kTileBytes + kTileBytes <= len) {  // uniform: every byte of the tile is input
+        cls = classify(p, ~0ull);
+    } else {
 #pragma unroll
-    for (int k = 0; k < 8; k++) p[k] &= valid;
-    const Classes cls = classify(p, valid);
+        for (int k = 0; k < 8; k++) p[k] &= valid;
+        cls = classify(p, valid);
+    }
 
     // ---- escape carry, lane level: g = carry-out if carry-in were 0, pr = all 64
     //      bytes are backslashes (carry propagates).  Wave level: carry-lookahead add.
@@ -345,8 +361,7 @@ __device__ __forceinline__ Pending compute_tile(const KernelArgs &a, const uint3
     const uint64_t scalar = ~(cls.op | cls.ws);
     const uint64_t nqs = scalar & ~quote;
     const uint32_t my_ps = (uint32_t)(nqs >> 63);
-    uint32_t prev_ps = __shfl_up(my_ps, 1);
-    if (lane == 0) prev_ps = tile_ps_in;
+    const uint32_t prev_ps = dpp_shift_up1(my_ps, tile_ps_in);
     const uint32_t tile_ps_out = bcast(my_ps, 63);
 
     const uint64_t lane_in = (uint64_t)(-(int64_t)lane_par);  // all-ones: inside a string
@@ -368,8 +383,7 @@ __device__ __forceinline__ Pending compute_tile(const KernelArgs &a, const uint3
     if (!(a.flags & kFlagNoUtf8) && (tile_u8_in != 0u || __ballot(p[7] != 0ull) != 0ull)) {
         const Utf8Planes u8p = utf8_planes(p);
         const uint32_t my_u8c = utf8_carry_out(u8p);
-        uint32_t prev_u8c = __shfl_up(my_u8c, 1);
-        if (lane == 0) prev_u8c = tile_u8_in;
+        const uint32_t prev_u8c = dpp_shift_up1(my_u8c, tile_u8_in);
         u8err = utf8_errors(p, u8p, prev_u8c) != 0;
         tile_pend = (bcast(my_u8c, 63) & 0x3Fu) ? 1u : 0u;
     }
@@ -377,12 +391,7 @@ __device__ __forceinline__ Pending compute_tile(const KernelArgs &a, const uint3
 
     // ---- packed inclusive scan of the per-lane structural counts
     const uint32_t pk = (uint32_t)__popcll(r.T0) | ((uint32_t)__popcll(r.T1) << 16);
-    uint32_t inc = pk;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        const uint32_t t = __shfl_up(inc, d);
-        if (lane >= (uint32_t)d) inc += t;
-    }
+    const uint32_t inc = dpp_add_scan(pk);
     r.excl = inc - pk;
     r.tile_cnt = bcast(inc, 63);
     r.tile = tile;
@@ -714,12 +723,8 @@ struct SubBlock {
 };
 
 __device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v, uint32_t lane) {
-#pragma unroll
-    for (int dd = 1; dd < 64; dd <<= 1) {
-        const uint32_t t = __shfl_up(v, dd);
-        if (lane >= (uint32_t)dd) v += t;
-    }
-    return v;
+    (void)lane;
+    return dpp_add_scan(v);
 }
 
 __device__ void resolver(const KernelArgs &a, Shared &sh) {
