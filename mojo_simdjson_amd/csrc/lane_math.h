@@ -45,6 +45,30 @@ MSJ_HD uint32_t perm(uint32_t s0, uint32_t s1, uint32_t sel) {
 
 MSJ_HD uint64_t u64(uint32_t lo, uint32_t hi) { return ((uint64_t)hi << 32) | lo; }
 
+// Any boolean function of three masks in ONE operation (v_bitop3_b32 on gfx950).  TT is
+// the truth table: bit (4a + 2b + c) of TT is f(a, b, c).  MSJ_TT builds it from an
+// expression in a, b, c at compile time.
+template <uint32_t TT>
+MSJ_HD uint32_t lut3(uint32_t a, uint32_t b, uint32_t c) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_bitop3_b32(a, b, c, TT);
+#else
+    uint32_t r = 0;
+    for (uint32_t i = 0; i < 8; i++)
+        if ((TT >> i) & 1u) r |= ((i & 4u) ? a : ~a) & ((i & 2u) ? b : ~b) & ((i & 1u) ? c : ~c);
+    return r;
+#endif
+}
+template <uint32_t TT>
+MSJ_HD uint64_t lut3(uint64_t a, uint64_t b, uint64_t c) {
+    return u64(lut3<TT>((uint32_t)a, (uint32_t)b, (uint32_t)c),
+               lut3<TT>((uint32_t)(a >> 32), (uint32_t)(b >> 32), (uint32_t)(c >> 32)));
+}
+// Truth tables are written as expressions in TA, TB, TC: evaluating the expression on the
+// three 8-bit constants below yields bit (4a + 2b + c) = f(a, b, c) for all eight inputs.
+constexpr uint32_t TA = 0xF0u, TB = 0xCCu, TC = 0xAAu;
+#define MSJ_TT(expr) ((uint32_t)(expr) & 0xFFu)
+
 // 4x4 byte transpose: o[k] = bytes k of (a,b,c,d), a in the low byte.
 MSJ_HD void byte_transpose4(uint32_t a, uint32_t b, uint32_t c, uint32_t d, uint32_t &o0,
                             uint32_t &o1, uint32_t &o2, uint32_t &o3) {
@@ -125,33 +149,51 @@ struct Classes {
 
 // valid: bit i set iff byte i is inside the input; bytes past the end behave as
 // the 0x20 padding the reference copies into its last block
-// (json_structural_indexer.mojo:103-107).
+// (json_structural_indexer.mojo:103-107).  Pass ~0 for a block that is entirely input.
+//
+// Every class is a product of a pattern of the low three bits (b2 b1 b0), of b3 and of the
+// high nibble; written as ~20 three-input operations per 32 bytes.
 MSJ_HD Classes classify(const uint64_t p[8], uint64_t valid) {
     const uint64_t b0 = p[0], b1 = p[1], b2 = p[2], b3 = p[3];
     const uint64_t b4 = p[4], b5 = p[5], b6 = p[6], b7 = p[7];
-    const uint64_t n7 = ~b7;
-    // low-nibble patterns
-    const uint64_t lo_C = b3 & b2 & ~b1 & ~b0;
-    const uint64_t lo_A = b3 & ~b2 & b1 & ~b0;
-    const uint64_t lo_B = b3 & ~b2 & b1 & b0;
-    const uint64_t lo_D = b3 & b2 & ~b1 & b0;
-    const uint64_t lo_9 = b3 & ~b2 & ~b1 & b0;
-    const uint64_t lo_0 = ~(b3 | b2 | b1 | b0);
-    const uint64_t lo_2 = ~b3 & ~b2 & b1 & ~b0;
-    // high-nibble patterns (all ASCII: b7 = 0)
-    const uint64_t n76 = n7 & ~b6;
-    const uint64_t h0 = n76 & ~b5 & ~b4;
-    const uint64_t h2 = n76 & b5 & ~b4;
-    const uint64_t h0or2 = n76 & ~b4;  // 0x0_, 0x2_
-    const uint64_t h1or3 = n76 & b4;   // 0x1_, 0x3_
-    const uint64_t h5or7 = n7 & b6 & b4;
-    const uint64_t h5 = h5or7 & ~b5;
+    // patterns of (b2 b1 b0)
+    const uint64_t g100 = lut3<MSJ_TT(TA & ~TB & ~TC)>(b2, b1, b0);           // xC
+    const uint64_t g010 = lut3<MSJ_TT(~TA & TB & ~TC)>(b2, b1, b0);           // xA, x2
+    const uint64_t g011_101 = lut3<MSJ_TT((TA ^ TB) & TC)>(b2, b1, b0);       // xB, xD
+    const uint64_t g001_010_101 = lut3<MSJ_TT((~TA & (TB ^ TC)) | (TA & ~TB & TC))>(b2, b1, b0);  // x9 xA xD
+    const uint64_t g000 = lut3<MSJ_TT(~TA & ~TB & ~TC)>(b2, b1, b0);          // x0
     Classes c;
-    c.backslash = h5 & lo_C & valid;
-    c.quote_chr = h2 & lo_2 & valid;
-    c.op = ((lo_C & h0or2) | (lo_A & h1or3) | ((lo_B | lo_D) & h5or7)) & valid;
-    c.ws = ((h0 & (lo_9 | lo_A | lo_D)) | (h2 & lo_0)) | ~valid;
-    c.ctrl = n76 & ~b5 & valid;
+    // operators {0C,2C} {1A,3A} {5B,5D,7B,7D}: b3 = 1, b7 = 0, b5 free
+    {
+        const uint64_t x = lut3<MSJ_TT((TC & TB) | (~TC & TA))>(g010, g011_101, b6);    // (xA & ~b6) | (xB/xD & b6)
+        const uint64_t y = lut3<MSJ_TT(TA & ~TB & ~TC)>(g100, b6, b4);        // xC with hi nibble 0 / 2
+        const uint64_t z = lut3<MSJ_TT((TA & TB) | TC)>(x, b4, y);
+        c.op = lut3<MSJ_TT(TA & TB & ~TC)>(z, b3, b7);
+    }
+    // whitespace 09 0A 0D (hi nibble 0, b3 = 1) and 20 (hi nibble 2, low nibble 0)
+    {
+        const uint64_t w1 = lut3<MSJ_TT(~TA & TB & TC)>(b5, b3, g001_010_101);
+        const uint64_t w2 = lut3<MSJ_TT(TA & ~TB & TC)>(b5, b3, g000);
+        const uint64_t w3 = lut3<MSJ_TT((TA | TB) & ~TC)>(w1, w2, b4);
+        c.ws = lut3<MSJ_TT(TA & ~TB & ~TC)>(w3, b7, b6);
+    }
+    // backslash 5C = 0101 1100, quote 22 = 0010 0010, control 000x xxxx
+    {
+        const uint64_t h5 = lut3<MSJ_TT(~TA & TB & ~TC)>(b7, b6, b5);
+        const uint64_t h5b = lut3<MSJ_TT(TA & TB & TC)>(h5, b4, b3);
+        c.backslash = h5b & g100;
+        const uint64_t h2 = lut3<MSJ_TT(~TA & ~TB & TC)>(b7, b6, b5);
+        const uint64_t h2b = lut3<MSJ_TT(TA & ~TB & ~TC)>(h2, b4, b3);
+        c.quote_chr = h2b & g010;
+        c.ctrl = lut3<MSJ_TT(~TA & ~TB & ~TC)>(b7, b6, b5);
+    }
+    if (valid != ~0ull) {
+        c.backslash &= valid;
+        c.quote_chr &= valid;
+        c.op &= valid;
+        c.ws = (c.ws & valid) | ~valid;
+        c.ctrl &= valid;
+    }
     return c;
 }
 

@@ -357,9 +357,9 @@ __device__ __forceinline__ Pending compute_tile(const KernelArgs &a, const uint3
     const uint32_t lane_par = lanes_below(PM) & 1u;  // parity of the lanes before me in the tile
     const uint32_t tile_par = (uint32_t)__popcll(PM) & 1u;
 
-    // ---- scalars (json_scanner.mojo:64-79)
-    const uint64_t scalar = ~(cls.op | cls.ws);
-    const uint64_t nqs = scalar & ~quote;
+    // ---- scalars (json_scanner.mojo:64-79); three-input mask operations throughout
+    const uint64_t nonscalar = cls.op | cls.ws;
+    const uint64_t nqs = lut3<MSJ_TT(~TA & ~TB)>(nonscalar, quote, quote);  // scalar & ~quote
     const uint32_t my_ps = (uint32_t)(nqs >> 63);
     const uint32_t prev_ps = dpp_shift_up1(my_ps, tile_ps_in);
     const uint32_t tile_ps_out = bcast(my_ps, 63);
@@ -367,12 +367,14 @@ __device__ __forceinline__ Pending compute_tile(const KernelArgs &a, const uint3
     const uint64_t lane_in = (uint64_t)(-(int64_t)lane_par);  // all-ones: inside a string
     // in_string / string_tail assuming the TILE starts outside a string
     const uint64_t in_string0 = S0 ^ lane_in;
-    const uint64_t string_tail0 = in_string0 ^ quote;  // json_string_scanner.mojo:40-44
     const uint64_t follows = (nqs << 1) | prev_ps;     // json_scanner.mojo:76-79
-    const uint64_t potential = cls.op | (scalar & ~follows);
+    // potential_structural_start = op | (scalar & ~follows)   (json_scanner.mojo:40-49)
+    const uint64_t potential = lut3<MSJ_TT(TA | (~TB & ~TC))>(cls.op, nonscalar, follows);
     Pending r;
-    r.T0 = potential & ~string_tail0;  // structural_start if tile s_in = 0
-    r.T1 = potential & string_tail0;   //                  if tile s_in = 1
+    // structural_start = potential & ~string_tail, string_tail = in_string ^ quote
+    // (json_scanner.mojo:24-26, json_string_scanner.mojo:40-44)
+    r.T0 = lut3<MSJ_TT(TA & ~(TB ^ TC))>(potential, in_string0, quote);  // if tile s_in = 0
+    r.T1 = lut3<MSJ_TT(TA & (TB ^ TC))>(potential, in_string0, quote);   // if tile s_in = 1
     const bool err0 = (cls.ctrl & in_string0) != 0;   // json_structural_indexer.mojo:143-145
     const bool err1 = (cls.ctrl & ~in_string0) != 0;
     MSJ_STAMP(tile, 4);
