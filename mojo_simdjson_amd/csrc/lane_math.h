@@ -88,8 +88,20 @@ MSJ_HD void byte_transpose4(uint32_t a, uint32_t b, uint32_t c, uint32_t d, uint
 // position; y symmetrically.  Two shift + two bit-select operations per pair.
 template <uint32_t SH, uint32_t M0>
 MSJ_HD void delta_swap(uint32_t &x, uint32_t &y) {
-    const uint32_t nx = (x & M0) | ((y << SH) & ~M0);
-    const uint32_t ny = ((x >> SH) & M0) | (y & ~M0);
+    // measured on gfx950 (scripts/ubench/valu_ops.hip): v_bitop3 / v_lshrrev / v_add run at
+    // full rate, v_bfi / v_lshlrev at half rate -> selects are written as 3-input LUTs and
+    // the shift by one as an add
+    uint32_t yl;
+#if defined(__HIP_DEVICE_COMPILE__)
+    if (SH == 1)
+        asm("v_add_u32_e32 %0, %1, %1" : "=v"(yl) : "v"(y));  // y << 1 at full rate
+    else
+#endif
+        yl = y << SH;
+    const uint32_t xr = x >> SH;
+    const uint32_t m0 = M0;
+    const uint32_t nx = lut3<MSJ_TT((TA & TB) | (~TA & TC))>(m0, x, yl);
+    const uint32_t ny = lut3<MSJ_TT((TA & TB) | (~TA & TC))>(m0, xr, y);
     x = nx;
     y = ny;
 }

@@ -446,21 +446,26 @@ __device__ __forceinline__ void emit_tile(const KernelArgs &a, uint32_t *stage, 
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        const uint64_t gbase = base - shift;
-        for (uint32_t q = lane; 4u * q < vend; q += 64u) {
-            const uint32_t vq = 4u * q;
-            const uint4 val = *reinterpret_cast<const uint4 *>(&stage[vq]);
-            const uint64_t g = gbase + vq;
-            if (fits && vq >= shift && vq + 4u <= vend) {
-                *reinterpret_cast<uint4 *>(&a.idx[g]) = val;
-            } else {
-                const uint32_t vv[4] = {val.x, val.y, val.z, val.w};
-#pragma unroll
-                for (uint32_t j = 0; j < 4; j++) {
-                    const uint32_t v = vq + j;
-                    if (v >= shift && v < vend && g + j < a.capacity) a.idx[g + j] = vv[j];
-                }
+        // copy-out: uniform 64-bit base + 32-bit lane offsets; full 16-byte quads in the
+        // body, the (at most two) partial quads at the ends element by element
+        uint32_t *out = a.idx + (base - shift);       // out[v] <-> stage[v]; 16-byte aligned
+        const uint32_t q_lo = (shift + 3u) >> 2;      // first quad with all four elements valid
+        const uint32_t q_hi = vend >> 2;              // one past the last full quad
+        if (fits) {
+            for (uint32_t q = q_lo + lane; q < q_hi; q += 64u)
+                *reinterpret_cast<uint4 *>(out + 4u * q) = *reinterpret_cast<const uint4 *>(stage + 4u * q);
+            // head (elements shift .. 4*q_lo) and tail (4*q_hi .. vend): < 8 elements in total
+            if (lane < 4u) {
+                const uint32_t vh = lane;  // head quad is quad 0
+                if (vh >= shift && vh < 4u * q_lo && vh < vend) out[vh] = stage[vh];
+            } else if (lane < 8u) {
+                const uint32_t vt = 4u * q_hi + (lane - 4u);
+                if (vt < vend && vt >= 4u * q_lo) out[vt] = stage[vt];
             }
+        } else {
+            // index buffer too small: clip (the launch reports CAPACITY)
+            for (uint32_t v = shift + lane; v < vend; v += 64u)
+                if (base - shift + v < a.capacity) out[v] = stage[v];
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();  // stage is reused by the next tile
