@@ -67,6 +67,16 @@ def main():
     print(f"slack prefix->needed            : median {np.median(slack):.2f} us  p10 {np.percentile(slack, 10):.2f}  frac<0 {np.mean(slack < 0):.3f}")
     span_rt = (rt[:, 2][okr].max() - rt[:, 0][okr].min()) * 10e-3
     print(f"real-time span {span_rt:.1f} us")
+    # iteration accounting for the first tile of each range-wave pair (t and t+4 belong to the same wave)
+    t0 = raw[:, 0]
+    per = t0[4:] - t0[:-4]
+    okk = (t0[4:] > 0) & (t0[:-4] > 0) & (per > 0) & (per < 10**7) & ((np.arange(len(per)) % 8) < 4)
+    print(f"iteration period (cycles): median {np.median(per[okk]):.0f}")
+    def seg(a, b, src=raw):
+        d = src[:, b] - src[:, a]
+        m = (src[:, a] > 0) & (src[:, b] > 0) & (d >= 0) & (d < 10**7)
+        return np.median(d[m]) if m.any() else float('nan')
+    print(f"  issue loads 0->11 {seg(0,11):.0f} | compute 1->6 {seg(1,6):.0f} | wait+publish 6->7 {seg(6,7):.0f}")
     s = raw[:, 1:11]
     d = np.diff(s, axis=1)
     life = s[:, 9] - s[:, 0]

@@ -296,9 +296,9 @@ def test_summary_pass_parity(torch_mod, dev, oracle):
     assert res.count == want[1]
 
 
-@pytest.mark.parametrize("name", ["minified", "pretty4"])
+@pytest.mark.parametrize("name", ["minified", "utf8", "pretty4"])
 def test_full_size_1gib_replication_property(torch_mod, dev, oracle, name):
-    """BASELINE.json configs 2/4 at full size.  The oracle indexes one ~64 MiB
+    """BASELINE.json configs 2/3/4 at full size.  The oracle indexes one ~64 MiB
     unit; the 1 GiB buffer is that unit repeated, and because every unit ends
     with all carries at zero the expected index array is unit_idx + k*unit_len
     (checked on the device, not by shipping 4 GB to the host)."""
@@ -326,6 +326,25 @@ def test_full_size_1gib_replication_property(torch_mod, dev, oracle, name):
     # size-independent properties: strictly increasing, every index on a plausible byte
     v = d_idx[: n * reps].to(torch.int64) & 0xFFFFFFFF
     assert bool((v[1:] > v[:-1]).all())
+    assert res.utf8_error == 0
+    if name == "utf8":
+        # negative variants at full size: one corrupted byte inside a string body (first
+        # tile, around a tile boundary deep in the buffer, last bytes).  The index array
+        # must not change; the strict verdict must flip.
+        first_hi = next(i for i, c in enumerate(b[:4096]) if c >= 0xE0)
+        unit_hi = np.flatnonzero(u >= 0xE0)
+        deep = (reps // 2) * len(b)
+        near_tile = int(unit_hi[np.searchsorted(unit_hi, (4096 * 1000) - 1)])
+        last_hi = int(unit_hi[-1]) + (reps - 1) * len(b)
+        for off in (first_hi, deep + near_tile, last_hi):
+            saved = int(d_buf[off].item())
+            d_buf[off] = 0xFF
+            d_idx2, res2 = device_indices(torch, dev, d_buf, total, cap)
+            assert res2.code == 0 and res2.utf8_error == 1 and res2.count == res.count
+            assert torch.equal(d_idx2[: n * reps + 3], d_idx[: n * reps + 3])
+            _, res3 = device_indices(torch, dev, d_buf, total, cap, flags=1)
+            assert res3.code == 11
+            d_buf[off] = saved
 
 
 def _sharded_dataset(name):
