@@ -165,9 +165,14 @@ def main():
         from mojo_simdjson_amd.sharded import ShardedStage1
 
         sh = ShardedStage1(dev, rank, world)
+        # the host that placed the shard had these bytes in host memory (they are part of
+        # what it copied to the GPU): the 64-byte halo and the shard's first 4 KiB
+        host_halo = d_alloc[:halo].cpu().numpy().tobytes() if halo else None
+        host_head = d_shard[:4096].cpu().numpy().tobytes() if halo else None
 
         def step():
-            return sh.run(d_shard, shard_len, d_idx, total_len, has_prefix=(rank > 0), flags=flags)
+            return sh.run(d_shard, shard_len, d_idx, total_len, has_prefix=(rank > 0), flags=flags,
+                          host_halo=host_halo, host_head=host_head)
 
     def barrier():
         if dist is not None:

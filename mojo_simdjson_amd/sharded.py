@@ -26,6 +26,7 @@ import torch
 import torch.distributed as dist
 
 from . import errors
+from ._lib import MsjCarry
 
 TAIL_BYTES = 4096
 _NONSCALAR = frozenset([0x20, 0x09, 0x0A, 0x0D, 0x0C, 0x1A, 0x2C, 0x3A, 0x5B, 0x5D, 0x7B, 0x7D])
@@ -238,10 +239,17 @@ class ShardedStage1:
         self.reruns = 0
 
     def run(self, d_shard, shard_len, d_idx, total_len, has_prefix, flags=0, segments=None,
-            d_halo=None):
-        """Index this rank's shard.  d_halo: the 64 stream bytes before the shard (device
-        tensor; by default the 64 bytes in front of d_shard's storage when has_prefix).
+            d_halo=None, host_halo=None, host_head=None):
+        """Index this rank's shard.
+
+        d_halo: the 64 stream bytes before the shard (device tensor; by default the 64
+        bytes in front of d_shard's storage when has_prefix).  host_halo / host_head:
+        host copies of those 64 bytes and of the shard's first <= 4096 bytes -- whoever
+        placed the shard on the GPU had them in host memory, and passing them saves two
+        small device-to-host copies per call.
         Returns (code, total_count, local msj_carry)."""
+        import torch
+
         dev = self.dev
         last = self.rank == self.world - 1
         if self.world == 1:
@@ -253,28 +261,39 @@ class ShardedStage1:
             return int(c.code), int(c.count), c
         # ---- speculative carries from local bytes only
         if has_prefix:
-            if d_halo is None:
-                import torch
-
-                d_halo = torch.as_strided(d_shard, (64,), (1,), d_shard.storage_offset() - 64)
-            halo = d_halo.cpu().numpy().tobytes()
-            head = d_shard[: min(4096, shard_len)].cpu().numpy().tobytes()
-            hc = halo_carry(halo)
+            if host_halo is None:
+                if d_halo is None:
+                    d_halo = torch.as_strided(d_shard, (64,), (1,), d_shard.storage_offset() - 64)
+                host_halo = d_halo.cpu().numpy().tobytes()
+            if host_head is None:
+                host_head = d_shard[: min(4096, shard_len)].cpu().numpy().tobytes()
+            hc = halo_carry(bytes(host_halo))
             e_used, ps_used = hc if hc is not None else (0, 1)
-            s_used = guess_in_string(halo, head, e_used)
+            s_used = guess_in_string(bytes(host_halo), bytes(host_head), e_used)
         else:
             s_used = e_used = ps_used = 0
+        nccl = dist.get_backend(self.group) == "nccl"
         while True:
             cin = dev.make_carry(s_used, e_used, ps_used)
             cout = dev.new_carry()
             dev.shard(d_shard, shard_len, d_idx, cin, cout, segments=segments, has_prefix=has_prefix,
                       is_final=last, trailer_len=total_len, flags=flags)
-            c = dev.fetch(cout)
-            got = exchange_words([s_used, e_used, ps_used, c.in_string, c.next_is_escaped,
-                                  c.prev_scalar, c.count, c.unescaped_error, c.utf8_error,
-                                  c.internal_error], dev.device, self.group)
-            reports = [dict(s_used=w[0], e_used=w[1], ps_used=w[2], s_out=w[3], e_out=w[4], ps_out=w[5])
-                       for w in got]
+            # ONE collective: every rank's (carry used | carry out), 128 bytes, gathered on the
+            # device (stream-ordered behind the kernel), then a single device-to-host copy
+            mine = torch.cat([cin, cout])
+            if not nccl:
+                mine = mine.cpu()
+            gathered = torch.empty(self.world * mine.numel(), dtype=torch.uint8, device=mine.device)
+            dist.all_gather_into_tensor(gathered, mine, group=self.group)
+            blob = gathered.cpu().numpy().tobytes()
+            reports, carries = [], []
+            for g in range(self.world):
+                used = MsjCarry.from_buffer_copy(blob[128 * g:128 * g + 64])
+                out = MsjCarry.from_buffer_copy(blob[128 * g + 64:128 * g + 128])
+                carries.append(out)
+                reports.append(dict(s_used=used.in_string, e_used=used.next_is_escaped,
+                                    ps_used=used.prev_scalar, s_out=out.in_string,
+                                    e_out=out.next_is_escaped, ps_out=out.prev_scalar))
             first_wrong, true_in = verify_chain(reports)
             if first_wrong == self.world:
                 break
@@ -283,8 +302,9 @@ class ShardedStage1:
                 s_used, e_used, ps_used = true_in[first_wrong]
                 self.reruns += 1
             # (ranks after first_wrong keep their speculation; they are re-verified next round)
-        total = sum(int(w[6]) for w in got)
-        code = global_code(int(got[-1][3]), any(int(w[7]) for w in got), total,
-                           any(int(w[8]) for w in got), any(int(w[9]) for w in got),
+        c = carries[self.rank]
+        total = sum(int(x.count) for x in carries)
+        code = global_code(int(carries[-1].in_string), any(int(x.unescaped_error) for x in carries), total,
+                           any(int(x.utf8_error) for x in carries), any(int(x.internal_error) for x in carries),
                            bool(flags & 1))
         return code, total, c
