@@ -435,3 +435,44 @@ def test_sharded_two_ranks_one_gpu(oracle):
             merged.append(vals + start)  # shard-relative offsets -> stream offsets
         merged = np.concatenate(merged)
         assert np.array_equal(merged, idx[:n].astype(np.int64)), name
+
+
+def test_multi_segment_over_4gib(torch_mod, dev, oracle):
+    """> 4 GiB in one shard call: chained segments with device-resident carries, offsets
+    relative to each segment's byte base (the reference's UInt32
+    offsets would silently wrap here, json_structural_indexer.mojo:138).  Checked with the
+    replication property on the device."""
+    torch = torch_mod
+    from mojo_simdjson_amd import _lib, synth
+
+    SEG = 0xFFFF0000
+    u = synth.workload("minified", 64 << 20)
+    b = u.tobytes()
+    code, n, idx = helpers.run_oracle(oracle.msj_oracle_stage1, b)
+    assert code == 0
+    reps = SEG // len(b) + 4
+    d_unit = torch.from_numpy(u).to(dev.device)
+    d_buf = d_unit.repeat(reps)
+    total = d_buf.numel()
+    assert total > SEG
+    cap = n * reps + 3
+    d_idx = torch.empty(cap, dtype=torch.int32, device=dev.device)
+    segs = torch.zeros(4 * 32, dtype=torch.uint8, device=dev.device)
+    cin, cout = dev.new_carry(), dev.new_carry()
+    rc, nseg = dev.shard(d_buf, total, d_idx, cin, cout, segments=segs, is_final=True, trailer_len=total)
+    assert rc == 0 and nseg == 2
+    res = dev.fetch(cout)
+    assert res.code == 0 and res.count == n * reps and res.bytes == total and res.internal_error == 0
+    table = np.frombuffer(segs.cpu().numpy().tobytes(), dtype=np.uint64).reshape(4, 4)
+    assert list(table[0][:2]) == [0, SEG] and list(table[1][:2]) == [SEG, total - SEG]
+    c0, c1 = int(table[0][3]), int(table[1][3])
+    assert int(table[0][2]) == 0 and int(table[1][2]) == c0 and c0 + c1 == n * reps
+    unit_idx = torch.from_numpy(idx[:n].astype(np.int64)).to(dev.device)
+    for k in range(reps):
+        want = unit_idx + k * len(b)
+        want = torch.where(want >= SEG, want - SEG, want)  # segment-relative
+        got = d_idx[k * n:(k + 1) * n].to(torch.int64) & 0xFFFFFFFF
+        assert torch.equal(got, want), f"repetition {k}"
+    assert c0 == int((unit_idx[None, :] + (torch.arange(reps, device=dev.device) * len(b))[:, None] < SEG).sum())
+    tail = (d_idx[n * reps:n * reps + 3].to(torch.int64) & 0xFFFFFFFF).tolist()
+    assert tail == [total & 0xFFFFFFFF, total & 0xFFFFFFFF, 0]
