@@ -10,11 +10,17 @@ namespace msj {
 constexpr int kWaves = 4;                          // wave64 per workgroup (each an independent worker)
 constexpr int kThreads = kWaves * 64;
 constexpr uint32_t kTileBytes = 64u * 64u;         // 4 KiB of input per wave: 64 lanes x one 64-byte block
-constexpr uint32_t kDescOffset = 8;                // ws[0] = tile ticket, ws[1] = role ticket, ws[8..] = agg[], pre[]
+// Workspace header: kTicketShards range-ticket counters, one per 4 KiB (a single word sustains
+// only ~80 returning atomics per microsecond chip-wide; shard c hands out ranges c, c + S, ...),
+// the role ticket in the second word; the descriptor arrays follow.
+constexpr uint32_t kTicketShards = 8;
+constexpr uint32_t kTicketStrideWords = 512;       // in 8-byte words
+constexpr uint32_t kDescOffset = kTicketShards * kTicketStrideWords;  // ws[kDescOffset..] = agg[], ragg[], rpre[]
 constexpr uint32_t kStageWords = 1024;             // per-wave LDS staging of indices (4 KiB) per round
-constexpr uint32_t kBatch = 2;                     // tiles per wave per ticket range = emission deferral depth
+constexpr uint32_t kBatch = 2;                     // tiles per wave per ticket range
+constexpr uint32_t kDefer = 2;                     // a tile is emitted kDefer ranges after it was computed
 constexpr uint32_t kRange = kWaves * kBatch;       // tiles per ticket range = per range aggregate
-constexpr uint32_t kPendSlots = 2 * kBatch;        // emission is deferred by two ranges
+constexpr uint32_t kPendSlots = kDefer * kBatch;   // parked tiles per wave
 constexpr int kResolveE = 4;                       // tiles folded per resolver lane
 constexpr uint32_t kResolveChunk = 64u * kResolveE; // tiles per resolver chunk (one wave, one round)
 constexpr uint32_t kSpinLimit = 1u << 18;          // bounded polling (internal_error on expiry, ~0.3 s)

@@ -119,6 +119,7 @@ __device__ __forceinline__ uint64_t uniform64(uint64_t v) {
 struct Shared {
     uint32_t role;
     uint32_t range_lo[2];    // worker workgroups: base tile of the next range (double buffered)
+    uint32_t range_seq;      // ... and the iteration it was handed over in (wave 0 -> the others)
     uint64_t tagg[2][kRange]; // worker workgroups: the range's tile aggregates, in tile order
     // resolver hand-off between its waves
     uint32_t rs_seq, rs_s, rs_cnt, rs_err, rs_u8, rs_poison;
@@ -134,11 +135,12 @@ struct Shared {
 
 // Bounded poll of one descriptor until its status is non-zero.
 __device__ __forceinline__ uint64_t wait_desc(const uint64_t *p, uint32_t *timeout) {
-    uint64_t d = ld_desc(p);
+    // one address for the whole wave: the value is uniform (scalar loop control)
+    uint64_t d = uniform64(ld_desc(p));
     uint32_t spins = 0;
     while ((d >> 62) == 0) {
         __builtin_amdgcn_s_sleep(2);
-        d = ld_desc(p);
+        d = uniform64(ld_desc(p));
         if (++spins > kSpinLimit) {
             *timeout = 1;
             break;
@@ -207,10 +209,10 @@ __device__ __forceinline__ uint32_t ticket_value(uint32_t reg) {
 
 // BitIndexer.write_index (json_structural_indexer.mojo:39-44) for one 32-bit half mask:
 // writes (value_base | bit position) of every set bit, ascending, to consecutive LDS words.
-// Straight-line: 32 steps, lanes drop out through EXEC as their mask runs empty (v_cmpx),
-// the wave leaves as soon as no lane is left; the LDS offsets are immediates.  (The
-// compiler's version of this loop spends ~8 scalar instructions per step on exec-mask
-// bookkeeping.)
+// Straight-line: 32 steps, lanes drop out through
+// EXEC as their mask runs empty (v_cmpx), the wave leaves as soon as no lane is left; the LDS
+// offsets are immediates.  (The compiler's version of this loop spends ~8 scalar
+// instructions per step on exec-mask bookkeeping.)
 __device__ __forceinline__ void scatter_bits32(uint32_t t, uint32_t lds_byte_addr, uint32_t value_base) {
     uint32_t tmp1, tmp2;
     uint64_t save;
@@ -292,25 +294,23 @@ __device__ __forceinline__ Pending compute_tile(const KernelArgs &a, const uint3
             tile_ps_in = a.carry_in->prev_scalar & 1u;
         } else {
             const uint64_t WB = __ballot(wb == 0x5Cu);
-            const uint32_t r = top_run(WB);  // backslashes ending at byte[-1]
-            bool resolved = (r != 64u);
+            const uint32_t r = top_run(WB);                         // backslashes ending at byte[-1]
+            // (WB<<1)|1 has bit 0 forced: a result of 64 means bits 1..63 are all set
+            const uint32_t r2 = top_run((WB << 1) | 1ull);          // run ending at byte[-2]
+            // branch-free scalar code.  op | ws as a 128-entry bit table (haswell.mojo:22-74):
+            // {09,0A,0C,0D,1A,20,2C,3A} in the low word, {5B,5D,7B,7D} in the high word
+            constexpr uint64_t kNsLo = (1ull << 0x09) | (1ull << 0x0A) | (1ull << 0x0C) | (1ull << 0x0D) |
+                                       (1ull << 0x1A) | (1ull << 0x20) | (1ull << 0x2C) | (1ull << 0x3A);
+            constexpr uint64_t kNsHi = (1ull << (0x5B - 64)) | (1ull << (0x5D - 64)) |
+                                       (1ull << (0x7B - 64)) | (1ull << (0x7D - 64));
+            const uint64_t tab = (b1 & 0x40u) ? kNsHi : kNsLo;
+            const uint32_t nonscalar = (uint32_t)(tab >> (b1 & 63u)) & (uint32_t)(b1 < 0x80u);
+            const uint32_t is_quote = (uint32_t)(b1 == 0x22u);
             tile_e_in = r & 1u;
-            const bool nonscalar = (b1 == 0x20u) | (b1 == 0x09u) | (b1 == 0x0Au) | (b1 == 0x0Du) |
-                                   (b1 == 0x0Cu) | (b1 == 0x1Au) | (b1 == 0x2Cu) | (b1 == 0x3Au) |
-                                   (b1 == 0x5Bu) | (b1 == 0x5Du) | (b1 == 0x7Bu) | (b1 == 0x7Du);
-            if (r >= 1u) {
-                tile_ps_in = 1u;  // byte[-1] is a backslash: a non-quote scalar
-            } else if (nonscalar) {
-                tile_ps_in = 0u;
-            } else if (b1 != 0x22u) {
-                tile_ps_in = 1u;
-            } else {
-                // byte[-1] is '"': a real quote unless escaped by an odd run before it.
-                // (WB<<1)|1 has bit 0 forced: a result of 64 means bits 1..63 are all set.
-                const uint32_t r2 = top_run((WB << 1) | 1ull);  // run ending at byte[-2]
-                if (r2 == 64u) resolved = false;
-                tile_ps_in = r2 & 1u;
-            }
+            // byte[-1] a backslash: non-quote scalar.  op/ws: not a scalar.  '"': a real quote
+            // unless escaped by an odd run before it.  Anything else: scalar.
+            tile_ps_in = (uint32_t)(r >= 1u) | (~nonscalar & 1u & (is_quote ? (r2 & 1u) : 1u));
+            const bool resolved = (r != 64u) & !((r == 0u) & (is_quote != 0u) & (r2 == 64u));
             if (!resolved) {
                 // >= 62 consecutive backslashes in front of the tile: take the exact
                 // carries the predecessor publishes with its aggregate.
@@ -407,74 +407,93 @@ __device__ __forceinline__ Pending compute_tile(const KernelArgs &a, const uint3
     return r;
 }
 
-// ---- BitIndexer.write (json_structural_indexer.mojo:46-58) for one computed tile:
-//      the ascending offsets are staged in this wave's LDS slice at their
-//      tile-relative position and written out as aligned 16-byte stores (one L2
-//      request per 64 B instead of one per index).  Wave-local: no barrier.
-__device__ __forceinline__ void emit_tile(const KernelArgs &a, uint32_t *stage, const uint32_t lane,
-                                          const Pending &r, const uint64_t rpre_word,
-                                          const uint64_t count0, uint32_t &timeout) {
-    MSJ_STAMP(r.tile, 8);
-    MSJ_RSTAMP(r.tile, 14, lane == 0);
-    // the range's prefix (resolver) + the tile's position inside the range (local fold);
-    // all of it is wave-uniform: tell the compiler (readfirstlane) so it stays scalar
+// ---- BitIndexer.write (json_structural_indexer.mojo:46-58) for one computed tile, in two
+//      steps so that the global stores of one range never sit between a load and its use:
+//      stage_indices() writes the offsets into the wave's LDS slice at their position in the
+//      output (LDS only), copy_out() turns them into aligned 16-byte
+//      stores (one L2 request per 64 B instead of one per index).  Wave-local: no barrier.
+struct Emit {
+    uint32_t tlo, thi;     // the tile's structural_start mask of this lane (state resolved)
+    uint32_t vpos;         // stage slot of the lane's first index
+    uint32_t shift, vend;  // stage[j] <-> idx[base - shift + j] for j in [shift, vend)
+    uint32_t cnt;          // structurals in the tile
+    uint32_t tile;
+    uint64_t base;         // index of the tile's first structural in the output
+    bool live;             // something to emit
+    bool staged;           // fits one staging round (the common case)
+};
+
+// Picks the masks / counts for the tile's actual incoming state from its pending slot.
+__device__ __forceinline__ Emit prepare_emit(const KernelArgs &a, Shared &sh, const uint32_t wave,
+                                             const uint32_t slot, const uint32_t lane,
+                                             const uint64_t rpre_word, const uint64_t count0,
+                                             uint32_t &timeout) {
+    Emit e;
+    e.tile = uniform32(sh.pend_meta[wave][slot][0]);
+    e.live = e.tile != 0xFFFFFFFFu;
+    e.staged = false;
+    e.tlo = e.thi = e.vpos = e.shift = e.vend = e.cnt = 0;
+    e.base = 0;
+    if (!e.live) return e;
+    const uint4 m = sh.pend_masks[wave][slot][lane];
+    const uint32_t excl = sh.pend_excl[wave][slot][lane];
+    const uint32_t tile_cnt = uniform32(sh.pend_meta[wave][slot][1]);
+    const uint32_t in_cnt = uniform32(sh.pend_meta[wave][slot][2]);
+    const uint32_t in_s = uniform32(sh.pend_meta[wave][slot][3]);
+    // the range's prefix (resolver) + the tile's position inside the range (local fold)
     const uint32_t q = (uint32_t)(rpre_word >> 61) & 1u;
-    const uint32_t s_in = (r.in_s >> q) & 1u;
-    const uint64_t base = count0 + (uint64_t)(uint32_t)rpre_word + (q ? (r.in_cnt >> 16) : (r.in_cnt & 0xFFFFu));
+    const uint32_t s_in = (in_s >> q) & 1u;
+    e.base = count0 + (uint64_t)(uint32_t)rpre_word + (q ? (in_cnt >> 16) : (in_cnt & 0xFFFFu));
     if ((rpre_word >> 54) & 1u) timeout = 1;
-    MSJ_STAMP(r.tile, 9);
-    if ((a.flags & kFlagNoEmit) || timeout) return;
-    const uint64_t T = s_in ? r.T1 : r.T0;
-    const uint32_t lane_off = s_in ? (r.excl >> 16) : (r.excl & 0xFFFFu);
-    const uint32_t my_cnt = s_in ? (r.tile_cnt >> 16) : (r.tile_cnt & 0xFFFFu);
-    const bool fits = base + my_cnt <= a.capacity;
-    const uint32_t shift = (uint32_t)(base & 3u);  // stage[j] <-> idx[base - shift + j]
-    const uint32_t vend = shift + my_cnt;
-    const uint32_t v0 = (uint32_t)((uint64_t)r.tile * kTileBytes) + lane * 64u;
-    uint32_t vpos = shift + lane_off;
-    uint32_t tlo = (uint32_t)T, thi = (uint32_t)(T >> 32);
-    if (vend <= kStageWords) {
-        // ---- common case: the whole tile fits one staging round.  Straight-line bit
-        //      extraction (fully unrolled, LDS offsets are immediates, lanes drop out as
-        //      their mask runs empty) instead of a data-dependent loop.
-        // v0 is a multiple of 64, so value_base | bit == value_base + bit
-        const uint32_t lds0 = (uint32_t)(uintptr_t)(stage + vpos);  // LDS byte address
-        const uint32_t nlo = (uint32_t)__builtin_popcount(tlo);
-        scatter_bits32(tlo, lds0, v0);
-        scatter_bits32(thi, lds0 + 4u * nlo, v0 | 32u);
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        // copy-out: uniform 64-bit base + 32-bit lane offsets; full 16-byte quads in the
-        // body, the (at most two) partial quads at the ends element by element
-        uint32_t *out = a.idx + (base - shift);       // out[v] <-> stage[v]; 16-byte aligned
-        const uint32_t q_lo = (shift + 3u) >> 2;      // first quad with all four elements valid
-        const uint32_t q_hi = vend >> 2;              // one past the last full quad
-        if (fits) {
-            for (uint32_t q = q_lo + lane; q < q_hi; q += 64u)
-                *reinterpret_cast<uint4 *>(out + 4u * q) = *reinterpret_cast<const uint4 *>(stage + 4u * q);
-            // head (elements shift .. 4*q_lo) and tail (4*q_hi .. vend): < 8 elements in total
-            if (lane < 4u) {
-                const uint32_t vh = lane;  // head quad is quad 0
-                if (vh >= shift && vh < 4u * q_lo && vh < vend) out[vh] = stage[vh];
-            } else if (lane < 8u) {
-                const uint32_t vt = 4u * q_hi + (lane - 4u);
-                if (vt < vend && vt >= 4u * q_lo) out[vt] = stage[vt];
-            }
-        } else {
-            // index buffer too small: clip (the launch reports CAPACITY)
-            for (uint32_t v = shift + lane; v < vend; v += 64u)
-                if (base - shift + v < a.capacity) out[v] = stage[v];
-        }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();  // stage is reused by the next tile
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        MSJ_STAMP(r.tile, 10);
-        return;
+    if ((a.flags & kFlagNoEmit) || timeout) {
+        e.live = false;
+        return e;
     }
-    // ---- dense tile (more than kStageWords indices): general multi-round path
-    for (uint32_t r0 = 0; r0 < vend; r0 += kStageWords) {
+    e.tlo = s_in ? m.z : m.x;
+    e.thi = s_in ? m.w : m.y;
+    e.cnt = s_in ? (tile_cnt >> 16) : (tile_cnt & 0xFFFFu);
+    e.shift = (uint32_t)(e.base & 3u);
+    e.vend = e.shift + e.cnt;
+    e.vpos = e.shift + (s_in ? (excl >> 16) : (excl & 0xFFFFu));
+    e.staged = e.vend <= kStageWords && e.base + e.cnt <= a.capacity;
+    return e;
+}
+
+__device__ __forceinline__ void stage_indices(const Emit &e, uint32_t *stage, const uint32_t lane) {
+    // the block offset is a multiple of 64, so value_base | bit == value_base + bit
+    const uint32_t v0 = e.tile * kTileBytes + lane * 64u;  // < 2^32 per launch
+    const uint32_t lds0 = (uint32_t)(uintptr_t)(stage + e.vpos);  // LDS byte address
+    const uint32_t nlo = (uint32_t)__builtin_popcount(e.tlo);
+    scatter_bits32(e.tlo, lds0, v0);
+    scatter_bits32(e.thi, lds0 + 4u * nlo, v0 | 32u);
+}
+
+__device__ __forceinline__ void copy_out(const KernelArgs &a, const Emit &e, const uint32_t *stage,
+                                         const uint32_t lane) {
+    // uniform 64-bit base + 32-bit lane offsets; full 16-byte quads in the body, the (at
+    // most two) partial quads at the ends element by element
+    uint32_t *out = a.idx + (e.base - e.shift);     // out[v] <-> stage[v]; 16-byte aligned
+    const uint32_t q_lo = (e.shift + 3u) >> 2;        // first quad with all four elements valid
+    const uint32_t q_hi = e.vend >> 2;                // one past the last full quad
+    for (uint32_t q = q_lo + lane; q < q_hi; q += 64u)
+        *reinterpret_cast<uint4 *>(out + 4u * q) = *reinterpret_cast<const uint4 *>(stage + 4u * q);
+    // head (elements shift .. 4*q_lo) and tail (4*q_hi .. vend): < 8 elements in total
+    if (lane < 4u) {
+        const uint32_t vh = lane;  // head quad is quad 0
+        if (vh >= e.shift && vh < 4u * q_lo && vh < e.vend) out[vh] = stage[vh];
+    } else if (lane < 8u) {
+        const uint32_t vt = 4u * q_hi + (lane - 4u);
+        if (vt < e.vend && vt >= 4u * q_lo) out[vt] = stage[vt];
+    }
+}
+
+// Dense tile (more than kStageWords indices) or an index buffer that is too small (the
+// launch reports CAPACITY): general multi-round path through the whole staging slice.
+__device__ __forceinline__ void emit_general(const KernelArgs &a, const Emit &e, uint32_t *stage,
+                                             const uint32_t lane) {
+    const uint32_t v0 = e.tile * kTileBytes + lane * 64u;
+    uint32_t tlo = e.tlo, thi = e.thi, vpos = e.vpos;
+    for (uint32_t r0 = 0; r0 < e.vend; r0 += kStageWords) {
         const uint32_t r1 = r0 + kStageWords;
         while (tlo && vpos < r1) {
             stage[vpos - r0] = v0 + (uint32_t)__builtin_ctz(tlo);
@@ -491,20 +510,20 @@ __device__ __forceinline__ void emit_tile(const KernelArgs &a, uint32_t *stage, 
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        const uint32_t lim = vend < r1 ? vend : r1;
-        const uint64_t gbase = base - shift + r0;
+        const uint32_t lim = e.vend < r1 ? e.vend : r1;
+        const uint64_t gbase = e.base - e.shift + r0;
         for (uint32_t q = lane; 4u * q < lim - r0; q += 64u) {
             const uint32_t vq = r0 + 4u * q;
             const uint4 val = *reinterpret_cast<const uint4 *>(&stage[4u * q]);
             const uint64_t g = gbase + 4u * q;
-            if (fits && vq >= shift && vq + 4u <= lim) {
+            if (vq >= e.shift && vq + 4u <= lim && g + 4u <= a.capacity) {
                 *reinterpret_cast<uint4 *>(&a.idx[g]) = val;
             } else {
                 const uint32_t vv[4] = {val.x, val.y, val.z, val.w};
 #pragma unroll
                 for (uint32_t j = 0; j < 4; j++) {
                     const uint32_t v = vq + j;
-                    if (v >= shift && v < lim && g + j < a.capacity) a.idx[g + j] = vv[j];
+                    if (v >= e.shift && v < lim && g + j < a.capacity) a.idx[g + j] = vv[j];
                 }
             }
         }
@@ -512,26 +531,15 @@ __device__ __forceinline__ void emit_tile(const KernelArgs &a, uint32_t *stage, 
         __builtin_amdgcn_wave_barrier();  // stage is reused by the next round / next tile
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     }
-    MSJ_STAMP(r.tile, 10);
 }
 
-// ---- worker: one wave, persistent ---------------------------------------------------
-// Work distribution.  One atomic counter hands out tiles in ascending order, but a
-// single word sustains only ~80-90 returning atomics per microsecond chip-wide, so one
-// atomic must pay for many tiles: thread 0 of a workgroup draws a RANGE of
-// kWaves * kBatch tiles, and wave w takes tiles lo + kWaves*j + w (j = 0..kBatch-1).
-// The emission of a tile is deferred by exactly kBatch tiles of the same wave, i.e.
-// to the same slot of the next range.  (kBatch <= deferral depth matters: a wave
-// that had to emit inside its own range would need that range's first prefix, hence
-// every lower range complete, and ranges would serialise.)  The four waves of a
-// workgroup meet at one barrier per range to pick up the next range's base from LDS;
-// everything else in the worker path is wave-local.
-//
-// Deadlock freedom: a wave only holds tiles once it is running, handles them in
-// increasing order, never blocks while computing, and the resolver publishes a
-// tile's prefix as soon as every earlier tile is in (partial progress).  The wave
-// holding the smallest not-yet-computed tile is therefore never waiting on anything
-// that needs a later tile, whatever the dispatch order or residency.
+__device__ __forceinline__ void lds_wave_sync() {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
 // Range prefix for this wave: requested once per range, polled only if the resolver
 // had not published it yet.
 __device__ __forceinline__ uint64_t range_prefix(const uint64_t *rpre, uint32_t range_id, uint64_t word,
@@ -547,9 +555,56 @@ __device__ __forceinline__ uint64_t range_prefix(const uint64_t *rpre, uint32_t 
     return word;
 }
 
+// One parked tile, start to end (the drain; the steady-state loop interleaves the same steps
+// with the hand-over of the next range).
+__device__ __forceinline__ void emit_one(const KernelArgs &a, uint32_t *stage, const Emit &e, const uint32_t lane) {
+    if (!e.live) return;  // uniform
+    if (e.staged) {
+        stage_indices(e, stage, lane);
+        lds_wave_sync();
+        copy_out(a, e, stage, lane);
+    } else {
+        emit_general(a, e, stage, lane);
+    }
+    lds_wave_sync();  // the staging slice is reused by the next tile
+}
+
+// ---- worker: one wave, persistent ---------------------------------------------------
+// Work distribution.  One atomic counter hands out tiles in ascending order, but a
+// single word sustains only ~80-90 returning atomics per microsecond chip-wide, so one
+// atomic must pay for many tiles: thread 0 of a workgroup draws a RANGE of
+// kWaves * kBatch tiles, and wave w takes tiles lo + kWaves*j + w (j = 0..kBatch-1).
+//
+// One range per loop iteration, in this order:
+//   1. compute the wave's kBatch tiles (their bytes are in registers), publish each tile
+//      aggregate; thread 0 draws the ticket of the NEXT range after the first tile;
+//   2. workgroup barrier (the only one); fold the range's tile aggregates and publish the
+//      range aggregate for the resolver -- before anything in this iteration can block;
+//   3. emit the tiles of the range computed kDefer iterations ago (parked in LDS): their
+//      range prefix has had kDefer iterations to arrive.  In between, as soon as the ticket
+//      is back (wave 0 hands it to the other waves through LDS, no barrier), the next
+//      range's bytes are requested; they are waited for before the LAST tile's stores, so
+//      no store sits between a load and its use, and those last stores drain during step 1;
+//   4. park this iteration's tiles in the freed slots.
+//
+// The resolver retires ranges in order, so what matters is how far the publish times of
+// neighbouring ranges spread: a ticket is drawn as late as the latencies (atomic, HBM)
+// allow, one emission phase before the range is computed, and nothing that can block sits
+// between the draw and the publish except that one emission.
+//
+// Deadlock freedom: a wave blocks only in step 3, after its own range is published, and
+// only on the prefix of a range below every range its workgroup holds (drawn or parked).
+// The workgroup holding the smallest unpublished range therefore never waits on anything
+// that needs a later range, whatever the dispatch order or residency, and the resolver
+// publishes a range's prefix as soon as every earlier range is in (partial progress).
 __device__ __forceinline__ void worker_wave(const KernelArgs &a, Shared &sh, const uint32_t lane,
                                             const uint32_t wave) {
-    unsigned int *ticket_ctr = reinterpret_cast<unsigned int *>(a.ws);
+    // ticket shard of this workgroup: by arrival order, so that the workgroups that are
+    // resident always cover every shard in use (shards in use <= number of workers)
+    const uint32_t workers = gridDim.x - 1u;
+    const uint32_t shards = workers < kTicketShards ? workers : kTicketShards;
+    const uint32_t shard = (uniform32(sh.role) - 1u) % shards;
+    unsigned int *ticket_ctr = reinterpret_cast<unsigned int *>(a.ws + (uint64_t)shard * kTicketStrideWords);
     uint32_t *stage = sh.stage[wave];
     const uint32_t tid = threadIdx.x;
     const uint32_t ntiles = a.ntiles;
@@ -557,150 +612,221 @@ __device__ __forceinline__ void worker_wave(const KernelArgs &a, Shared &sh, con
     uint64_t *ragg = a.ws + kDescOffset + ntiles;
     const uint64_t *rpre = ragg + nranges;
     if (tid == 0) {
-        sh.range_lo[0] = atomicAdd(ticket_ctr, kRange);
-        sh.range_lo[1] = atomicAdd(ticket_ctr, kRange);
+        sh.range_lo[0] = (atomicAdd(ticket_ctr, 1u) * shards + shard) * kRange;
+        sh.range_seq = 0;
     }
     if (lane < kPendSlots) sh.pend_meta[wave][lane][0] = 0xFFFFFFFFu;  // all slots empty
     __syncthreads();
-    uint32_t lo_cur = sh.range_lo[0], lo_next = sh.range_lo[1];
+    // LDS words every lane reads identically: uniform (tile indices and all control flow stay scalar)
+    uint32_t lo_cur = uniform32(sh.range_lo[0]);
     const uint64_t count0 = uniform64(a.carry_in->count);  // launch invariant: read once
     uint32_t timeout = 0;
+    volatile uint32_t *range_seq = &sh.range_seq;
 
-    Block cur;
-    load_block(a, lo_cur + wave < ntiles ? lo_cur + wave : ntiles - 1u, lane, cur);
-    touch_block(cur);  // loop invariant: `cur` has arrived (no vmcnt wait on it inside the loop)
-    // Emission is deferred by TWO ranges: the tile computed in slot (r & 1, j) replaces,
-    // and first emits, the tile of range r-2 kept in that slot (in LDS).  Its range
-    // prefix has had a whole range of compute time to arrive, which absorbs both the
-    // resolver's latency and the skew between workgroups.
-    uint32_t range_of[2] = {0u, 0u};
-    bool have_range[2] = {false, false};
-    uint32_t r = 0;
+    Block blk[kBatch];
+#pragma unroll
+    for (uint32_t j = 0; j < kBatch; j++) {
+        const uint32_t t = lo_cur + kWaves * j + wave;
+        load_block(a, t < ntiles ? t : ntiles - 1u, lane, blk[j]);
+    }
+#pragma unroll
+    for (uint32_t j = 0; j < kBatch; j++) touch_block(blk[j]);  // loop invariant: the bytes have arrived
+
+    uint32_t r = 0, ring = 0;  // ring = r % kDefer: the slots to emit from, then to park in
     while (lo_cur < ntiles) {  // uniform across the workgroup
         const uint32_t par = r & 1u;
-        // range r+2, requested now, needed at the end of this range
+        // prefix of the range parked in this ring position (published long ago, normally)
+        const uint32_t old_first = uniform32(sh.pend_meta[wave][ring * kBatch][0]);  // its first tile of this wave
+        const bool have_old = old_first != 0xFFFFFFFFu;  // later tiles of a wave are past the end if the first is
+        const uint32_t old_range = have_old ? old_first / kRange : 0u;
+        uint64_t rp_word = ld_desc(&rpre[old_range]);
+        MSJ_RSTAMP(old_range * kRange, 10, tid == 0 && have_old);  // prefix word sampled (real time)
+        // ---- 1. compute
+        Pending now[kBatch];
         uint32_t req_reg = 0;
-        if (tid == 0) req_reg = ticket_request(ticket_ctr, 0u, kRange);
-        // prefix of range r-2 (published two barriers ago)
-        uint64_t rp_word = ld_desc(&rpre[have_range[par] ? range_of[par] : 0u]);
 #pragma unroll
         for (uint32_t j = 0; j < kBatch; j++) {
             const uint32_t t_cur = lo_cur + kWaves * j + wave;
-            const uint32_t t_nxt = (j + 1u < kBatch) ? t_cur + kWaves : lo_next + wave;
             const bool valid_tile = t_cur < ntiles;
-            const uint32_t slot = par * kBatch + j;
             MSJ_STAMP(valid_tile ? t_cur : ntiles - 1u, 0);
-            // request the next tile's bytes
-            Block nxt;  // past the last tile: harmless re-read of the last tile (branch-free)
-            load_block(a, t_nxt < ntiles ? t_nxt : ntiles - 1u, lane, nxt);
-            MSJ_STAMP(valid_tile ? t_cur : ntiles - 1u, 11);
             uint64_t agg_word = kAgg;  // a tile past the end: identity
-            Pending now;
-            now.T0 = 0;
-            now.T1 = 0;
-            now.excl = 0;
-            now.tile_cnt = 0;
-            if (valid_tile) now = compute_tile(a, t_cur, lane, cur, timeout, agg_word);
-            // everything requested above has had a whole compute phase to arrive; wait for
-            // it before this iteration's first store goes into the queue
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            touch_block(nxt);
-            touch_u64(rp_word);
+            now[j].T0 = 0;
+            now[j].T1 = 0;
+            now[j].excl = 0;
+            now[j].tile_cnt = 0;
+            now[j].tile = valid_tile ? t_cur : 0xFFFFFFFFu;
+            if (valid_tile) {
+                now[j] = compute_tile(a, t_cur, lane, blk[j], timeout, agg_word);
+                now[j].tile = t_cur;
+            }
+            if (j == 0) {
+                // the prefix word requested above has arrived (nothing younger is in flight yet) ...
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                touch_u64(rp_word);
+                // ... and the next range's ticket is drawn: one compute + one staging phase
+                // ahead of its use, which covers the atomic's round trip
+                if (tid == 0) req_reg = ticket_request(ticket_ctr, 0u, 1u);
+            }
             if (lane == 0) {
                 if (valid_tile) st_desc(&a.ws[kDescOffset + t_cur], agg_word);  // carries for t_cur + 1
                 sh.tagg[par][kWaves * j + wave] = agg_word;
             }
             MSJ_STAMP(valid_tile ? t_cur : ntiles - 1u, 7);
-            MSJ_RSTAMP(t_cur, 12, lane == 0 && valid_tile);
-            // emit the tile of range r-2 that sits in this slot, then take the slot
-            const uint32_t old_tile = uniform32(sh.pend_meta[wave][slot][0]);
-            if (old_tile != 0xFFFFFFFFu) {  // uniform
-                Pending old;
-                const uint4 m = sh.pend_masks[wave][slot][lane];
-                old.T0 = u64(m.x, m.y);
-                old.T1 = u64(m.z, m.w);
-                old.excl = sh.pend_excl[wave][slot][lane];
-                old.tile = old_tile;
-                old.tile_cnt = uniform32(sh.pend_meta[wave][slot][1]);
-                old.in_cnt = uniform32(sh.pend_meta[wave][slot][2]);
-                old.in_s = uniform32(sh.pend_meta[wave][slot][3]);
-                MSJ_STAMP(old_tile, 15);
-                rp_word = range_prefix(rpre, range_of[par], rp_word, timeout);
-                rp_word = uniform64(rp_word);
-                emit_tile(a, stage, lane, old, rp_word, count0, timeout);
-            }
-            sh.pend_masks[wave][slot][lane] =
-                make_uint4((uint32_t)now.T0, (uint32_t)(now.T0 >> 32), (uint32_t)now.T1, (uint32_t)(now.T1 >> 32));
-            sh.pend_excl[wave][slot][lane] = now.excl;
-            if (lane == 0) {
-                sh.pend_meta[wave][slot][0] = valid_tile ? t_cur : 0xFFFFFFFFu;
-                sh.pend_meta[wave][slot][1] = now.tile_cnt;
-            }
-            cur = nxt;
         }
-        if (tid == 0) sh.range_lo[par] = req_reg;  // arrived: vmcnt(0) above
-        __syncthreads();
-        // ---- fold the range's kRange tile aggregates in tile order (every wave does it:
-        //      it is a few dozen scalar operations) -> the range aggregate for the resolver,
-        //      and every tile's state / count inside the range for both range states
+        const uint32_t last_row = (lo_cur + kWaves * (kBatch - 1u) + wave < ntiles)
+                                      ? lo_cur + kWaves * (kBatch - 1u) + wave : ntiles - 1u;
+        const uint32_t first_row = (lo_cur + wave < ntiles) ? lo_cur + wave : ntiles - 1u;
+        (void)last_row;
+        (void)first_row;
+#ifdef MSJ_STAMPS
+        if (tid == 0 && have_old && a.stamps) a.stamps[(uint64_t)(old_range * kRange) * 16 + 11] = 1 + (rp_word >> 62);
+#endif
+        MSJ_STAMP(last_row, 8);
+        // workgroup barrier for the LDS words only: the descriptor stores above need not have
+        // completed (__syncthreads() would wait for them)
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        MSJ_STAMP(last_row, 9);
+        // wave 0 passes the next range's ticket on (drawn a compute phase ago) ...
+        if (wave == 0) {
+            const uint32_t v = ticket_value(req_reg);  // the shard's k-th draw is range k * shards + shard
+            if (lane == 0) sh.range_lo[par] = (v * shards + shard) * kRange;
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            if (lane == 0) *range_seq = r + 1u;
+        }
+        // ---- 2. fold the range's kRange tile aggregates in tile order -> the range aggregate
+        //      for the resolver, and every tile's state / count inside the range for both range
+        //      states.  Lane k (< kRange) holds tile k's aggregate: the in-range parity is a
+        //      ballot + mbcnt, the counts a three-step DPP scan.
+        uint32_t in_cnt[kBatch], in_state[kBatch];
         {
-            uint32_t s0 = 0, s1 = 1, c0s = 0, c1s = 0, e0s = 0, e1s = 0, u8s = 0, pzs = 0;
+            const uint64_t w = sh.tagg[par][lane & (kRange - 1u)];
+            const uint32_t wl = (uint32_t)w, wh = (uint32_t)(w >> 32);
+            const bool in8 = lane < kRange;
+            const uint32_t c0 = wl & 0x7FFFu, c1 = (uint32_t)(w >> 15) & 0xFFFFu;
+            const uint32_t P8 = (uint32_t)__ballot(in8 && ((wh >> 29) & 1u));  // tile parities (bit 61)
+            const uint32_t s0 = __builtin_amdgcn_mbcnt_lo(P8, 0u) & 1u;  // tile k's state if the range starts outside a string
+            // count of tile k under range state 0 | state 1 << 16  (state 1 sees the other one)
+            const uint32_t ab = s0 ? (c1 | (c0 << 16)) : (c0 | (c1 << 16));
+            uint32_t inc = ab;
+            inc += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)inc, 0x111, 0xF, 0xF, false);  // row_shr:1
+            inc += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)inc, 0x112, 0xF, 0xF, false);  // row_shr:2
+            inc += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)inc, 0x114, 0xF, 0xF, false);  // row_shr:4
+            const uint32_t excl = inc - ab;
+            const uint32_t e0 = (wh >> 28) & 1u, e1 = (wh >> 27) & 1u;  // bits 60, 59
+            const uint32_t e0s = __ballot(in8 && (s0 ? e1 : e0)) != 0ull;
+            const uint32_t e1s = __ballot(in8 && (s0 ? e0 : e1)) != 0ull;
+            const uint32_t u8s = __ballot(in8 && ((wh >> 24) & 1u)) != 0ull;  // bit 56
+            const uint32_t pzs = __ballot(in8 && ((wh >> 22) & 1u)) != 0ull;  // bit 54
+            const uint32_t in_s = s0 | ((s0 ^ 1u) << 1);
 #pragma unroll
-            for (uint32_t k = 0; k < kRange; k++) {
-                const uint64_t w = sh.tagg[par][k];
-                if (k % kWaves == wave && lane == 0) {
-                    sh.pend_meta[wave][par * kBatch + k / kWaves][2] = c0s | (c1s << 16);
-                    sh.pend_meta[wave][par * kBatch + k / kWaves][3] = s0 | (s1 << 1);
-                }
-                const uint32_t p = (uint32_t)(w >> 61) & 1u;
-                const uint32_t c0 = (uint32_t)w & 0x7FFFu, c1 = (uint32_t)(w >> 15) & 0xFFFFu;
-                const uint32_t e0 = (uint32_t)(w >> 60) & 1u, e1 = (uint32_t)(w >> 59) & 1u;
-                c0s += s0 ? c1 : c0;
-                e0s |= s0 ? e1 : e0;
-                s0 ^= p;
-                c1s += s1 ? c1 : c0;
-                e1s |= s1 ? e1 : e0;
-                s1 ^= p;
-                u8s |= (uint32_t)(w >> 56) & 1u;
-                pzs |= (uint32_t)(w >> 54) & 1u;
+            for (uint32_t j = 0; j < kBatch; j++) {
+                const uint32_t k = kWaves * j + wave;  // this wave's tiles of the range
+                in_cnt[j] = bcast(excl, (int)k);
+                in_state[j] = bcast(in_s, (int)k);
             }
             if (tid == 0) {
-                st_desc(&ragg[lo_cur / kRange], kAgg | ((uint64_t)s0 << 61) | ((uint64_t)e0s << 60) |
+                const uint32_t tot = bcast(inc, (int)kRange - 1);
+                const uint32_t s_out = (uint32_t)__builtin_popcount(P8 & 0xFFu) & 1u;
+                st_desc(&ragg[lo_cur / kRange], kAgg | ((uint64_t)s_out << 61) | ((uint64_t)e0s << 60) |
                                                     ((uint64_t)e1s << 59) | ((uint64_t)u8s << 56) |
-                                                    ((uint64_t)pzs << 54) | ((uint64_t)c1s << 16) |
-                                                    (uint64_t)c0s);
+                                                    ((uint64_t)pzs << 54) | ((uint64_t)(tot >> 16) << 16) |
+                                                    (uint64_t)(tot & 0xFFFFu));
             }
         }
-        range_of[par] = lo_cur / kRange;
-        have_range[par] = true;
-        lo_cur = lo_next;
-        lo_next = sh.range_lo[par];
-        r++;
-    }
-    // ---- drain: the older range first
-#pragma unroll
-    for (uint32_t step = 0; step < 2; step++) {
-        const uint32_t par = (r + step) & 1u;
-        if (!have_range[par]) continue;
-        uint64_t w = 0;
+        MSJ_STAMP(last_row, 10);
+        // ... and everybody requests the next range's bytes: in flight during the whole emission
+        {
+            // one LDS word; loop control stays workgroup-uniform whatever happens: everybody
+            // continues with the LDS word
+            uint32_t spins = 0;
+            while (*range_seq != r + 1u) {
+                __builtin_amdgcn_s_sleep(1);
+                if (++spins > 64u * kSpinLimit) {
+                    timeout = 1;
+                    break;
+                }
+            }
+        }
+        const uint32_t lo_next = uniform32(sh.range_lo[par]);
 #pragma unroll
         for (uint32_t j = 0; j < kBatch; j++) {
-            const uint32_t slot = par * kBatch + j;
-            const uint32_t old_tile = sh.pend_meta[wave][slot][0];
-            if (old_tile != 0xFFFFFFFFu) {
-                Pending old;
-                const uint4 m = sh.pend_masks[wave][slot][lane];
-                old.T0 = u64(m.x, m.y);
-                old.T1 = u64(m.z, m.w);
-                old.excl = sh.pend_excl[wave][slot][lane];
-                old.tile = old_tile;
-                old.tile_cnt = sh.pend_meta[wave][slot][1];
-                old.in_cnt = sh.pend_meta[wave][slot][2];
-                old.in_s = sh.pend_meta[wave][slot][3];
-                w = range_prefix(rpre, range_of[par], w, timeout);
-                emit_tile(a, stage, lane, old, w, count0, timeout);
+            const uint32_t t = lo_next + kWaves * j + wave;
+            load_block(a, t < ntiles ? t : ntiles - 1u, lane, blk[j]);  // past the end: harmless re-read
+        }
+        MSJ_RSTAMP(lo_cur, 8, tid == 0);  // range aggregate published (real time)
+        // ---- 3. emit the range parked kDefer iterations ago; hand the next range over in between
+        if (have_old) {
+            rp_word = uniform64(range_prefix(rpre, old_range, uniform64(rp_word), timeout));
+            MSJ_RSTAMP(old_range * kRange, 9, tid == 0);  // its prefix is in hand (real time)
+        }
+        MSJ_STAMP(last_row, 12);
+        Emit e0;
+        e0.live = false;
+        e0.staged = false;
+        if (have_old) e0 = prepare_emit(a, sh, wave, ring * kBatch, lane, rp_word, count0, timeout);
+        if (e0.live && e0.staged) stage_indices(e0, stage, lane);  // uniform
+        lds_wave_sync();
+        MSJ_STAMP(first_row, 12);
+        MSJ_STAMP(first_row, 13);
+        if (e0.live) {
+            if (e0.staged)
+                copy_out(a, e0, stage, lane);
+            else
+                emit_general(a, e0, stage, lane);
+        }
+        lds_wave_sync();  // the staging slice is reused by the next tile
+        MSJ_STAMP(first_row, 14);
+        static_assert(kBatch == 2, "the emission below is written for two tiles per wave and range");
+        Emit e1;
+        e1.live = false;
+        e1.staged = false;
+        if (have_old) e1 = prepare_emit(a, sh, wave, ring * kBatch + 1u, lane, rp_word, count0, timeout);
+        if (e1.live && e1.staged) stage_indices(e1, stage, lane);
+        lds_wave_sync();
+        MSJ_STAMP(first_row, 15);
+        // the bytes requested above (and the first tile's stores) have had a whole staging phase
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+        for (uint32_t j = 0; j < kBatch; j++) touch_block(blk[j]);
+        MSJ_STAMP(last_row, 13);
+        if (e1.live) {
+            if (e1.staged)
+                copy_out(a, e1, stage, lane);
+            else
+                emit_general(a, e1, stage, lane);
+        }
+        lds_wave_sync();
+        MSJ_STAMP(last_row, 14);
+        // ---- 4. park this iteration's tiles
+#pragma unroll
+        for (uint32_t j = 0; j < kBatch; j++) {
+            const uint32_t slot = ring * kBatch + j;
+            sh.pend_masks[wave][slot][lane] = make_uint4((uint32_t)now[j].T0, (uint32_t)(now[j].T0 >> 32),
+                                                         (uint32_t)now[j].T1, (uint32_t)(now[j].T1 >> 32));
+            sh.pend_excl[wave][slot][lane] = now[j].excl;
+            if (lane == 0) {
+                sh.pend_meta[wave][slot][0] = now[j].tile;
+                sh.pend_meta[wave][slot][1] = now[j].tile_cnt;
+                sh.pend_meta[wave][slot][2] = in_cnt[j];
+                sh.pend_meta[wave][slot][3] = in_state[j];
             }
         }
+        lo_cur = lo_next;
+        r++;
+        ring = (ring + 1u == kDefer) ? 0u : ring + 1u;
+        MSJ_STAMP(last_row, 15);
+    }
+    // ---- drain: oldest first
+    for (uint32_t step = 0; step < kDefer; step++) {
+        lds_wave_sync();
+        const uint32_t old_first = uniform32(sh.pend_meta[wave][ring * kBatch][0]);
+        if (old_first != 0xFFFFFFFFu) {
+            const uint64_t w = uniform64(range_prefix(rpre, old_first / kRange, 0ull, timeout));
+#pragma unroll
+            for (uint32_t j = 0; j < kBatch; j++)
+                emit_one(a, stage, prepare_emit(a, sh, wave, ring * kBatch + j, lane, w, count0, timeout), lane);
+        }
+        ring = (ring + 1u == kDefer) ? 0u : ring + 1u;
     }
 }
 
@@ -760,6 +886,8 @@ __device__ void resolver(const KernelArgs &a, Shared &sh) {
 #pragma unroll
         for (int e = 0; e < kResolveE; e++) d[e] = 0;
         uint32_t spins = 0, published = 0, force = 0;
+        MSJ_RSTAMP(a.ntiles + c, 0, lane == 0);
+        uint32_t rounds = 0; (void)rounds;
         bool have_state = false, full = false, agg_done = false;
         uint32_t s = 0, cnt = 0, err = 0, u8 = 0, poison = 0;
         uint32_t m = 0;
@@ -781,6 +909,8 @@ __device__ void resolver(const KernelArgs &a, Shared &sh) {
                     if (nr) m = (uint32_t)e * 64u + (uint32_t)__builtin_ctzll(nr);
                 }
                 full = (m == kResolveChunk);
+                rounds++;
+                if (full) MSJ_RSTAMP(a.ntiles + c, 1, lane == 0);
             }
             if (full && !agg_done) {
                 // everything that does not need the running state, done before it arrives
@@ -816,6 +946,7 @@ __device__ void resolver(const KernelArgs &a, Shared &sh) {
                 u8 = sh.rs_u8;
                 poison = sh.rs_poison;
                 have_state = true;
+                MSJ_RSTAMP(a.ntiles + c, 2, lane == 0);
             }
             if (have_state && full) {
                 // ---- the serial section of the whole launch: scalar steps only
@@ -857,9 +988,11 @@ __device__ void resolver(const KernelArgs &a, Shared &sh) {
                         const uint32_t u_in = ub[e] | (((UM[e] & below) != 0ull) ? 1u : 0u);
                         st_desc(&pre[t], kPre | ((uint64_t)s_in << 61) | ((uint64_t)e_in << 60) |
                                              ((uint64_t)u_in << 56) | pz | (uint64_t)before);
-                        MSJ_RSTAMP(t, 13, true);
                     }
                 }
+#ifdef MSJ_STAMPS
+                if (lane == 0 && a.stamps) { a.stamps[(uint64_t)(a.ntiles + c) * 16 + 3] = __builtin_amdgcn_s_memrealtime(); a.stamps[(uint64_t)(a.ntiles + c) * 16 + 4] = rounds; a.stamps[(uint64_t)(a.ntiles + c) * 16 + 5] = published; }
+#endif
                 if (c + 1u == nchunks && lane == 0) {
                     // ---- finish(): json_structural_indexer.mojo:147-186
                     const msj_carry cin = *a.carry_in;
@@ -945,8 +1078,7 @@ __device__ void resolver(const KernelArgs &a, Shared &sh) {
                                                             ((uint32_t)(de >> 54) & 1u))) << 54;
                             st_desc(&pre[t], kPre | ((uint64_t)in_l << 61) | ((uint64_t)e_in << 60) |
                                                  ((uint64_t)u_in << 56) | pz | (uint64_t)(cc + incl - mine));
-                            MSJ_RSTAMP(t, 13, true);
-                        }
+                            }
                         cc += bcast(incl, 63);
                         ce |= EM ? 1u : 0u;
                         cu |= U ? 1u : 0u;
@@ -975,7 +1107,8 @@ __global__ __launch_bounds__(kThreads, 4) void stage1_kernel(const KernelArgs a)
         resolver(a, sh);
         return;
     }
-    worker_wave(a, sh, tid & 63u, tid >> 6);
+    // the wave index is wave-uniform: say so, or every tile-derived value and branch is vector code
+    worker_wave(a, sh, tid & 63u, uniform32(tid >> 6));
 }
 
 }  // namespace msj

@@ -16,14 +16,20 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from mojo_simdjson_amd import _lib, synth  # noqa: E402
 
-PHASES = ["window carries", "planes+classify+escape", "strings+scalars", "utf8", "count scan",
-          "waits+publish agg", "deferred (2 tiles)", "prefix word", "emit (LDS staged)"]
+TILE_ORDER = [0, 1, 2, 3, 4, 5, 6, 7]
+RANGE_ORDER = [7, 8, 9, 10, 12, 13, 14, 15]  # on the wave's last tile row; 12..15 of the first tile row: inside the emission
+NAMES = {0: "tile loop top", 1: "compute_tile entered", 2: "window carries",
+         3: "planes+classify+escape carry", 4: "strings+scalars", 5: "utf8", 6: "count scan+ballots",
+         7: "publish tile aggregate", 8: "prefix word arrived (vmcnt 0)", 9: "barrier wait",
+         10: "fold + publish range aggregate + ticket request", 12: "range prefix word (poll if late)",
+         13: "stage A, ticket hand-over, loads, copy A, stage B, bytes wait", 14: "copy out B",
+         15: "park new tiles in LDS"}
 
 
 def main():
     workload = sys.argv[1] if len(sys.argv) > 1 else "minified"
     _lib._share_torch_hip_runtime()
-    lib = ctypes.CDLL(os.path.join(ROOT, "mojo_simdjson_amd", "libmsj_stage1_stamps.so"))
+    lib = ctypes.CDLL(os.environ.get("MSJ_STAMPS_LIB", os.path.join(ROOT, "mojo_simdjson_amd", "libmsj_stage1_stamps.so")))
     dev = torch.device("cuda", 0)
     torch.cuda.set_device(0)
     u = synth.workload(workload, 64 << 20)
@@ -31,7 +37,7 @@ def main():
     d_buf = d_unit.repeat((1 << 30) // u.size)
     n = d_buf.numel()
     ntiles = (n + 4095) // 4096
-    stamps = torch.zeros(ntiles * 16, dtype=torch.int64, device=dev)
+    stamps = torch.zeros((ntiles + 8192) * 16, dtype=torch.int64, device=dev)
     d_idx = torch.empty(int(n * 0.75), dtype=torch.int32, device=dev)
     d_res = torch.zeros(64, dtype=torch.uint8, device=dev)
     h = ctypes.c_void_p()
@@ -39,54 +45,87 @@ def main():
     lib.msj_debug_set_stamps(ctypes.c_void_p(stamps.data_ptr()))
     lib.msj_stage1_device.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint64, ctypes.c_void_p,
                                       ctypes.c_uint64, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint32]
+    flags = int(os.environ.get("MSJ_STAMPS_FLAGS", "0"))
     for _ in range(3):
+        stamps.zero_()
         rc = lib.msj_stage1_device(h, d_buf.data_ptr(), n, d_idx.data_ptr(), d_idx.numel(),
-                                   d_res.data_ptr(), None, 0)
+                                   d_res.data_ptr(), None, flags)
         assert rc == 0
         torch.cuda.synchronize()
-    raw = stamps.cpu().numpy().reshape(ntiles, 16).astype(np.int64)
-    ok = raw[:, 0] > 0
-    print(f"loop top -> prefetch issued : median {np.median((raw[:, 11] - raw[:, 0])[ok]):.0f}")
-    print(f"prefetch issued -> compute  : median {np.median((raw[:, 1] - raw[:, 11])[ok]):.0f}")
-    okp = (raw[:, 15] > 0) & (raw[:, 8] > 0)
-    print(f"range-prefix wait (cycles): median {np.median((raw[:, 8] - raw[:, 15])[okp]):.0f} mean {np.mean((raw[:, 8] - raw[:, 15])[okp]):.0f}")
-    print(f"publish -> emit slot reached (cycles): median {np.median((raw[:, 15] - raw[:, 7])[okp]):.0f}")
-    w = (raw[:, 8] - raw[:, 15])[okp]
-    print("range-prefix wait percentiles (cycles):", {q: int(np.percentile(w, q)) for q in (50, 75, 90, 95, 99, 99.9)})
-    print(f"sum of waits / sum of lifetimes: {w.clip(0, 10**9).sum() / max(1, (raw[:, 10] - raw[:, 1])[okp].clip(0, 10**9).sum()):.3f}")
-    tt = raw[:, 14][okp]; tt = (tt - tt.min()) * 10e-3
-    for lo in range(0, int(tt.max()) + 1, 100):
-        sel = (tt >= lo) & (tt < lo + 100)
-        if sel.any():
-            print(f"  t=[{lo:5d},{lo+100:5d}) us: tiles {sel.sum():6d} median wait {np.median(w[sel]):8.0f} mean {w[sel].clip(0,10**9).mean():10.0f}")
-    rt = raw[:, 12:15]
-    okr = (rt[:, 0] > 0) & (rt[:, 1] > 0) & (rt[:, 2] > 0)
-    lat = (rt[:, 1] - rt[:, 0])[okr] * 10e-3  # 100 MHz ticks -> us
-    slack = (rt[:, 2] - rt[:, 1])[okr] * 10e-3
-    print(f"resolver latency publish->prefix: median {np.median(lat):.2f} us  p90 {np.percentile(lat, 90):.2f}  max {lat.max():.2f}  (n={okr.sum()})")
-    print(f"slack prefix->needed            : median {np.median(slack):.2f} us  p10 {np.percentile(slack, 10):.2f}  frac<0 {np.mean(slack < 0):.3f}")
-    span_rt = (rt[:, 2][okr].max() - rt[:, 0][okr].min()) * 10e-3
-    print(f"real-time span {span_rt:.1f} us")
-    # iteration accounting for the first tile of each range-wave pair (t and t+4 belong to the same wave)
-    t0 = raw[:, 0]
-    per = t0[4:] - t0[:-4]
-    okk = (t0[4:] > 0) & (t0[:-4] > 0) & (per > 0) & (per < 10**7) & ((np.arange(len(per)) % 8) < 4)
-    print(f"iteration period (cycles): median {np.median(per[okk]):.0f}")
-    def seg(a, b, src=raw):
-        d = src[:, b] - src[:, a]
-        m = (src[:, a] > 0) & (src[:, b] > 0) & (d >= 0) & (d < 10**7)
-        return np.median(d[m]) if m.any() else float('nan')
-    print(f"  issue loads 0->11 {seg(0,11):.0f} | compute 1->6 {seg(1,6):.0f} | wait+publish 6->7 {seg(6,7):.0f}")
-    s = raw[:, 1:11]
-    d = np.diff(s, axis=1)
-    life = s[:, 9] - s[:, 0]
-    print(f"workload {workload}: {ntiles} tiles; tile lifetime median {np.median(life):.0f} ticks, "
-          f"p90 {np.percentile(life, 90):.0f}")
-    span = s[:, 9].max() - s[:, 0].min()
-    print(f"kernel span {span} ticks; sum of lifetimes / span = {life.sum() / span:.1f} tiles in flight")
-    for k, name in enumerate(PHASES):
-        print(f"  {name:20s} median {np.median(d[:, k]):9.0f}  mean {d[:, k].mean():9.0f}  "
-              f"share {100 * d[:, k].sum() / life.sum():5.1f} %")
+    allraw = stamps.cpu().numpy().reshape(ntiles + 8192, 16).astype(np.int64)
+    raw = allraw[:ntiles]
+    res = allraw[ntiles:]
+    okt = np.all(raw[:, TILE_ORDER] > 0, axis=1)
+    okr = okt & np.all(raw[:, RANGE_ORDER] > 0, axis=1)   # the wave's last tile of a range, steady state
+    print(f"workload {workload}: {ntiles} tiles, {okt.sum()} tile rows, {okr.sum()} range rows")
+    tt = (raw[:, 7] - raw[:, 0])[okt]
+    print(f"per tile (loop top -> aggregate published): median {np.median(tt):.0f}  mean {tt.mean():.0f}  p90 {np.percentile(tt, 90):.0f}")
+    for a_, b_ in zip(TILE_ORDER[:-1], TILE_ORDER[1:]):
+        d = (raw[:, b_] - raw[:, a_])[okt]
+        print(f"  -> {NAMES[b_]:44s} median {np.median(d):7.0f}  mean {d.mean():8.0f}  p90 {np.percentile(d, 90):7.0f}")
+    # range part; the whole iteration = 2 tiles + range part: first tile of the wave is row - 4
+    first0 = np.zeros(ntiles, dtype=np.int64)
+    first0[4:] = raw[:-4, 0]
+    it = (raw[:, 15] - first0)
+    m = okr & (first0 > 0) & (it > 0) & (it < 10**7)
+    print(f"per range iteration (2 tiles): median {np.median(it[m]):.0f}  mean {it[m].mean():.0f}  p90 {np.percentile(it[m], 90):.0f}")
+    for a_, b_ in zip(RANGE_ORDER[:-1], RANGE_ORDER[1:]):
+        d = (raw[:, b_] - raw[:, a_])[m]
+        d = d[(d >= 0) & (d < 10**6)]
+        print(f"  -> {NAMES[b_]:44s} median {np.median(d):7.0f}  mean {d.mean():8.0f}  p90 {np.percentile(d, 90):7.0f}  share {100 * d.sum() / it[m].sum():5.1f} %")
+    # inside the emission (stamps on the wave's first tile row of the range: row - 4)
+    fr = np.zeros((ntiles, 16), dtype=np.int64); fr[4:] = raw[:-4]
+    me = m & np.all(fr[:, [12, 13, 14, 15]] > 0, axis=1)
+    for nm, x, y in (("prepare + stage tile A", raw[:, 12], fr[:, 12]), ("ticket hand-over + issue loads", fr[:, 12], fr[:, 13]),
+                     ("copy out A", fr[:, 13], fr[:, 14]), ("prepare + stage tile B", fr[:, 14], fr[:, 15]),
+                     ("wait for next range's bytes", fr[:, 15], raw[:, 13])):
+        d = (y - x)[me]
+        d = d[(d >= 0) & (d < 10**6)]
+        print(f"     . {nm:32s} median {np.median(d):7.0f}  mean {d.mean():8.0f}  p90 {np.percentile(d, 90):7.0f}")
+    mh = me & (fr[:, 11] > 0) & ((np.arange(ntiles) % 4) != 0)
+    d = (fr[:, 11] - fr[:, 12])[mh]
+    print(f"     . (waves 1-3) staged -> ticket seen  median {np.median(d):7.0f}  mean {d.mean():8.0f}  p90 {np.percentile(d, 90):7.0f}")
+    d = (fr[:, 13] - fr[:, 11])[mh]
+    print(f"     . (waves 1-3) ticket seen -> loads issued median {np.median(d):7.0f}  mean {d.mean():8.0f}  p90 {np.percentile(d, 90):7.0f}")
+    ct = (raw[:, 7] - first0)[m]
+    ct = ct[(ct >= 0) & (ct < 10**6)]
+    print(f"  (the two computes: median {np.median(ct):.0f} mean {ct.mean():.0f}  share {100 * ct.sum() / it[m].sum():5.1f} %)")
+    # ---- real-time (100 MHz) view of the resolver chain
+    nch = int((res[:, 3] > 0).sum())
+    rr = res[:nch]
+    t0 = rr[0, 0]
+    us = lambda x: (x - t0) * 0.01
+    print(f"resolver: {nch} chunks of 256 ranges; first chunk entered at 0 us, last done at {us(rr[-1, 3]):.1f} us")
+    print(f"  rounds per chunk: mean {rr[:, 4].mean():.2f} max {rr[:, 4].max()};  published by partial progress: mean {rr[:, 5].mean():.1f}")
+    print(f"  entry -> full   : median {np.median(us(rr[:, 1]) - us(rr[:, 0])):.2f} us mean {np.mean(us(rr[:, 1]) - us(rr[:, 0])):.2f}")
+    print(f"  full  -> done   : median {np.median(us(rr[:, 3]) - us(rr[:, 1])):.2f} us mean {np.mean(us(rr[:, 3]) - us(rr[:, 1])):.2f}")
+    print(f"  state -> done   : median {np.median(us(rr[:, 3]) - us(rr[:, 2])):.2f} us")
+    print(f"  done(c) - done(c-1): median {np.median(np.diff(us(rr[:, 3]))):.2f} us  mean {np.mean(np.diff(us(rr[:, 3]))):.2f}")
+    # per range: publish time (worker) vs its chunk's full / done time vs when the owner had the prefix in hand
+    lo = np.arange(0, ntiles - 8, 8)
+    pub = raw[lo, 8]; got = raw[lo, 9]
+    mk = (pub > 0)
+    chunk = (lo // 8) // 256
+    cdone = np.where(chunk < nch, rr[np.minimum(chunk, nch - 1), 3], 0)
+    cfull = np.where(chunk < nch, rr[np.minimum(chunk, nch - 1), 1], 0)
+    mk2 = mk & (cdone > 0)
+    print(f"range publish -> its chunk full : median {np.median((cfull - pub)[mk2]) * 0.01:.2f} us  p90 {np.percentile((cfull - pub)[mk2], 90) * 0.01:.2f}")
+    print(f"range publish -> its chunk done : median {np.median((cdone - pub)[mk2]) * 0.01:.2f} us  p90 {np.percentile((cdone - pub)[mk2], 90) * 0.01:.2f}")
+    mk3 = mk2 & (got > 0)
+    print(f"range publish -> prefix in hand : median {np.median((got - pub)[mk3]) * 0.01:.2f} us  p10 {np.percentile((got - pub)[mk3], 10) * 0.01:.2f}")
+    print(f"chunk done -> prefix in hand    : median {np.median((got - cdone)[mk3]) * 0.01:.2f} us  p10 {np.percentile((got - cdone)[mk3], 10) * 0.01:.2f}  frac<1us {np.mean((got - cdone)[mk3] < 100):.3f}")
+    smp = raw[lo, 10]; rdy = raw[lo, 11]
+    mk4 = mk3 & (smp > 0) & (rdy > 0)
+    print(f"first sample ready: {np.mean(rdy[mk4] > 1):.3f} of ranges;  publish -> sample: median {np.median((smp - pub)[mk4]) * 0.01:.2f} us;  chunk done -> sample: median {np.median((smp - cdone)[mk4]) * 0.01:.2f} us")
+    nr = mk4 & (rdy == 1)
+    if nr.any():
+        print(f"  not ready at sample ({nr.sum()}): chunk done -> sample median {np.median((smp - cdone)[nr]) * 0.01:.2f} us p90 {np.percentile((smp - cdone)[nr], 90) * 0.01:.2f};  sample -> in hand median {np.median((got - smp)[nr]) * 0.01:.2f} us")
+        print(f"  position in chunk of the not-ready ones: mean {np.mean(((lo // 8) % 256)[nr]):.1f}")
+    # publish times relative to range order: how far out of order do ranges publish
+    order_lag = (pub[mk] - np.maximum.accumulate(pub[mk]))
+    print(f"publish time behind the running max of earlier ranges: median {np.median(order_lag) * 0.01:.2f} us  p1 {np.percentile(order_lag, 1) * 0.01:.2f} us")
+    cm = np.maximum.accumulate(pub[mk])
+    print(f"kernel real-time span by publishes: {(pub[mk].max() - pub[mk].min()) * 0.01:.1f} us")
     lib.msj_ctx_destroy(h)
 
 
