@@ -17,8 +17,13 @@
 
 struct msj_ctx {
     int device = 0;
-    uint64_t *ws = nullptr;       // tile ticket + descriptors
-    uint64_t ws_words = 0;
+    // Two workspace buffers (tickets + descriptors) used alternately.  A launch needs its
+    // buffer zeroed; instead of a memset in front of every launch, each launch zeroes the
+    // OTHER buffer word for word when that one was dirtied with the same layout (same ntiles).
+    uint64_t *ws = nullptr;
+    uint64_t ws_words = 0;        // words per buffer
+    uint32_t ws_toggle = 0;
+    uint32_t ws_dirty[2] = {0, 0}; // ntiles of the launch that last used the buffer; 0 = clean, ~0 = all of it
     msj_carry *carries = nullptr; // [0] = zero carry, [1..] chained segment carries
     uint32_t n_carries = 0;
     // staging for the host-pointer entry points
@@ -37,18 +42,36 @@ constexpr uint32_t kMaxChain = 64;  // segments per shard call (64 x ~4 GiB)
 
 bool hip_ok(hipError_t e) { return e == hipSuccess; }
 
+constexpr uint32_t kAllDirty = 0xFFFFFFFFu;
+
 int32_t ensure_workspace(msj_ctx *ctx, uint32_t ntiles) {
     const uint64_t need = msj::workspace_words(ntiles);
     if (need <= ctx->ws_words) return MSJ_SUCCESS;
-    if (ctx->ws) (void)hipFree(ctx->ws);
+    if (ctx->ws) {
+        (void)hipDeviceSynchronize();  // nothing of ours may still be using the old buffers
+        (void)hipFree(ctx->ws);
+    }
     ctx->ws = nullptr;
     ctx->ws_words = 0;
     // grow with head-room so repeated calls of similar size do not re-allocate
-    const uint64_t words = need + need / 4 + 64;
-    if (!hip_ok(hipMalloc(reinterpret_cast<void **>(&ctx->ws), words * sizeof(uint64_t))))
+    const uint64_t words = (need + need / 4 + 64 + 511) & ~511ull;
+    if (!hip_ok(hipMalloc(reinterpret_cast<void **>(&ctx->ws), 2 * words * sizeof(uint64_t))))
         return MSJ_MEMALLOC;
     ctx->ws_words = words;
+    ctx->ws_toggle = 0;
+    ctx->ws_dirty[0] = ctx->ws_dirty[1] = kAllDirty;  // fresh memory: zeroed before first use
     return MSJ_SUCCESS;
+}
+
+// Zero what a previous launch (or nothing known) left in workspace buffer b.
+bool scrub(msj_ctx *ctx, uint32_t b, hipStream_t stream) {
+    const uint32_t d = ctx->ws_dirty[b];
+    if (d == 0) return true;
+    const uint64_t words = (d == kAllDirty) ? ctx->ws_words : msj::workspace_words(d);
+    if (!hip_ok(hipMemsetAsync(ctx->ws + (uint64_t)b * ctx->ws_words, 0, words * sizeof(uint64_t), stream)))
+        return false;
+    ctx->ws_dirty[b] = 0;
+    return true;
 }
 
 // Enqueue the kernels for one shard: a chain of <= kSegmentBytes launches whose
@@ -80,7 +103,8 @@ int32_t enqueue_shard(msj_ctx *ctx, const uint8_t *d_buf, uint64_t len, uint32_t
         a.len = seg_len;
         a.idx = d_idx;
         a.capacity = idx_capacity;
-        a.ws = ctx->ws;
+        const uint32_t wb = ctx->ws_toggle, wo = wb ^ 1u;
+        a.ws = ctx->ws + (uint64_t)wb * ctx->ws_words;
         a.carry_in = (s == 0) ? d_carry_in : &ctx->carries[s];
         a.carry_out = (s + 1 == nseg) ? d_carry_out : &ctx->carries[s + 1];
         a.segment = d_segments ? &d_segments[s] : nullptr;
@@ -92,11 +116,22 @@ int32_t enqueue_shard(msj_ctx *ctx, const uint8_t *d_buf, uint64_t len, uint32_t
         if (has_prefix || s > 0) a.flags |= msj::kFlagHasPrefix;
         if (no_emit) a.flags |= msj::kFlagNoEmit;
         a.stamps = g_stamps;
-        // ticket + descriptors must read as "not ready" at launch
-        if (!hip_ok(hipMemsetAsync(ctx->ws, 0, msj::workspace_words(a.ntiles) * sizeof(uint64_t),
-                                   stream)))
+        // ticket + descriptors must read as "not ready" at launch: this launch's buffer is clean
+        // already in the steady state; the other one is cleaned by this launch if its dirt has
+        // this launch's layout, by a memset otherwise
+        a.ws_clean = nullptr;
+        if (ctx->ws_dirty[wo] == a.ntiles) a.ws_clean = ctx->ws + (uint64_t)wo * ctx->ws_words;
+        if (!scrub(ctx, wb, stream) || (!a.ws_clean && !scrub(ctx, wo, stream))) {
+            ctx->ws_dirty[0] = ctx->ws_dirty[1] = kAllDirty;
             return MSJ_ERR_HIP;
-        if (msj_launch_stage1(&a, stream, ctx->grid) != 0) return MSJ_ERR_HIP;
+        }
+        if (msj_launch_stage1(&a, stream, ctx->grid) != 0) {
+            ctx->ws_dirty[0] = ctx->ws_dirty[1] = kAllDirty;
+            return MSJ_ERR_HIP;
+        }
+        ctx->ws_dirty[wb] = a.ntiles;
+        ctx->ws_dirty[wo] = 0;
+        ctx->ws_toggle = wo;
     }
     if (n_segments_out) *n_segments_out = (uint32_t)nseg;
     return MSJ_SUCCESS;

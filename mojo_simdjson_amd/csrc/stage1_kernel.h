@@ -40,6 +40,8 @@ struct KernelArgs {
     uint32_t *idx;            // index array base (absolute positions: carry_in->count + ...)
     uint64_t capacity;        // index array capacity in elements
     uint64_t *ws;             // zeroed workspace: ticket + one descriptor per tile
+    uint64_t *ws_clean;       // optional: the OTHER workspace buffer, dirtied by the previous launch with the
+                              // same ntiles; this launch zeroes it word for word (no memset between launches)
     const msj_carry *carry_in;
     msj_carry *carry_out;
     msj_segment *segment;     // optional: segment-table entry to fill

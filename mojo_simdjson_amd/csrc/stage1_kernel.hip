@@ -733,6 +733,18 @@ __device__ __forceinline__ void worker_wave(const KernelArgs &a, Shared &sh, con
                                                     (uint64_t)(tot & 0xFFFFu));
             }
         }
+        if (a.ws_clean && wave == kWaves - 1) {  // uniform
+            // double-buffered workspace: zero, in the buffer the NEXT launch will use, exactly
+            // the words this range dirtied in the previous launch (same ntiles, same layout)
+            const uint32_t rid = lo_cur / kRange;
+            if (lane < kRange) {
+                if (lo_cur + lane < ntiles) a.ws_clean[kDescOffset + lo_cur + lane] = 0ull;
+            } else if (lane == kRange) {
+                a.ws_clean[kDescOffset + ntiles + rid] = 0ull;
+            } else if (lane == kRange + 1u) {
+                a.ws_clean[kDescOffset + ntiles + nranges + rid] = 0ull;
+            }
+        }
         MSJ_STAMP(last_row, 10);
         // ... and everybody requests the next range's bytes: in flight during the whole emission
         {
@@ -868,6 +880,10 @@ __device__ void resolver(const KernelArgs &a, Shared &sh) {
     const uint64_t *agg = a.ws + kDescOffset + a.ntiles;
     uint64_t *pre = a.ws + kDescOffset + a.ntiles + ntiles;
     const uint32_t nchunks = (ntiles + kResolveChunk - 1) / kResolveChunk;
+    if (a.ws_clean && tid < kTicketShards) {
+        a.ws_clean[(uint64_t)tid * kTicketStrideWords] = 0ull;  // ticket counters (+ role ticket in word 1)
+        if (tid == 0) a.ws_clean[1] = 0ull;
+    }
     if (tid == 0) {
         sh.rs_seq = 0;
         sh.rs_s = a.carry_in->in_string & 1u;

@@ -10,7 +10,7 @@ TAG=${1:-run}; shift
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 OUT=gpurun_out/prof/$TAG
 mkdir -p "$OUT"
-ARGS="--steps 5 --warmup 1 --no-cpu-baseline $*"
+ARGS="--steps 20 --warmup 3 --no-cpu-baseline $*"   # same as the default bench run: the kernel slows by ~10 % over the first launches (clocks settle)
 timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/kt" -- python3 bench.py $ARGS > "$OUT/kt.log" 2>&1 || { echo "kernel-trace pass failed"; tail -5 "$OUT/kt.log"; exit 1; }
 i=0
 for PMC in "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU" \

@@ -82,11 +82,6 @@ def main():
         d = (y - x)[me]
         d = d[(d >= 0) & (d < 10**6)]
         print(f"     . {nm:32s} median {np.median(d):7.0f}  mean {d.mean():8.0f}  p90 {np.percentile(d, 90):7.0f}")
-    mh = me & (fr[:, 11] > 0) & ((np.arange(ntiles) % 4) != 0)
-    d = (fr[:, 11] - fr[:, 12])[mh]
-    print(f"     . (waves 1-3) staged -> ticket seen  median {np.median(d):7.0f}  mean {d.mean():8.0f}  p90 {np.percentile(d, 90):7.0f}")
-    d = (fr[:, 13] - fr[:, 11])[mh]
-    print(f"     . (waves 1-3) ticket seen -> loads issued median {np.median(d):7.0f}  mean {d.mean():8.0f}  p90 {np.percentile(d, 90):7.0f}")
     ct = (raw[:, 7] - first0)[m]
     ct = ct[(ct >= 0) & (ct < 10**6)]
     print(f"  (the two computes: median {np.median(ct):.0f} mean {ct.mean():.0f}  share {100 * ct.sum() / it[m].sum():5.1f} %)")
