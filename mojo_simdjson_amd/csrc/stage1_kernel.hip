@@ -5,32 +5,33 @@
 //   (src/mojo_simdjson/generic/stage1/json_structural_indexer.mojo:81-186)
 // by one kernel launch over the whole buffer:
 //
-//   * every wave64 is an independent, persistent worker: it draws 4 KiB tiles from
-//     an ordered ticket counter; each lane owns one 64-byte block = the unit of one
-//     JsonScanner.next call, and all masks are uint64 with the reference's bit
-//     order (lane_math.h).  The worker path contains no workgroup barrier;
+//   * persistent workgroups of four worker waves; a workgroup draws RANGES of 8 consecutive
+//     4 KiB tiles from sharded ticket counters, each wave takes two of the tiles.  Each lane
+//     owns one 64-byte block = the unit of one JsonScanner.next call, and all masks are
+//     uint64 with the reference's bit order (lane_math.h);
 //   * the three 1-bit carries the reference threads through its loop
 //     (next_is_escaped json_escape_scanner.mojo:13, prev_in_string
 //     json_string_scanner.mojo:49, prev_scalar json_scanner.mojo:57) are
 //     resolved lane -> wave with __ballot + a 64-bit carry-lookahead add
-//     (escape), ballot/mbcnt prefix parity (in-string) and a one-lane shuffle
+//     (escape), ballot/mbcnt prefix parity (in-string) and a DPP lane shift
 //     (prev_scalar); the escape / prev_scalar / UTF-8 carries INTO a tile are
 //     derived locally from the 64 bytes in front of it;
 //   * across tiles only the in-string bit and the running structural count are
-//     chained.  Each tile publishes a 64-bit aggregate (parity, count and error
-//     bit for both possible incoming in-string states); one workgroup does not
-//     index anything: it is the RESOLVER, whose four waves fold those aggregates
-//     in order (chunks of 64*kResolveE tiles, pipelined across the waves, state
-//     handed over through LDS) and publish every tile's prefix.  Workers read one
+//     chained.  Each tile yields a 64-bit aggregate (parity, count and error
+//     bit for both possible incoming in-string states); the four waves fold a range's
+//     eight aggregates at one barrier and publish one range aggregate.  One workgroup
+//     does not index anything: it is the RESOLVER, whose four waves fold the range
+//     aggregates in order (chunks of 64*kResolveE ranges, pipelined across the waves, state
+//     handed over through LDS) and publish every range's prefix.  Workers read one
 //     word.  All words are relaxed agent-scope 8-byte stores/loads: the data is
 //     the flag;
 //   * BitIndexer.write (json_structural_indexer.mojo:46-58) becomes a packed
-//     (count|count<<16) wave scan, a per-lane ctz loop into a per-wave LDS staging
-//     slice at the index's tile-relative position, and aligned 16-byte stores;
-//   * software pipeline per wave: the ticket after next, the next tile's bytes and
-//     the prefix of the tile to be emitted next are requested before the current
-//     tile is computed, and the index emission of a tile is deferred by two tiles,
-//     so ticket, HBM, prefix and store latencies overlap with compute.
+//     (count|count<<16) wave scan, a straight-line per-lane ctz chain into a per-wave LDS
+//     staging slice at the index's tile-relative position, and aligned 16-byte stores;
+//   * per range iteration (worker_wave): compute two tiles -> publish -> request the next
+//     range's bytes -> emit the range computed two iterations ago (parked in LDS).  The
+//     resolver retires ranges in order, so the loop keeps the time between drawing a range
+//     and publishing it short and free of anything that can block.
 //
 // No MFMA (nothing here is a contraction); integer/bitwise work on u8 input,
 // u64 masks, u32 output.
