@@ -228,83 +228,151 @@ def verify_chain(reports):
 class ShardedStage1:
     """Drives the HIP kernels for this rank's shard (one process per GPU).
 
-    One single-pass kernel launch per shard and ONE all-gather (a few words per rank) in
+    One single-pass kernel launch per shard and ONE all-gather (128 bytes per rank) in
     the common case: the carries into the shard are derived from its own 64-byte halo and
     a speculative in_string, the all-gathered end states verify the whole chain, and only
     a rank whose speculation was refuted runs again.
+
+    ``submit`` enqueues the kernel and the all-gather and returns at once; ``result``
+    waits for the gathered carries (on a side stream, so that the next ``submit`` --
+    another document, or the next benchmark step -- can already be running on the GPU)
+    and verifies them.  ``run`` = ``result(submit(...))``.
     """
 
-    def __init__(self, dev, rank, world, group=None):
+    DEPTH = 2  # submissions in flight
+
+    def __init__(self, dev, rank, world, group=None, always_gather=False):
+        """always_gather: take the collective path even for world == 1 (lets a one-GPU box
+        exercise the RCCL / side-stream plumbing)."""
         self.dev, self.rank, self.world, self.group = dev, rank, world, group
+        self.always_gather = always_gather
         self.reruns = 0
+        self._slots = None
+        self._next = 0
 
-    def run(self, d_shard, shard_len, d_idx, total_len, has_prefix, flags=0, segments=None,
-            d_halo=None, host_halo=None, host_head=None):
-        """Index this rank's shard.
+    # ---- speculation from local bytes only (host logic; compute once per placed shard)
+    def speculate(self, has_prefix, d_shard=None, shard_len=0, d_halo=None, host_halo=None, host_head=None):
+        """(in_string, next_is_escaped, prev_scalar) assumed at the shard's first byte.
 
-        d_halo: the 64 stream bytes before the shard (device tensor; by default the 64
-        bytes in front of d_shard's storage when has_prefix).  host_halo / host_head:
-        host copies of those 64 bytes and of the shard's first <= 4096 bytes -- whoever
-        placed the shard on the GPU had them in host memory, and passing them saves two
-        small device-to-host copies per call.
-        Returns (code, total_count, local msj_carry)."""
-        import torch
+        host_halo / host_head: host copies of the 64 stream bytes before the shard and of
+        its first <= 4096 bytes -- whoever placed the shard on the GPU had them in host
+        memory; without them they are fetched from the device."""
+        if not has_prefix:
+            return (0, 0, 0)
+        if host_halo is None:
+            if d_halo is None:
+                d_halo = torch.as_strided(d_shard, (64,), (1,), d_shard.storage_offset() - 64)
+            host_halo = d_halo.cpu().numpy().tobytes()
+        if host_head is None:
+            host_head = d_shard[: min(4096, shard_len)].cpu().numpy().tobytes()
+        hc = halo_carry(bytes(host_halo))
+        e_used, ps_used = hc if hc is not None else (0, 1)
+        s_used = guess_in_string(bytes(host_halo), bytes(host_head), e_used)
+        return (s_used, e_used, ps_used)
 
+    def _make_slots(self):
         dev = self.dev
-        last = self.rank == self.world - 1
-        if self.world == 1:
+        nccl = dist.get_backend(self.group) == "nccl"
+        slots = []
+        for _ in range(self.DEPTH):
+            sl = dict(mine=torch.zeros(128, dtype=torch.uint8, device=dev.device), spec=None)
+            if nccl:
+                sl["gathered"] = torch.empty(self.world * 128, dtype=torch.uint8, device=dev.device)
+                sl["host"] = torch.empty(self.world * 128, dtype=torch.uint8).pin_memory()
+                sl["event"] = torch.cuda.Event()
+            slots.append(sl)
+        self._slots = slots
+        self._nccl = nccl
+        self._side = torch.cuda.Stream(device=dev.device) if nccl else None
+
+    def submit(self, d_shard, shard_len, d_idx, total_len, has_prefix, flags=0, segments=None,
+               d_halo=None, host_halo=None, host_head=None, speculation=None):
+        """Enqueue this rank's shard (kernel + all-gather of the carries); returns a ticket."""
+        if self.world == 1 and not self.always_gather:
+            dev = self.dev
             cin = dev.make_carry(0, 0, 0)
             cout = dev.new_carry()
             dev.shard(d_shard, shard_len, d_idx, cin, cout, segments=segments, has_prefix=has_prefix,
                       is_final=True, trailer_len=total_len, flags=flags)
-            c = dev.fetch(cout)
+            return dict(single=cout)
+        if speculation is None:
+            speculation = self.speculate(has_prefix, d_shard, shard_len, d_halo, host_halo, host_head)
+        if self._slots is None:
+            self._make_slots()
+        sl = self._slots[self._next]
+        self._next = (self._next + 1) % self.DEPTH
+        args = dict(d_shard=d_shard, shard_len=shard_len, d_idx=d_idx, total_len=total_len,
+                    has_prefix=has_prefix, flags=flags, segments=segments)
+        self._launch(sl, speculation, args)
+        return dict(slot=sl, args=args)
+
+    def _launch(self, sl, speculation, a):
+        """Kernel + all-gather of (carry used | carry out) = 128 bytes per rank, both
+        stream-ordered behind each other on the device; nothing waits on the host here."""
+        dev = self.dev
+        last = self.rank == self.world - 1
+        mine = sl["mine"]
+        if sl["spec"] != speculation:  # the carry used lives in the first half of the 128-byte report
+            mine[:64].copy_(dev.make_carry(*speculation))
+            sl["spec"] = speculation
+        dev.shard(a["d_shard"], a["shard_len"], a["d_idx"], mine[:64], mine[64:], segments=a["segments"],
+                  has_prefix=a["has_prefix"], is_final=last, trailer_len=a["total_len"], flags=a["flags"])
+        if self._nccl:
+            work = dist.all_gather_into_tensor(sl["gathered"], mine, group=self.group, async_op=True)
+            with torch.cuda.stream(self._side):
+                work.wait()  # the side stream (not the host, not the compute stream) waits for the collective
+                sl["host"].copy_(sl["gathered"], non_blocking=True)
+                sl["event"].record(self._side)
+            sl["blob"] = None
+        else:  # gloo (CPU tests, rehearsal): host tensors, synchronous
+            m = mine.cpu()
+            gathered = torch.empty(self.world * 128, dtype=torch.uint8)
+            dist.all_gather_into_tensor(gathered, m, group=self.group)
+            sl["blob"] = gathered.numpy().tobytes()
+
+    def _collect(self, sl):
+        if sl["blob"] is None:
+            sl["event"].synchronize()
+            sl["blob"] = sl["host"].numpy().tobytes()
+        blob = sl["blob"]
+        reports, carries = [], []
+        for g in range(self.world):
+            used = MsjCarry.from_buffer_copy(blob[128 * g:128 * g + 64])
+            out = MsjCarry.from_buffer_copy(blob[128 * g + 64:128 * g + 128])
+            carries.append(out)
+            reports.append(dict(s_used=used.in_string, e_used=used.next_is_escaped,
+                                ps_used=used.prev_scalar, s_out=out.in_string,
+                                e_out=out.next_is_escaped, ps_out=out.prev_scalar))
+        return reports, carries
+
+    def result(self, ticket, flags=None):
+        """Wait for a submission; returns (code, total_count, local msj_carry)."""
+        if "single" in ticket:
+            c = self.dev.fetch(ticket["single"])
             return int(c.code), int(c.count), c
-        # ---- speculative carries from local bytes only
-        if has_prefix:
-            if host_halo is None:
-                if d_halo is None:
-                    d_halo = torch.as_strided(d_shard, (64,), (1,), d_shard.storage_offset() - 64)
-                host_halo = d_halo.cpu().numpy().tobytes()
-            if host_head is None:
-                host_head = d_shard[: min(4096, shard_len)].cpu().numpy().tobytes()
-            hc = halo_carry(bytes(host_halo))
-            e_used, ps_used = hc if hc is not None else (0, 1)
-            s_used = guess_in_string(bytes(host_halo), bytes(host_head), e_used)
-        else:
-            s_used = e_used = ps_used = 0
-        nccl = dist.get_backend(self.group) == "nccl"
+        sl, a = ticket["slot"], ticket["args"]
         while True:
-            cin = dev.make_carry(s_used, e_used, ps_used)
-            cout = dev.new_carry()
-            dev.shard(d_shard, shard_len, d_idx, cin, cout, segments=segments, has_prefix=has_prefix,
-                      is_final=last, trailer_len=total_len, flags=flags)
-            # ONE collective: every rank's (carry used | carry out), 128 bytes, gathered on the
-            # device (stream-ordered behind the kernel), then a single device-to-host copy
-            mine = torch.cat([cin, cout])
-            if not nccl:
-                mine = mine.cpu()
-            gathered = torch.empty(self.world * mine.numel(), dtype=torch.uint8, device=mine.device)
-            dist.all_gather_into_tensor(gathered, mine, group=self.group)
-            blob = gathered.cpu().numpy().tobytes()
-            reports, carries = [], []
-            for g in range(self.world):
-                used = MsjCarry.from_buffer_copy(blob[128 * g:128 * g + 64])
-                out = MsjCarry.from_buffer_copy(blob[128 * g + 64:128 * g + 128])
-                carries.append(out)
-                reports.append(dict(s_used=used.in_string, e_used=used.next_is_escaped,
-                                    ps_used=used.prev_scalar, s_out=out.in_string,
-                                    e_out=out.next_is_escaped, ps_out=out.prev_scalar))
+            reports, carries = self._collect(sl)
             first_wrong, true_in = verify_chain(reports)
             if first_wrong == self.world:
                 break
-            # every rank sees the same reports, so all agree on who runs again
+            # every rank sees the same reports, so all agree on who runs again; ranks after
+            # first_wrong keep their speculation and are re-verified in the next round
+            spec = sl["spec"]
             if self.rank == first_wrong:
-                s_used, e_used, ps_used = true_in[first_wrong]
+                spec = tuple(true_in[first_wrong])
                 self.reruns += 1
-            # (ranks after first_wrong keep their speculation; they are re-verified next round)
+            self._launch(sl, spec, a)
         c = carries[self.rank]
         total = sum(int(x.count) for x in carries)
         code = global_code(int(carries[-1].in_string), any(int(x.unescaped_error) for x in carries), total,
                            any(int(x.utf8_error) for x in carries), any(int(x.internal_error) for x in carries),
-                           bool(flags & 1))
+                           bool(a["flags"] & 1))
         return code, total, c
+
+    def run(self, d_shard, shard_len, d_idx, total_len, has_prefix, flags=0, segments=None,
+            d_halo=None, host_halo=None, host_head=None, speculation=None):
+        """Index this rank's shard.  Returns (code, total_count, local msj_carry)."""
+        return self.result(self.submit(d_shard, shard_len, d_idx, total_len, has_prefix, flags=flags,
+                                       segments=segments, d_halo=d_halo, host_halo=host_halo,
+                                       host_head=host_head, speculation=speculation))

@@ -393,8 +393,16 @@ def _sharded_worker(rank, world, port, q):
             d_idx = torch.full(((end - start) + 3,), -1, dtype=torch.int32, device=dev.device)
             sh = ShardedStage1(dev, rank, world)
             code, total_count, c = sh.run(d_shard, end - start, d_idx, total, has_prefix=(rank > 0))
+            reruns_first = sh.reruns
+            # two submissions in flight (what bench.py does for N > 1) give the same answer
+            d_idx2 = torch.full_like(d_idx, -1)
+            t1 = sh.submit(d_shard, end - start, d_idx2, total, has_prefix=(rank > 0))
+            t2 = sh.submit(d_shard, end - start, d_idx, total, has_prefix=(rank > 0))
+            r1, r2 = sh.result(t1), sh.result(t2)
+            assert (r1[0], r1[1], int(r1[2].count)) == (code, total_count, int(c.count)) == (r2[0], r2[1], int(r2[2].count))
+            assert torch.equal(d_idx2[: int(c.count)], d_idx[: int(c.count)])
             got = d_idx[: int(c.count) + (3 if rank == world - 1 else 0)].cpu().numpy().view(np.uint32)
-            results.append((name, code, total_count, int(c.count), start, got.tobytes(), sh.reruns))
+            results.append((name, code, total_count, int(c.count), start, got.tobytes(), reruns_first))
         q.put((rank, results))
         dev.close()
     finally:
@@ -476,3 +484,55 @@ def test_multi_segment_over_4gib(torch_mod, dev, oracle):
     assert c0 == int((unit_idx[None, :] + (torch.arange(reps, device=dev.device) * len(b))[:, None] < SEG).sum())
     tail = (d_idx[n * reps:n * reps + 3].to(torch.int64) & 0xFFFFFFFF).tolist()
     assert tail == [total & 0xFFFFFFFF, total & 0xFFFFFFFF, 0]
+
+
+def _rccl_single_rank_worker(port, q):
+    """world_size 1 over the real "nccl" (= RCCL) backend: the asynchronous all-gather, the side
+    stream and the pinned read-back of ShardedStage1 on the one GPU this box has."""
+    import torch
+    import torch.distributed as dist
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        from mojo_simdjson_amd.device import Stage1Device
+        from mojo_simdjson_amd.sharded import ShardedStage1
+
+        dev = Stage1Device(0)
+        data = _sharded_dataset(_SHARDED_SETS[0])
+        d_buf = torch.from_numpy(np.frombuffer(data, dtype=np.uint8).copy()).to(dev.device)
+        sh = ShardedStage1(dev, 0, 1, always_gather=True)
+        bufs = [torch.full((len(data) + 3,), -1, dtype=torch.int32, device=dev.device) for _ in range(3)]
+        tickets = []
+        out = []
+        for k in range(6):  # DEPTH submissions in flight at any time
+            tickets.append(sh.submit(d_buf, len(data), bufs[k % 3], len(data), has_prefix=False))
+            if len(tickets) == ShardedStage1.DEPTH:
+                out.append(sh.result(tickets.pop(0)))
+        while tickets:
+            out.append(sh.result(tickets.pop(0)))
+        code, total, c = out[-1]
+        got = bufs[2][: total + 3].cpu().numpy().view(np.uint32).tobytes()
+        q.put(([(o[0], o[1]) for o in out], got))
+        dev.close()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_sharded_rccl_plumbing_single_rank(oracle):
+    import multiprocessing as mp
+
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_rccl_single_rank_worker, args=(29500 + (os.getpid() % 400) + 411, q))
+    p.start()
+    res, got = q.get(timeout=240)
+    p.join(timeout=60)
+    assert p.exitcode == 0
+    data = _sharded_dataset(_SHARDED_SETS[0])
+    code, n, idx = helpers.run_oracle(oracle.msj_oracle_stage1, data)
+    assert all(r == (code, n) for r in res), res
+    want = np.concatenate([idx[:n], np.array([len(data), len(data), 0], dtype=np.uint32)]).astype(np.uint32)
+    assert got == want.tobytes()
