@@ -263,17 +263,22 @@ struct Utf8Planes {
 MSJ_HD Utf8Planes utf8_planes(const uint64_t p[8]) {
     const uint64_t b0 = p[0], b1 = p[1], b2 = p[2], b3 = p[3];
     const uint64_t b4 = p[4], b5 = p[5], b6 = p[6], b7 = p[7];
-    const uint64_t hi2 = b7 & b6;
-    const uint64_t l3 = hi2 & b5 & ~b4;
-    const uint64_t l4 = hi2 & b5 & b4 & ~b3;
+    // three-input LUTs throughout (v_bitop3_b32 on the device)
+    const uint64_t hi2 = b7 & b6;                                          // 11xxxxxx
+    const uint64_t l3 = lut3<MSJ_TT(TA & TB & ~TC)>(hi2, b5, b4);          // 1110xxxx
+    const uint64_t f = lut3<MSJ_TT(TA & TB & TC)>(hi2, b5, b4);            // 1111xxxx
+    const uint64_t l4 = lut3<MSJ_TT(TA & ~TB)>(f, b3, b3);                 // 11110xxx
+    const uint64_t z210 = lut3<MSJ_TT(~TA & ~TB & ~TC)>(b2, b1, b0);       // xxxxx000
+    const uint64_t n101 = lut3<MSJ_TT(TA & ~TB & TC)>(b2, b1, b0);         // xxxxx101
+    const uint64_t n100 = lut3<MSJ_TT(TA & ~TB & ~TC)>(b2, b1, b0);        // xxxxx100
     Utf8Planes u;
-    u.lead234 = hi2 & ~(b5 & b4 & b3);
+    u.lead234 = lut3<MSJ_TT(TA & ~(TB & TC))>(hi2, f, b3);                 // C0..F7
     u.lead34 = l3 | l4;
     u.lead4 = l4;
-    u.isE0 = l3 & ~(b3 | b2 | b1 | b0);
-    u.isED = l3 & b3 & b2 & ~b1 & b0;
-    u.isF0 = l4 & ~(b2 | b1 | b0);
-    u.isF4 = l4 & b2 & ~(b1 | b0);
+    u.isE0 = lut3<MSJ_TT(TA & ~TB & TC)>(l3, b3, z210);
+    u.isED = lut3<MSJ_TT(TA & TB & TC)>(l3, b3, n101);
+    u.isF0 = l4 & z210;
+    u.isF4 = l4 & n100;
     return u;
 }
 
@@ -287,32 +292,68 @@ MSJ_HD uint32_t utf8_carry_out(const Utf8Planes &u) {
 // Error mask of one block given the previous block's carry word.  Planes must
 // already be masked with `valid` (bytes past the end read as 0x00 = ASCII, so a
 // sequence truncated at EOF shows up as a missing continuation).
-MSJ_HD uint64_t utf8_errors(const uint64_t p[8], const Utf8Planes &u, uint32_t carry_in) {
+// (x << K) with `low` (K bits) shifted in at the bottom: three operations on the halves
+// (bit-field extract by the caller, v_lshl_or_b32, v_alignbit_b32) instead of a 64-bit shift.
+template <int K>
+MSJ_HD uint64_t shl_in(uint64_t x, uint32_t low) {
+    const uint32_t lo = (uint32_t)x, hi = (uint32_t)(x >> 32);
+#if defined(__HIP_DEVICE_COMPILE__)
+    const uint32_t nh = __builtin_amdgcn_alignbit(hi, lo, 32 - K);
+#else
+    const uint32_t nh = (hi << K) | (lo >> (32 - K));
+#endif
+    return u64((lo << K) | low, nh);
+}
+
+// The lead planes moved to the positions of the bytes they constrain (1, 2 or 3 bytes on),
+// with the previous block's top bits shifted in at the bottom.
+struct Utf8Shifted {
+    uint64_t exp1, exp2, exp3;     // a continuation byte is expected here (lead 1 / 2 / 3 bytes back)
+    uint64_t pE0, pED, pF0, pF4;   // the byte before is E0 / ED / F0 / F4
+};
+
+MSJ_HD Utf8Shifted utf8_shift(const Utf8Planes &u, uint32_t carry_in) {
+    const uint32_t c = carry_in;
+    Utf8Shifted s;
+    s.exp1 = shl_in<1>(u.lead234, c & 1u);
+    s.exp2 = shl_in<2>(u.lead34, (c >> 1) & 3u);
+    s.exp3 = shl_in<3>(u.lead4, (c >> 3) & 7u);
+    s.pE0 = shl_in<1>(u.isE0, (c >> 6) & 1u);
+    s.pED = shl_in<1>(u.isED, (c >> 7) & 1u);
+    s.pF0 = shl_in<1>(u.isF0, (c >> 8) & 1u);
+    s.pF4 = shl_in<1>(u.isF4, (c >> 9) & 1u);
+    return s;
+}
+
+// Error mask of one block.  Planes must already be masked with `valid` (bytes past the end
+// read as 0x00 = ASCII, so a sequence truncated at EOF shows up as a missing continuation).
+MSJ_HD uint64_t utf8_errors_shifted(const uint64_t p[8], const Utf8Planes &u, const Utf8Shifted &s) {
     const uint64_t b0 = p[0], b1 = p[1], b2 = p[2], b3 = p[3];
     const uint64_t b4 = p[4], b5 = p[5], b6 = p[6], b7 = p[7];
-    const uint64_t cont = b7 & ~b6;
-    const uint64_t hi2 = b7 & b6;
-    const uint64_t l2 = hi2 & ~b5;
-    const uint64_t bad5 = hi2 & b5 & b4 & b3;  // F8..FF
-    const uint64_t c = carry_in;
-    const uint64_t exp1 = (u.lead234 << 1) | (c & 1);
-    const uint64_t exp2 = (u.lead34 << 2) | ((c >> 1) & 3);
-    const uint64_t exp3 = (u.lead4 << 3) | ((c >> 3) & 7);
-    const uint64_t expected = exp1 | exp2 | exp3;
-    const uint64_t pE0 = (u.isE0 << 1) | ((c >> 6) & 1);
-    const uint64_t pED = (u.isED << 1) | ((c >> 7) & 1);
-    const uint64_t pF0 = (u.isF0 << 1) | ((c >> 8) & 1);
-    const uint64_t pF4 = (u.isF4 << 1) | ((c >> 9) & 1);
+    const uint64_t expected = lut3<MSJ_TT(TA | TB | TC)>(s.exp1, s.exp2, s.exp3);
+    // expected ^ continuation (10xxxxxx): a missing or a stray continuation byte
+    const uint64_t cont = lut3<MSJ_TT(TA & ~TB)>(b7, b6, b6);
     uint64_t err = expected ^ cont;
-    err |= bad5;
-    err |= l2 & ~(b4 | b3 | b2 | b1);          // C0, C1
-    err |= u.lead4 & b2 & (b1 | b0);           // F5..F7
-    err |= pE0 & ~b5;                          // E0 80..9F  (overlong)
-    err |= pED & b5;                           // ED A0..BF  (surrogates)
-    err |= pF0 & ~b5 & ~b4;                    // F0 80..8F  (overlong)
-    err |= pF4 & (b5 | b4);                    // F4 90..BF  (> U+10FFFF)
-    (void)b0;
+    const uint64_t hi2 = b7 & b6;
+    // F8..FF; C0, C1 (110 0000x)
+    const uint64_t bad5 = lut3<MSJ_TT(TA & TB & TC)>(lut3<MSJ_TT(TA & TB & TC)>(hi2, b5, b4), b3, b3);
+    const uint64_t z432 = lut3<MSJ_TT(~TA & ~TB & ~TC)>(b4, b3, b2);
+    const uint64_t c0c1 = lut3<MSJ_TT(TA & ~TB & TC)>(hi2, b5, lut3<MSJ_TT(TA & ~TB)>(z432, b1, b1));
+    err = lut3<MSJ_TT(TA | TB | TC)>(err, bad5, c0c1);
+    // F5..F7 (lead4 with low bits 101, 110, 111)
+    const uint64_t f567 = lut3<MSJ_TT(TA & (TB | TC))>(b2, b1, b0);
+    err = lut3<MSJ_TT(TA | (TB & TC))>(err, u.lead4, f567);
+    err = lut3<MSJ_TT(TA | (TB & ~TC))>(err, s.pE0, b5);                    // E0 80..9F  (overlong)
+    err = lut3<MSJ_TT(TA | (TB & TC))>(err, s.pED, b5);                     // ED A0..BF  (surrogates)
+    const uint64_t f0bad = lut3<MSJ_TT(TA & ~TB & ~TC)>(s.pF0, b5, b4);     // F0 80..8F  (overlong)
+    const uint64_t f4bad = lut3<MSJ_TT(TA & (TB | TC))>(s.pF4, b5, b4);     // F4 90..BF  (> U+10FFFF)
+    err = lut3<MSJ_TT(TA | TB | TC)>(err, f0bad, f4bad);
     return err;
+}
+
+// Same, given the previous block's carry word.
+MSJ_HD uint64_t utf8_errors(const uint64_t p[8], const Utf8Planes &u, uint32_t carry_in) {
+    return utf8_errors_shifted(p, u, utf8_shift(u, carry_in));
 }
 
 // ---------------------------------------------------------------------------

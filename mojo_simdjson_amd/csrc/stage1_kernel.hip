@@ -87,6 +87,16 @@ __device__ __forceinline__ uint32_t dpp_shift_up1(uint32_t v, uint32_t first) {
     return (uint32_t)__builtin_amdgcn_update_dpp((int)first, (int)v, 0x138, 0xF, 0xF, false);  // wave_shr:1
 }
 
+// (x << K) of a 64-bit per-lane plane, with the top K bits of the PREVIOUS lane's plane shifted
+// in at the bottom (lane 0: `first_low`, K bits): the planes of a tile form one 4096-bit
+// sequence.  One DPP move and two v_alignbit_b32.
+template <int K>
+__device__ __forceinline__ uint64_t wave_shl_in(uint64_t x, uint32_t first_low) {
+    const uint32_t lo = (uint32_t)x, hi = (uint32_t)(x >> 32);
+    const uint32_t prev_hi = dpp_shift_up1(hi, first_low << (32 - K));
+    return u64(__builtin_amdgcn_alignbit(lo, prev_hi, 32 - K), __builtin_amdgcn_alignbit(hi, lo, 32 - K));
+}
+
 // A value every lane holds identically (loaded from one address): move it to an SGPR so
 // that everything derived from it is scalar code.
 __device__ __forceinline__ uint32_t uniform32(uint32_t v) {
@@ -385,10 +395,21 @@ __device__ __forceinline__ Pending compute_tile(const KernelArgs &a, const uint3
     bool u8err = false;
     if (!(a.flags & kFlagNoUtf8) && (tile_u8_in != 0u || __ballot(p[7] != 0ull) != 0ull)) {
         const Utf8Planes u8p = utf8_planes(p);
-        const uint32_t my_u8c = utf8_carry_out(u8p);
-        const uint32_t prev_u8c = dpp_shift_up1(my_u8c, tile_u8_in);
-        u8err = utf8_errors(p, u8p, prev_u8c) != 0;
-        tile_pend = (bcast(my_u8c, 63) & 0x3Fu) ? 1u : 0u;
+        // the lead planes moved onto the bytes they constrain; across lanes by DPP, into lane 0
+        // from the carry word of the window bytes (lane_math.h: utf8_carry_out layout)
+        const uint32_t c = tile_u8_in;
+        Utf8Shifted sh8;
+        sh8.exp1 = wave_shl_in<1>(u8p.lead234, c & 1u);
+        sh8.exp2 = wave_shl_in<2>(u8p.lead34, (c >> 1) & 3u);
+        sh8.exp3 = wave_shl_in<3>(u8p.lead4, (c >> 3) & 7u);
+        sh8.pE0 = wave_shl_in<1>(u8p.isE0, (c >> 6) & 1u);
+        sh8.pED = wave_shl_in<1>(u8p.isED, (c >> 7) & 1u);
+        sh8.pF0 = wave_shl_in<1>(u8p.isF0, (c >> 8) & 1u);
+        sh8.pF4 = wave_shl_in<1>(u8p.isF4, (c >> 9) & 1u);
+        u8err = utf8_errors_shifted(p, u8p, sh8) != 0;
+        // a sequence still open at the end of the tile (the last lane's top lead bits)
+        tile_pend = ((bcast((uint32_t)(u8p.lead234 >> 32), 63) >> 31) | (bcast((uint32_t)(u8p.lead34 >> 32), 63) >> 30) |
+                     (bcast((uint32_t)(u8p.lead4 >> 32), 63) >> 29)) ? 1u : 0u;
     }
     MSJ_STAMP(tile, 5);
 
