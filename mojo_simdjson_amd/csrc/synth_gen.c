@@ -320,6 +320,19 @@ uint64_t msj_gen_extreme(uint8_t *out, uint64_t n, int kind) {
             out[p++] = ']';
             return p;
         }
+        case 4: {  /* [123,123,...,7] : one scalar start + one comma per 4 bytes, d = 0.5 */
+            uint64_t p = 0;
+            out[p++] = '[';
+            while (p + 6 < n) {
+                out[p++] = '1';
+                out[p++] = '2';
+                out[p++] = '3';
+                out[p++] = ',';
+            }
+            out[p++] = '7';
+            out[p++] = ']';
+            return p;
+        }
         case 2:
             out[0] = '"';
             memset(out + 1, 'a', n - 2);

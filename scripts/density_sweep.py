@@ -1,0 +1,65 @@
+#!/usr/bin/env python3
+"""GB/s against structural density d = S/N.
+
+1 GiB streams (a 64 MiB unit repeated on the device), resident in HBM, 3 warm-up + 10 timed
+launches each (HIP events); the structural count of every run is checked against the
+oracle's count of the unit (checker only, outside the timed region).
+"""
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import helpers  # noqa: E402
+from mojo_simdjson_amd import synth  # noqa: E402
+from mojo_simdjson_amd.device import Stage1Device  # noqa: E402
+
+UNIT = 64 << 20
+CASES = [("spaces + one scalar", lambda: synth.extreme(UNIT, 3)), ("one giant string", lambda: synth.extreme(UNIT, 2)),
+         ("pretty, indent 8", lambda: synth.workload("pretty8", UNIT)), ("pretty, indent 4", lambda: synth.workload("pretty4", UNIT)),
+         ("pretty, tab + CRLF", lambda: synth.workload("pretty_tab_crlf", UNIT)),
+         ("pretty, indent 2", lambda: synth.workload("pretty2", UNIT)), ("UTF-8 heavy", lambda: synth.workload("utf8", UNIT)),
+         ("minified", lambda: synth.workload("minified", UNIT)), ("[123,123,...]", lambda: synth.extreme(UNIT, 4)),
+         ("[10,10,...]", lambda: synth.extreme(UNIT, 1)), ("[[[[...]]]]", lambda: synth.extreme(UNIT, 0))]
+
+
+def main():
+    oracle = helpers.load_oracle()
+    dev = Stage1Device(0)
+    torch.cuda.set_device(0)
+    print(f"{'workload':24s} {'bytes':>12s} {'d = S/N':>8s} {'ms':>8s} {'ingest GB/s':>12s} {'(N+4S)/t GB/s':>14s} {'frac of 8 TB/s':>14s}")
+    for name, gen in CASES:
+        u = gen()
+        code, n_unit, _ = helpers.run_oracle(oracle.msj_oracle_stage1, u.tobytes())
+        d_unit = torch.from_numpy(u).to(dev.device)
+        reps = (1 << 30) // u.size
+        d_buf = d_unit.repeat(reps)
+        n = d_buf.numel()
+        want = n_unit * reps
+        d_idx = torch.empty(want + 16, dtype=torch.int32, device=dev.device)
+        d_res = dev.new_carry()
+        for _ in range(3):
+            dev.index(d_buf, d_idx, d_res)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(10):
+            dev.index(d_buf, d_idx, d_res)
+        e1.record()
+        torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / 10
+        res = dev.fetch(d_res)
+        assert int(res.count) == want and res.internal_error == 0, (name, int(res.count), want)
+        # the reference's code for the repeated stream: only meaningful for the valid documents
+        alg = n + 4 * want
+        print(f"{name:24s} {n:12d} {want / n:8.4f} {ms:8.4f} {n / ms / 1e6:12.1f} {alg / ms / 1e6:14.1f} {alg / ms / 1e6 / 8000:14.3f}", flush=True)
+        del d_buf, d_idx
+    dev.close()
+
+
+if __name__ == "__main__":
+    main()
