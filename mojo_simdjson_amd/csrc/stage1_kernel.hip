@@ -443,6 +443,7 @@ struct Emit {
     uint64_t base;         // index of the tile's first structural in the output
     bool live;             // something to emit
     bool staged;           // fits one staging round (the common case)
+    bool fits;             // the output buffer has room for all of the tile's indices
 };
 
 // Picks the masks / counts for the tile's actual incoming state from its pending slot.
@@ -454,6 +455,7 @@ __device__ __forceinline__ Emit prepare_emit(const KernelArgs &a, Shared &sh, co
     e.tile = uniform32(sh.pend_meta[wave][slot][0]);
     e.live = e.tile != 0xFFFFFFFFu;
     e.staged = false;
+    e.fits = false;
     e.tlo = e.thi = e.vpos = e.shift = e.vend = e.cnt = 0;
     e.base = 0;
     if (!e.live) return e;
@@ -477,7 +479,8 @@ __device__ __forceinline__ Emit prepare_emit(const KernelArgs &a, Shared &sh, co
     e.shift = (uint32_t)(e.base & 3u);
     e.vend = e.shift + e.cnt;
     e.vpos = e.shift + (s_in ? (excl >> 16) : (excl & 0xFFFFu));
-    e.staged = e.vend <= kStageWords && e.base + e.cnt <= a.capacity;
+    e.fits = e.base + e.cnt <= a.capacity;
+    e.staged = e.vend <= kStageWords && e.fits;
     return e;
 }
 
@@ -509,8 +512,52 @@ __device__ __forceinline__ void copy_out(const KernelArgs &a, const Emit &e, con
     }
 }
 
-// Dense tile (more than kStageWords indices) or an index buffer that is too small (the
-// launch reports CAPACITY): general multi-round path through the whole staging slice.
+__device__ __forceinline__ void lds_wave_sync() {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// Dense tile (more than kStageWords indices, i.e. more than a quarter of its bytes are
+// structural) whose indices fit the output buffer: the same straight-line staging and 16-byte
+// copy-out, in rounds.  A round takes the lanes whose first index falls into a window of
+// kRoundSlots = kStageWords - 64 output slots (a lane has at most 64 indices, so whatever
+// starts inside the window fits the slice); lanes are ordered by position, so a round is a
+// contiguous group of lanes and its indices a contiguous piece of the output.
+constexpr uint32_t kRoundSlots = kStageWords - 64u;
+__device__ __forceinline__ void emit_rounds(const KernelArgs &a, const Emit &e, uint32_t *stage,
+                                            const uint32_t lane) {
+    const uint32_t v0 = e.tile * kTileBytes + lane * 64u;
+    uint32_t *out = a.idx + (e.base - e.shift);  // out[v] <-> slot v of the tile; 16-byte aligned
+    const uint32_t nlo = (uint32_t)__builtin_popcount(e.tlo);
+    uint32_t v_begin = e.shift;
+    for (uint32_t r0 = 0; r0 < e.vend; r0 += kRoundSlots) {  // uniform; kRoundSlots is a multiple of 4
+        const bool mine = e.vpos >= r0 && e.vpos < r0 + kRoundSlots;
+        // this round's indices end where the next round's first lane starts
+        const uint64_t later = __ballot(e.vpos >= r0 + kRoundSlots);
+        const uint32_t v_end = later ? bcast(e.vpos, (int)__builtin_ctzll(later)) : e.vend;
+        const uint32_t lds0 = (uint32_t)(uintptr_t)(stage + (e.vpos - r0));
+        scatter_bits32(mine ? e.tlo : 0u, lds0, v0);
+        scatter_bits32(mine ? e.thi : 0u, lds0 + 4u * nlo, v0 | 32u);
+        lds_wave_sync();
+        // copy out slots [v_begin, v_end): full quads in the body, partial quads element-wise
+        const uint32_t q_lo = (v_begin + 3u) >> 2, q_hi = v_end >> 2;
+        for (uint32_t q = q_lo + lane; q < q_hi; q += 64u)
+            *reinterpret_cast<uint4 *>(out + 4u * q) = *reinterpret_cast<const uint4 *>(stage + (4u * q - r0));
+        if (lane < 4u) {
+            const uint32_t vh = (v_begin & ~3u) + lane;  // head quad
+            if (vh >= v_begin && vh < 4u * q_lo && vh < v_end) out[vh] = stage[vh - r0];
+        } else if (lane < 8u) {
+            const uint32_t vt = 4u * q_hi + (lane - 4u);  // tail quad
+            if (vt < v_end && vt >= 4u * q_lo && vt >= v_begin) out[vt] = stage[vt - r0];
+        }
+        lds_wave_sync();  // the slice is reused by the next round
+        v_begin = v_end;
+    }
+}
+
+// An index buffer that is too small (the launch reports CAPACITY): element-wise, clipped.
 __device__ __forceinline__ void emit_general(const KernelArgs &a, const Emit &e, uint32_t *stage,
                                              const uint32_t lane) {
     const uint32_t v0 = e.tile * kTileBytes + lane * 64u;
@@ -555,12 +602,6 @@ __device__ __forceinline__ void emit_general(const KernelArgs &a, const Emit &e,
     }
 }
 
-__device__ __forceinline__ void lds_wave_sync() {
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-}
 
 // Range prefix for this wave: requested once per range, polled only if the resolver
 // had not published it yet.
@@ -585,6 +626,8 @@ __device__ __forceinline__ void emit_one(const KernelArgs &a, uint32_t *stage, c
         stage_indices(e, stage, lane);
         lds_wave_sync();
         copy_out(a, e, stage, lane);
+    } else if (e.fits) {
+        emit_rounds(a, e, stage, lane);
     } else {
         emit_general(a, e, stage, lane);
     }
@@ -797,6 +840,7 @@ __device__ __forceinline__ void worker_wave(const KernelArgs &a, Shared &sh, con
         Emit e0;
         e0.live = false;
         e0.staged = false;
+        e0.fits = false;
         if (have_old) e0 = prepare_emit(a, sh, wave, ring * kBatch, lane, rp_word, count0, timeout);
         if (e0.live && e0.staged) stage_indices(e0, stage, lane);  // uniform
         lds_wave_sync();
@@ -805,6 +849,8 @@ __device__ __forceinline__ void worker_wave(const KernelArgs &a, Shared &sh, con
         if (e0.live) {
             if (e0.staged)
                 copy_out(a, e0, stage, lane);
+            else if (e0.fits)
+                emit_rounds(a, e0, stage, lane);
             else
                 emit_general(a, e0, stage, lane);
         }
@@ -814,6 +860,7 @@ __device__ __forceinline__ void worker_wave(const KernelArgs &a, Shared &sh, con
         Emit e1;
         e1.live = false;
         e1.staged = false;
+        e1.fits = false;
         if (have_old) e1 = prepare_emit(a, sh, wave, ring * kBatch + 1u, lane, rp_word, count0, timeout);
         if (e1.live && e1.staged) stage_indices(e1, stage, lane);
         lds_wave_sync();
@@ -826,6 +873,8 @@ __device__ __forceinline__ void worker_wave(const KernelArgs &a, Shared &sh, con
         if (e1.live) {
             if (e1.staged)
                 copy_out(a, e1, stage, lane);
+            else if (e1.fits)
+                emit_rounds(a, e1, stage, lane);
             else
                 emit_general(a, e1, stage, lane);
         }
