@@ -157,9 +157,16 @@ def main():
     d_idx = torch.empty(cap, dtype=torch.int32, device=device)
     d_res = dev.new_carry()
 
-    if world == 1:
+    if world == 1 and shard_len <= 0xFFFFFFFF:
         def step():
             dev.index(d_shard, d_idx, d_res, flags=flags, length=shard_len)
+            return None
+    elif world == 1:
+        # longer than one uint32 segment: the shard entry point chains segments on the device
+        d_zero = dev.new_carry()
+
+        def step():
+            dev.shard(d_shard, shard_len, d_idx, d_zero, d_res, is_final=True, trailer_len=total_len, flags=flags)
             return None
     else:
         from mojo_simdjson_amd.sharded import ShardedStage1
@@ -217,6 +224,7 @@ def main():
         res = dev.fetch(d_res)
         code, total_count = int(res.code), int(res.count)
         assert res.internal_error == 0
+        assert int(res.bytes) == shard_len and total_count > 0, (int(res.bytes), shard_len, total_count)
     else:
         code, total_count, res = last
     assert code == 0, f"stage 1 returned {code}"

@@ -67,7 +67,7 @@ class Stage1Device:
         n = int(d_buf.numel() if length is None else length)
         rc = self.lib.msj_stage1_device(self.ctx, _ptr(d_buf), n, _ptr(d_idx), d_idx.numel(),
                                         _ptr(d_result), self._stream(), flags)
-        if rc < 0:
+        if rc != 0:  # nothing was enqueued (argument / launch error; 1 = longer than one uint32 segment)
             raise RuntimeError(f"msj_stage1_device failed: {rc}")
         return rc
 
@@ -83,7 +83,7 @@ class Stage1Device:
             (segments.numel() // SEGMENT_BYTES) if segments is not None else 0,
             ctypes.byref(nseg), int(has_prefix), int(is_final), int(no_emit), int(trailer_len),
             self._stream(), flags)
-        if rc < 0:
+        if rc != 0:  # nothing (or not everything) was enqueued
             raise RuntimeError(f"msj_stage1_shard_device failed: {rc}")
         return rc, nseg.value
 
