@@ -247,6 +247,31 @@ __device__ __forceinline__ void scatter_bits32(uint32_t t, uint32_t lds_byte_add
         : "vcc", "memory");
 }
 
+// Same with 16-bit slots (tile-relative offsets fit 12 bits): twice as many indices per staging
+// round, for tiles with 1021..2044 structurals.
+__device__ __forceinline__ void scatter_bits16(uint32_t t, uint32_t lds_byte_addr, uint32_t value_base) {
+    uint32_t tmp1, tmp2;
+    uint64_t save;
+    asm volatile(
+        "s_mov_b64 %[save], exec\n"
+        ".set msj_sb_off, 0\n"
+        ".rept 32\n"
+        "v_cmpx_ne_u32_e32 vcc, 0, %[t]\n"
+        "s_cbranch_execz 1f\n"
+        "v_ffbl_b32_e32 %[a], %[t]\n"
+        "v_or_b32_e32 %[a], %[a], %[vb]\n"
+        "ds_write_b16 %[addr], %[a] offset:msj_sb_off\n"
+        "v_add_u32_e32 %[b], -1, %[t]\n"
+        "v_and_b32_e32 %[t], %[b], %[t]\n"
+        ".set msj_sb_off, msj_sb_off+2\n"
+        ".endr\n"
+        "1:\n"
+        "s_mov_b64 exec, %[save]\n"
+        : [t] "+v"(t), [a] "=&v"(tmp1), [b] "=&v"(tmp2), [save] "=&s"(save)
+        : [addr] "v"(lds_byte_addr), [vb] "v"(value_base)
+        : "vcc", "memory");
+}
+
 // What a computed tile keeps in registers until its indices are emitted.
 struct Pending {
     uint64_t T0, T1;     // structural_start masks for tile s_in = 0 / 1
@@ -443,6 +468,7 @@ struct Emit {
     uint64_t base;         // index of the tile's first structural in the output
     bool live;             // something to emit
     bool staged;           // fits one staging round (the common case)
+    bool staged16;         // fits one round with 16-bit slots (1021..2044 indices)
     bool fits;             // the output buffer has room for all of the tile's indices
 };
 
@@ -455,6 +481,7 @@ __device__ __forceinline__ Emit prepare_emit(const KernelArgs &a, Shared &sh, co
     e.tile = uniform32(sh.pend_meta[wave][slot][0]);
     e.live = e.tile != 0xFFFFFFFFu;
     e.staged = false;
+    e.staged16 = false;
     e.fits = false;
     e.tlo = e.thi = e.vpos = e.shift = e.vend = e.cnt = 0;
     e.base = 0;
@@ -481,6 +508,7 @@ __device__ __forceinline__ Emit prepare_emit(const KernelArgs &a, Shared &sh, co
     e.vpos = e.shift + (s_in ? (excl >> 16) : (excl & 0xFFFFu));
     e.fits = e.base + e.cnt <= a.capacity;
     e.staged = e.vend <= kStageWords && e.fits;
+    e.staged16 = !e.staged && e.vend <= 2u * kStageWords && e.fits;
     return e;
 }
 
@@ -509,6 +537,35 @@ __device__ __forceinline__ void copy_out(const KernelArgs &a, const Emit &e, con
     } else if (lane < 8u) {
         const uint32_t vt = 4u * q_hi + (lane - 4u);
         if (vt < e.vend && vt >= 4u * q_lo) out[vt] = stage[vt];
+    }
+}
+
+// Medium-dense tile: 16-bit slots holding tile-relative offsets, widened in the copy-out.
+__device__ __forceinline__ void stage_indices16(const Emit &e, uint32_t *stage, const uint32_t lane) {
+    uint16_t *stage16 = reinterpret_cast<uint16_t *>(stage);
+    const uint32_t lds0 = (uint32_t)(uintptr_t)(stage16 + e.vpos);  // LDS byte address
+    const uint32_t nlo = (uint32_t)__builtin_popcount(e.tlo);
+    scatter_bits16(e.tlo, lds0, lane * 64u);
+    scatter_bits16(e.thi, lds0 + 2u * nlo, lane * 64u + 32u);
+}
+
+__device__ __forceinline__ void copy_out16(const KernelArgs &a, const Emit &e, const uint32_t *stage,
+                                           const uint32_t lane) {
+    const uint16_t *stage16 = reinterpret_cast<const uint16_t *>(stage);
+    uint32_t *out = a.idx + (e.base - e.shift);     // out[v] <-> stage16[v]; 16-byte aligned
+    const uint32_t tb = e.tile * kTileBytes;          // < 2^32 per launch
+    const uint32_t q_lo = (e.shift + 3u) >> 2, q_hi = e.vend >> 2;
+    for (uint32_t q = q_lo + lane; q < q_hi; q += 64u) {
+        const uint2 h = *reinterpret_cast<const uint2 *>(stage16 + 4u * q);
+        *reinterpret_cast<uint4 *>(out + 4u * q) =
+            make_uint4(tb + (h.x & 0xFFFFu), tb + (h.x >> 16), tb + (h.y & 0xFFFFu), tb + (h.y >> 16));
+    }
+    if (lane < 4u) {
+        const uint32_t vh = lane;
+        if (vh >= e.shift && vh < 4u * q_lo && vh < e.vend) out[vh] = tb + stage16[vh];
+    } else if (lane < 8u) {
+        const uint32_t vt = 4u * q_hi + (lane - 4u);
+        if (vt < e.vend && vt >= 4u * q_lo) out[vt] = tb + stage16[vt];
     }
 }
 
@@ -626,6 +683,10 @@ __device__ __forceinline__ void emit_one(const KernelArgs &a, uint32_t *stage, c
         stage_indices(e, stage, lane);
         lds_wave_sync();
         copy_out(a, e, stage, lane);
+    } else if (e.staged16) {
+        stage_indices16(e, stage, lane);
+        lds_wave_sync();
+        copy_out16(a, e, stage, lane);
     } else if (e.fits) {
         emit_rounds(a, e, stage, lane);
     } else {
@@ -840,15 +901,19 @@ __device__ __forceinline__ void worker_wave(const KernelArgs &a, Shared &sh, con
         Emit e0;
         e0.live = false;
         e0.staged = false;
+        e0.staged16 = false;
         e0.fits = false;
         if (have_old) e0 = prepare_emit(a, sh, wave, ring * kBatch, lane, rp_word, count0, timeout);
-        if (e0.live && e0.staged) stage_indices(e0, stage, lane);  // uniform
+        if (e0.live && e0.staged) stage_indices(e0, stage, lane);
+        if (e0.live && e0.staged16) stage_indices16(e0, stage, lane);  // uniform
         lds_wave_sync();
         MSJ_STAMP(first_row, 12);
         MSJ_STAMP(first_row, 13);
         if (e0.live) {
             if (e0.staged)
                 copy_out(a, e0, stage, lane);
+            else if (e0.staged16)
+                copy_out16(a, e0, stage, lane);
             else if (e0.fits)
                 emit_rounds(a, e0, stage, lane);
             else
@@ -860,9 +925,11 @@ __device__ __forceinline__ void worker_wave(const KernelArgs &a, Shared &sh, con
         Emit e1;
         e1.live = false;
         e1.staged = false;
+        e1.staged16 = false;
         e1.fits = false;
         if (have_old) e1 = prepare_emit(a, sh, wave, ring * kBatch + 1u, lane, rp_word, count0, timeout);
         if (e1.live && e1.staged) stage_indices(e1, stage, lane);
+        if (e1.live && e1.staged16) stage_indices16(e1, stage, lane);
         lds_wave_sync();
         MSJ_STAMP(first_row, 15);
         // the bytes requested above (and the first tile's stores) have had a whole staging phase
@@ -873,6 +940,8 @@ __device__ __forceinline__ void worker_wave(const KernelArgs &a, Shared &sh, con
         if (e1.live) {
             if (e1.staged)
                 copy_out(a, e1, stage, lane);
+            else if (e1.staged16)
+                copy_out16(a, e1, stage, lane);
             else if (e1.fits)
                 emit_rounds(a, e1, stage, lane);
             else

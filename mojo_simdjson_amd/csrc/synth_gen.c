@@ -333,6 +333,20 @@ uint64_t msj_gen_extreme(uint8_t *out, uint64_t n, int kind) {
             out[p++] = ']';
             return p;
         }
+        case 5: {  /* [1234,1234,...,7] : d = 0.4 (1 638 structurals per 4 KiB tile) */
+            uint64_t p = 0;
+            out[p++] = '[';
+            while (p + 7 < n) {
+                out[p++] = '1';
+                out[p++] = '2';
+                out[p++] = '3';
+                out[p++] = '4';
+                out[p++] = ',';
+            }
+            out[p++] = '7';
+            out[p++] = ']';
+            return p;
+        }
         case 2:
             out[0] = '"';
             memset(out + 1, 'a', n - 2);

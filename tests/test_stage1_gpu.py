@@ -169,9 +169,15 @@ def test_strings_spanning_tiles(oracle):
 def test_density_extremes(oracle):
     from mojo_simdjson_amd import synth
 
-    for kind in range(4):
-        d = synth.extreme(3 * TILE + 1000, kind).tobytes()
-        assert_matches_oracle(oracle, d, f"extreme kind {kind}")
+    # kinds 0/1: > 2 044 structurals per tile (staging in rounds); 4/5: 2 048 / 1 638 per tile
+    # (one round of 16-bit slots, or rounds when the alignment shift pushes it over); 2/3: none
+    for kind in range(6):
+        for n in (3 * TILE + 1000, 40 * TILE + 123):
+            d = synth.extreme(n, kind).tobytes()
+            assert_matches_oracle(oracle, d, f"extreme kind {kind} len {n}")
+    # density changing from tile to tile: every emission path next to every other one
+    parts = [synth.extreme(TILE + 7 * k, k % 6).tobytes() for k in range(24)]
+    assert_matches_oracle(oracle, b" ".join(parts), "mixed densities")
 
 
 def test_utf8_negative_variants(oracle):

@@ -33,7 +33,8 @@ def test_units_are_valid_json(name, oracle):
 
 
 def test_extremes(oracle):
-    for kind, lo, hi in ((0, 0.99, 1.01), (1, 0.6, 0.7), (2, 0.0, 0.001), (3, 0.0, 0.001)):
+    for kind, lo, hi in ((0, 0.99, 1.01), (1, 0.6, 0.7), (2, 0.0, 0.001), (3, 0.0, 0.001),
+                         (4, 0.49, 0.51), (5, 0.39, 0.41)):
         b = synth.extreme(100000, kind).tobytes()
         code, n, _ = helpers.run_oracle(oracle.msj_oracle_stage1, b)
         assert code == 0
