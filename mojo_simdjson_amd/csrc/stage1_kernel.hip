@@ -725,11 +725,15 @@ __device__ __forceinline__ void emit_one(const KernelArgs &a, uint32_t *stage, c
 // publishes a range's prefix as soon as every earlier range is in (partial progress).
 __device__ __forceinline__ void worker_wave(const KernelArgs &a, Shared &sh, const uint32_t lane,
                                             const uint32_t wave) {
-    // ticket shard of this workgroup: by arrival order, so that the workgroups that are
-    // resident always cover every shard in use (shards in use <= number of workers)
+    // Worker w = blockIdx.x - 1 starts on range w without drawing anything (no atomic on the
+    // start-up path: 1 024 workgroups hitting one word cost 13 us); later ranges come from ticket
+    // shard w % shards, whose k-th draw is range (k + first_draws) * shards + shard.  Workgroups
+    // are dispatched in index order, so the resident ones cover every shard in use.
     const uint32_t workers = gridDim.x - 1u;
+    const uint32_t wg = blockIdx.x - 1u;
     const uint32_t shards = workers < kTicketShards ? workers : kTicketShards;
-    const uint32_t shard = (uniform32(sh.role) - 1u) % shards;
+    const uint32_t shard = wg % shards;
+    const uint32_t first_draws = (workers - shard + shards - 1u) / shards;  // ranges of this shard given away up front
     unsigned int *ticket_ctr = reinterpret_cast<unsigned int *>(a.ws + (uint64_t)shard * kTicketStrideWords);
     uint32_t *stage = sh.stage[wave];
     const uint32_t tid = threadIdx.x;
@@ -737,14 +741,11 @@ __device__ __forceinline__ void worker_wave(const KernelArgs &a, Shared &sh, con
     const uint32_t nranges = (ntiles + kRange - 1u) / kRange;
     uint64_t *ragg = a.ws + kDescOffset + ntiles;
     const uint64_t *rpre = ragg + nranges;
-    if (tid == 0) {
-        sh.range_lo[0] = (atomicAdd(ticket_ctr, 1u) * shards + shard) * kRange;
-        sh.range_seq = 0;
-    }
+    if (tid == 0) sh.range_seq = 0;
     if (lane < kPendSlots) sh.pend_meta[wave][lane][0] = 0xFFFFFFFFu;  // all slots empty
     __syncthreads();
-    // LDS words every lane reads identically: uniform (tile indices and all control flow stay scalar)
-    uint32_t lo_cur = uniform32(sh.range_lo[0]);
+    MSJ_RSTAMP(a.ntiles + 4096u + blockIdx.x, 2, tid == 0);
+    uint32_t lo_cur = wg * kRange;
     const uint64_t count0 = uniform64(a.carry_in->count);  // launch invariant: read once
     uint32_t timeout = 0;
     volatile uint32_t *range_seq = &sh.range_seq;
@@ -757,6 +758,7 @@ __device__ __forceinline__ void worker_wave(const KernelArgs &a, Shared &sh, con
     }
 #pragma unroll
     for (uint32_t j = 0; j < kBatch; j++) touch_block(blk[j]);  // loop invariant: the bytes have arrived
+    MSJ_RSTAMP(a.ntiles + 4096u + blockIdx.x, 3, tid == 0);  // first bytes in registers
 
     uint32_t r = 0, ring = 0;  // ring = r % kDefer: the slots to emit from, then to park in
     while (lo_cur < ntiles) {  // uniform across the workgroup
@@ -814,8 +816,8 @@ __device__ __forceinline__ void worker_wave(const KernelArgs &a, Shared &sh, con
         MSJ_STAMP(last_row, 9);
         // wave 0 passes the next range's ticket on (drawn a compute phase ago) ...
         if (wave == 0) {
-            const uint32_t v = ticket_value(req_reg);  // the shard's k-th draw is range k * shards + shard
-            if (lane == 0) sh.range_lo[par] = (v * shards + shard) * kRange;
+            const uint32_t v = ticket_value(req_reg);
+            if (lane == 0) sh.range_lo[par] = ((v + first_draws) * shards + shard) * kRange;
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             if (lane == 0) *range_seq = r + 1u;
         }
@@ -968,6 +970,7 @@ __device__ __forceinline__ void worker_wave(const KernelArgs &a, Shared &sh, con
         ring = (ring + 1u == kDefer) ? 0u : ring + 1u;
         MSJ_STAMP(last_row, 15);
     }
+    MSJ_RSTAMP(a.ntiles + 4096u + blockIdx.x, 4, tid == 0);  // last range computed
     // ---- drain: oldest first
     for (uint32_t step = 0; step < kDefer; step++) {
         lds_wave_sync();
@@ -980,6 +983,7 @@ __device__ __forceinline__ void worker_wave(const KernelArgs &a, Shared &sh, con
         }
         ring = (ring + 1u == kDefer) ? 0u : ring + 1u;
     }
+    MSJ_RSTAMP(a.ntiles + 4096u + blockIdx.x, 5, tid == 0);  // drained
 }
 
 // ---- resolver: the four waves of one workgroup turn tile aggregates into tile
@@ -1254,12 +1258,12 @@ __device__ void resolver(const KernelArgs &a, Shared &sh) {
 __global__ __launch_bounds__(kThreads, 4) void stage1_kernel(const KernelArgs a) {
     __shared__ Shared sh;
     const uint32_t tid = threadIdx.x;
-    // The first workgroup to get here becomes the resolver (it is running, so the
-    // workers that wait on its output can always make progress); every wave of
-    // every other workgroup is an independent worker.
-    if (tid == 0) sh.role = atomicAdd(reinterpret_cast<unsigned int *>(a.ws) + 2, 1u);
-    __syncthreads();
-    if (sh.role == 0u) {
+    // Workgroup 0 is the resolver, every wave of every other workgroup a worker.  Workgroups
+    // are dispatched in index order, so the resolver is running before any worker can wait on
+    // its output (a role ticket would say the same for any order, but 1 024 atomics on one word
+    // are 13 us of start-up).
+    MSJ_RSTAMP(a.ntiles + 4096u + blockIdx.x, 0, tid == 0);  // workgroup started
+    if (blockIdx.x == 0u) {
         resolver(a, sh);
         return;
     }

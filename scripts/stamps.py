@@ -121,6 +121,19 @@ def main():
     print(f"publish time behind the running max of earlier ranges: median {np.median(order_lag) * 0.01:.2f} us  p1 {np.percentile(order_lag, 1) * 0.01:.2f} us")
     cm = np.maximum.accumulate(pub[mk])
     print(f"kernel real-time span by publishes: {(pub[mk].max() - pub[mk].min()) * 0.01:.1f} us")
+    # ---- start-up and tail per workgroup (real time)
+    wg = allraw[ntiles + 4096: ntiles + 4096 + 1100]
+    wg = wg[wg[:, 0] > 0]
+    k0 = wg[:, 0].min()
+    u = lambda x: (x - k0) * 0.01
+    workers = wg[wg[:, 3] > 0]
+    print(f"workgroups: {len(wg)} started within {u(wg[:, 0]).max():.2f} us of the first")
+    for nm, c in (("prologue done", 2), ("first bytes in registers", 3), ("last range computed", 4), ("drained", 5)):
+        col = workers[:, c]
+        col = col[col > 0]
+        if col.size == 0:
+            continue
+        print(f"  {nm:26s} median {np.median(u(col)):8.2f} us   min {u(col).min():8.2f}   max {u(col).max():8.2f}")
     lib.msj_ctx_destroy(h)
 
 
