@@ -12,7 +12,7 @@ constexpr int kThreads = kWaves * 64;
 constexpr uint32_t kTileBytes = 64u * 64u;         // 4 KiB of input per wave: 64 lanes x one 64-byte block
 // Workspace header: kTicketShards range-ticket counters, one per 4 KiB (a single word sustains
 // only ~80 returning atomics per microsecond chip-wide; shard c hands out ranges c, c + S, ...),
-// the role ticket in the second word; the descriptor arrays follow.
+// the descriptor arrays follow.
 constexpr uint32_t kTicketShards = 8;
 constexpr uint32_t kTicketStrideWords = 512;       // in 8-byte words
 constexpr uint32_t kDescOffset = kTicketShards * kTicketStrideWords;  // ws[kDescOffset..] = agg[], ragg[], rpre[]
@@ -52,7 +52,7 @@ struct KernelArgs {
     uint64_t *stamps;         // diagnostic builds only (-DMSJ_STAMPS): 16 words per tile, else null
 };
 
-// ws: [0] tile ticket, [1] role ticket, [8..] per-tile carry words, range aggregates, range prefixes
+// ws: ticket shards (header), then per-tile carry words, range aggregates, range prefixes
 inline uint64_t workspace_words(uint32_t ntiles) {
     const uint64_t nranges = (ntiles + kRange - 1u) / kRange;
     return (uint64_t)kDescOffset + ntiles + 2ull * nranges;

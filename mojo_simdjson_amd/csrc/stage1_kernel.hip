@@ -128,7 +128,6 @@ __device__ __forceinline__ uint64_t uniform64(uint64_t v) {
 #endif
 
 struct Shared {
-    uint32_t role;
     uint32_t range_lo[2];    // worker workgroups: base tile of the next range (double buffered)
     uint32_t range_seq;      // ... and the iteration it was handed over in (wave 0 -> the others)
     uint64_t tagg[2][kRange]; // worker workgroups: the range's tile aggregates, in tile order
@@ -721,7 +720,7 @@ __device__ __forceinline__ void emit_one(const KernelArgs &a, uint32_t *stage, c
 // Deadlock freedom: a wave blocks only in step 3, after its own range is published, and
 // only on the prefix of a range below every range its workgroup holds (drawn or parked).
 // The workgroup holding the smallest unpublished range therefore never waits on anything
-// that needs a later range, whatever the dispatch order or residency, and the resolver
+// that needs a later range, whatever the residency (dispatch is in index order), and the resolver
 // publishes a range's prefix as soon as every earlier range is in (partial progress).
 __device__ __forceinline__ void worker_wave(const KernelArgs &a, Shared &sh, const uint32_t lane,
                                             const uint32_t wave) {
@@ -1025,8 +1024,7 @@ __device__ void resolver(const KernelArgs &a, Shared &sh) {
     uint64_t *pre = a.ws + kDescOffset + a.ntiles + ntiles;
     const uint32_t nchunks = (ntiles + kResolveChunk - 1) / kResolveChunk;
     if (a.ws_clean && tid < kTicketShards) {
-        a.ws_clean[(uint64_t)tid * kTicketStrideWords] = 0ull;  // ticket counters (+ role ticket in word 1)
-        if (tid == 0) a.ws_clean[1] = 0ull;
+        a.ws_clean[(uint64_t)tid * kTicketStrideWords] = 0ull;  // ticket counters
     }
     if (tid == 0) {
         sh.rs_seq = 0;
