@@ -128,6 +128,7 @@ __device__ __forceinline__ uint64_t uniform64(uint64_t v) {
 #endif
 
 struct Shared {
+    uint32_t role;
     uint32_t range_lo[2];    // worker workgroups: base tile of the next range (double buffered)
     uint32_t range_seq;      // ... and the iteration it was handed over in (wave 0 -> the others)
     uint64_t tagg[2][kRange]; // worker workgroups: the range's tile aggregates, in tile order
@@ -720,19 +721,18 @@ __device__ __forceinline__ void emit_one(const KernelArgs &a, uint32_t *stage, c
 // Deadlock freedom: a wave blocks only in step 3, after its own range is published, and
 // only on the prefix of a range below every range its workgroup holds (drawn or parked).
 // The workgroup holding the smallest unpublished range therefore never waits on anything
-// that needs a later range, whatever the residency (dispatch is in index order), and the resolver
+// that needs a later range, whatever the dispatch order or residency, and the resolver
 // publishes a range's prefix as soon as every earlier range is in (partial progress).
 __device__ __forceinline__ void worker_wave(const KernelArgs &a, Shared &sh, const uint32_t lane,
                                             const uint32_t wave) {
-    // Worker w = blockIdx.x - 1 starts on range w without drawing anything (no atomic on the
-    // start-up path: 1 024 workgroups hitting one word cost 13 us); later ranges come from ticket
-    // shard w % shards, whose k-th draw is range (k + first_draws) * shards + shard.  Workgroups
-    // are dispatched in index order, so the resident ones cover every shard in use.
+    // Ticket shard of this workgroup: its arrival number mod (shards in use), so that whichever
+    // workgroups are resident cover every shard; a shard's k-th draw is range k * shards + shard.
+    // Every range is DRAWN, including the first one: handing range w to worker w up front
+    // would save an atomic at start-up, but a workgroup that is not resident yet (a GPU shared
+    // with other kernels) would then own a range everybody else waits for.
     const uint32_t workers = gridDim.x - 1u;
-    const uint32_t wg = blockIdx.x - 1u;
     const uint32_t shards = workers < kTicketShards ? workers : kTicketShards;
-    const uint32_t shard = wg % shards;
-    const uint32_t first_draws = (workers - shard + shards - 1u) / shards;  // ranges of this shard given away up front
+    const uint32_t shard = (uniform32(sh.role) - 1u) % shards;
     unsigned int *ticket_ctr = reinterpret_cast<unsigned int *>(a.ws + (uint64_t)shard * kTicketStrideWords);
     uint32_t *stage = sh.stage[wave];
     const uint32_t tid = threadIdx.x;
@@ -740,11 +740,15 @@ __device__ __forceinline__ void worker_wave(const KernelArgs &a, Shared &sh, con
     const uint32_t nranges = (ntiles + kRange - 1u) / kRange;
     uint64_t *ragg = a.ws + kDescOffset + ntiles;
     const uint64_t *rpre = ragg + nranges;
-    if (tid == 0) sh.range_seq = 0;
+    if (tid == 0) {
+        sh.range_lo[0] = (atomicAdd(ticket_ctr, 1u) * shards + shard) * kRange;
+        sh.range_seq = 0;
+    }
     if (lane < kPendSlots) sh.pend_meta[wave][lane][0] = 0xFFFFFFFFu;  // all slots empty
     __syncthreads();
     MSJ_RSTAMP(a.ntiles + 4096u + blockIdx.x, 2, tid == 0);
-    uint32_t lo_cur = wg * kRange;
+    // LDS words every lane reads identically: uniform (tile indices and all control flow stay scalar)
+    uint32_t lo_cur = uniform32(sh.range_lo[0]);
     const uint64_t count0 = uniform64(a.carry_in->count);  // launch invariant: read once
     uint32_t timeout = 0;
     volatile uint32_t *range_seq = &sh.range_seq;
@@ -816,7 +820,7 @@ __device__ __forceinline__ void worker_wave(const KernelArgs &a, Shared &sh, con
         // wave 0 passes the next range's ticket on (drawn a compute phase ago) ...
         if (wave == 0) {
             const uint32_t v = ticket_value(req_reg);
-            if (lane == 0) sh.range_lo[par] = ((v + first_draws) * shards + shard) * kRange;
+            if (lane == 0) sh.range_lo[par] = (v * shards + shard) * kRange;
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             if (lane == 0) *range_seq = r + 1u;
         }
@@ -1025,6 +1029,7 @@ __device__ void resolver(const KernelArgs &a, Shared &sh) {
     const uint32_t nchunks = (ntiles + kResolveChunk - 1) / kResolveChunk;
     if (a.ws_clean && tid < kTicketShards) {
         a.ws_clean[(uint64_t)tid * kTicketStrideWords] = 0ull;  // ticket counters
+        if (tid == 0) a.ws_clean[1] = 0ull;                       // role ticket
     }
     if (tid == 0) {
         sh.rs_seq = 0;
@@ -1256,12 +1261,16 @@ __device__ void resolver(const KernelArgs &a, Shared &sh) {
 __global__ __launch_bounds__(kThreads, 4) void stage1_kernel(const KernelArgs a) {
     __shared__ Shared sh;
     const uint32_t tid = threadIdx.x;
-    // Workgroup 0 is the resolver, every wave of every other workgroup a worker.  Workgroups
-    // are dispatched in index order, so the resolver is running before any worker can wait on
-    // its output (a role ticket would say the same for any order, but 1 024 atomics on one word
-    // are 13 us of start-up).
+    // The first workgroup to get here becomes the resolver (it is running, so the workers that
+    // wait on its output can always make progress); every wave of every other workgroup is a
+    // worker.  Arrival order, not blockIdx: with other kernels on the GPU, block 0 is not
+    // necessarily resident first (measured: four processes sharing one GPU time out with a
+    // static resolver), and a shard chosen by blockIdx can be left without a resident worker.
+    // The price is 1 024 atomics on one word at start-up (6 us median, 13 us for the last).
     MSJ_RSTAMP(a.ntiles + 4096u + blockIdx.x, 0, tid == 0);  // workgroup started
-    if (blockIdx.x == 0u) {
+    if (tid == 0) sh.role = atomicAdd(reinterpret_cast<unsigned int *>(a.ws) + 2, 1u);
+    __syncthreads();
+    if (sh.role == 0u) {
         resolver(a, sh);
         return;
     }

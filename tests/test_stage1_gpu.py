@@ -542,3 +542,45 @@ def test_sharded_rccl_plumbing_single_rank(oracle):
     assert all(r == (code, n) for r in res), res
     want = np.concatenate([idx[:n], np.array([len(data), len(data), 0], dtype=np.uint32)]).astype(np.uint32)
     assert got == want.tobytes()
+
+
+def _shared_gpu_worker(k, barrier, q):
+    """One of several processes hammering the same GPU at once: every kernel then has only part
+    of its persistent workgroups resident, which is what the deadlock-freedom argument is about."""
+    import torch
+
+    from mojo_simdjson_amd import synth
+    from mojo_simdjson_amd.device import Stage1Device
+
+    dev = Stage1Device(0)
+    u = synth.workload(("minified", "utf8", "pretty4")[k % 3], 32 << 20)
+    d_buf = torch.from_numpy(u).to(dev.device).repeat(8)  # 256 MiB
+    d_idx = torch.empty(d_buf.numel() // 2, dtype=torch.int32, device=dev.device)
+    d_res = dev.new_carry()
+    barrier.wait()
+    out = []
+    for _ in range(8):
+        dev.index(d_buf, d_idx, d_res)
+        r = dev.fetch(d_res)
+        out.append((int(r.code), int(r.count), int(r.internal_error)))
+    q.put((k, u.tobytes(), out))
+    dev.close()
+
+
+def test_processes_sharing_one_gpu(oracle):
+    import multiprocessing as mp
+
+    ctx = mp.get_context("spawn")
+    n = 4
+    q, barrier = ctx.Queue(), ctx.Barrier(n)
+    procs = [ctx.Process(target=_shared_gpu_worker, args=(k, barrier, q)) for k in range(n)]
+    for p in procs:
+        p.start()
+    got = [q.get(timeout=300) for _ in range(n)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for k, unit, out in got:
+        code, cnt, _ = helpers.run_oracle(oracle.msj_oracle_stage1, unit)
+        assert code == 0
+        assert all(o == (0, 8 * cnt, 0) for o in out), (k, out, cnt)
