@@ -584,3 +584,15 @@ def test_processes_sharing_one_gpu(oracle):
         code, cnt, _ = helpers.run_oracle(oracle.msj_oracle_stage1, unit)
         assert code == 0
         assert all(o == (0, 8 * cnt, 0) for o in out), (k, out, cnt)
+
+
+def test_random_byte_soups():
+    """A short run of scripts/stress.py (randomised byte soups against the oracle, indices compared
+    even when the reference returns an error code); the script runs for minutes by hand."""
+    import subprocess
+    import sys
+
+    out = subprocess.run([sys.executable, os.path.join(helpers.ROOT, "scripts", "stress.py"), "12", "7"],
+                         capture_output=True, text=True, timeout=240)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    assert "stress ok" in out.stdout
