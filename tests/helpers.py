@@ -29,6 +29,21 @@ def load_oracle():
     return lib
 
 
+FAST_SO = os.path.join(ROOT, "oracle", "libmsj_oracle_fast.so")
+
+
+def load_oracle_fast():
+    """The optimised CPU variants (oracle/stage1_fast.c): measurement infrastructure, not the reference."""
+    if not os.path.exists(FAST_SO):
+        subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle")])
+    lib = ctypes.CDLL(FAST_SO)
+    lib.msj_fast_stage1.restype = ctypes.c_int32
+    lib.msj_fast_stage1.argtypes = _ARGS
+    lib.msj_fast_stage1_mt.restype = ctypes.c_int32
+    lib.msj_fast_stage1_mt.argtypes = _ARGS + [ctypes.c_int32]
+    return lib
+
+
 SENTINEL = 0xDEADBEEF
 
 
