@@ -13,8 +13,7 @@ import torch
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-sys.path.insert(0, os.path.join(ROOT, "tests"))
-import helpers  # noqa: E402
+from tests import helpers  # noqa: E402
 from mojo_simdjson_amd import synth  # noqa: E402
 from mojo_simdjson_amd.device import Stage1Device  # noqa: E402
 

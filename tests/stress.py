@@ -5,7 +5,7 @@ Byte soups over an alphabet chosen to hit every carry (quotes, long backslash ru
 operators, control characters, multi-byte UTF-8 incl. invalid sequences) at sizes from a few
 bytes to tens of MiB, with density changing along the stream; every index, the count, the
 trailer, the return code and the strict UTF-8 verdict are compared with the oracle.
-usage: scripts/stress.py [seconds] [seed]
+usage: tests/stress.py [seconds] [seed]
 """
 import os
 import sys
@@ -15,8 +15,7 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-sys.path.insert(0, os.path.join(ROOT, "tests"))
-import helpers  # noqa: E402
+from tests import helpers  # noqa: E402
 from mojo_simdjson_amd.dom_parser_implementation import DomParserImplementation  # noqa: E402
 
 ALPHABETS = [

@@ -587,12 +587,12 @@ def test_processes_sharing_one_gpu(oracle):
 
 
 def test_random_byte_soups():
-    """A short run of scripts/stress.py (randomised byte soups against the oracle, indices compared
+    """A short run of tests/stress.py (randomised byte soups against the oracle, indices compared
     even when the reference returns an error code); the script runs for minutes by hand."""
     import subprocess
     import sys
 
-    out = subprocess.run([sys.executable, os.path.join(helpers.ROOT, "scripts", "stress.py"), "12", "7"],
+    out = subprocess.run([sys.executable, os.path.join(helpers.ROOT, "tests", "stress.py"), "12", "7"],
                          capture_output=True, text=True, timeout=240)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
     assert "stress ok" in out.stdout
