@@ -278,8 +278,6 @@ struct Pending {
     uint32_t excl;       // packed exclusive wave scan of the per-lane counts
     uint32_t tile_cnt;   // packed tile totals
     uint32_t tile;
-    uint32_t in_cnt;     // structurals of the range before this tile: range state 0 | state 1 << 16
-    uint32_t in_s;       // tile's incoming in-string state: bit 0 for range state 0, bit 1 for state 1
 };
 
 // ---- one tile: masks, carries, counts; publishes the tile aggregate ------------
@@ -675,24 +673,32 @@ __device__ __forceinline__ uint64_t range_prefix(const uint64_t *rpre, uint32_t 
     return word;
 }
 
-// One parked tile, start to end (the drain; the steady-state loop interleaves the same steps
-// with the hand-over of the next range).
-__device__ __forceinline__ void emit_one(const KernelArgs &a, uint32_t *stage, const Emit &e, const uint32_t lane) {
+// The two halves of one parked tile's emission: LDS-only staging (the one-round cases), then
+// everything that stores to global memory (copy-out, or the multi-round / clipped paths).
+__device__ __forceinline__ void stage_tile(const Emit &e, uint32_t *stage, const uint32_t lane) {
     if (!e.live) return;  // uniform
-    if (e.staged) {
+    if (e.staged)
         stage_indices(e, stage, lane);
-        lds_wave_sync();
-        copy_out(a, e, stage, lane);
-    } else if (e.staged16) {
+    else if (e.staged16)
         stage_indices16(e, stage, lane);
-        lds_wave_sync();
+}
+__device__ __forceinline__ void store_tile(const KernelArgs &a, const Emit &e, uint32_t *stage, const uint32_t lane) {
+    if (!e.live) return;  // uniform
+    if (e.staged)
+        copy_out(a, e, stage, lane);
+    else if (e.staged16)
         copy_out16(a, e, stage, lane);
-    } else if (e.fits) {
+    else if (e.fits)
         emit_rounds(a, e, stage, lane);
-    } else {
+    else
         emit_general(a, e, stage, lane);
-    }
-    lds_wave_sync();  // the staging slice is reused by the next tile
+}
+__device__ __forceinline__ Emit no_emit() {
+    Emit e;
+    e.live = e.staged = e.staged16 = e.fits = false;
+    e.tlo = e.thi = e.vpos = e.shift = e.vend = e.cnt = e.tile = 0;
+    e.base = 0;
+    return e;
 }
 
 // ---- worker: one wave, persistent ---------------------------------------------------
@@ -903,38 +909,17 @@ __device__ __forceinline__ void worker_wave(const KernelArgs &a, Shared &sh, con
             MSJ_RSTAMP(old_range * kRange, 9, tid == 0);  // its prefix is in hand (real time)
         }
         MSJ_STAMP(last_row, 12);
-        Emit e0;
-        e0.live = false;
-        e0.staged = false;
-        e0.staged16 = false;
-        e0.fits = false;
-        if (have_old) e0 = prepare_emit(a, sh, wave, ring * kBatch, lane, rp_word, count0, timeout);
-        if (e0.live && e0.staged) stage_indices(e0, stage, lane);
-        if (e0.live && e0.staged16) stage_indices16(e0, stage, lane);  // uniform
+        static_assert(kBatch == 2, "the emission below is written for two tiles per wave and range");
+        const Emit e0 = have_old ? prepare_emit(a, sh, wave, ring * kBatch, lane, rp_word, count0, timeout) : no_emit();
+        stage_tile(e0, stage, lane);
         lds_wave_sync();
         MSJ_STAMP(first_row, 12);
         MSJ_STAMP(first_row, 13);
-        if (e0.live) {
-            if (e0.staged)
-                copy_out(a, e0, stage, lane);
-            else if (e0.staged16)
-                copy_out16(a, e0, stage, lane);
-            else if (e0.fits)
-                emit_rounds(a, e0, stage, lane);
-            else
-                emit_general(a, e0, stage, lane);
-        }
+        store_tile(a, e0, stage, lane);
         lds_wave_sync();  // the staging slice is reused by the next tile
         MSJ_STAMP(first_row, 14);
-        static_assert(kBatch == 2, "the emission below is written for two tiles per wave and range");
-        Emit e1;
-        e1.live = false;
-        e1.staged = false;
-        e1.staged16 = false;
-        e1.fits = false;
-        if (have_old) e1 = prepare_emit(a, sh, wave, ring * kBatch + 1u, lane, rp_word, count0, timeout);
-        if (e1.live && e1.staged) stage_indices(e1, stage, lane);
-        if (e1.live && e1.staged16) stage_indices16(e1, stage, lane);
+        const Emit e1 = have_old ? prepare_emit(a, sh, wave, ring * kBatch + 1u, lane, rp_word, count0, timeout) : no_emit();
+        stage_tile(e1, stage, lane);
         lds_wave_sync();
         MSJ_STAMP(first_row, 15);
         // the bytes requested above (and the first tile's stores) have had a whole staging phase
@@ -942,16 +927,7 @@ __device__ __forceinline__ void worker_wave(const KernelArgs &a, Shared &sh, con
 #pragma unroll
         for (uint32_t j = 0; j < kBatch; j++) touch_block(blk[j]);
         MSJ_STAMP(last_row, 13);
-        if (e1.live) {
-            if (e1.staged)
-                copy_out(a, e1, stage, lane);
-            else if (e1.staged16)
-                copy_out16(a, e1, stage, lane);
-            else if (e1.fits)
-                emit_rounds(a, e1, stage, lane);
-            else
-                emit_general(a, e1, stage, lane);
-        }
+        store_tile(a, e1, stage, lane);
         lds_wave_sync();
         MSJ_STAMP(last_row, 14);
         // ---- 4. park this iteration's tiles
@@ -981,8 +957,13 @@ __device__ __forceinline__ void worker_wave(const KernelArgs &a, Shared &sh, con
         if (old_first != 0xFFFFFFFFu) {
             const uint64_t w = uniform64(range_prefix(rpre, old_first / kRange, 0ull, timeout));
 #pragma unroll
-            for (uint32_t j = 0; j < kBatch; j++)
-                emit_one(a, stage, prepare_emit(a, sh, wave, ring * kBatch + j, lane, w, count0, timeout), lane);
+            for (uint32_t j = 0; j < kBatch; j++) {
+                const Emit e = prepare_emit(a, sh, wave, ring * kBatch + j, lane, w, count0, timeout);
+                stage_tile(e, stage, lane);
+                lds_wave_sync();
+                store_tile(a, e, stage, lane);
+                lds_wave_sync();  // the staging slice is reused by the next tile
+            }
         }
         ring = (ring + 1u == kDefer) ? 0u : ring + 1u;
     }
