@@ -596,3 +596,24 @@ def test_random_byte_soups():
                          capture_output=True, text=True, timeout=240)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
     assert "stress ok" in out.stdout
+
+
+def test_host_pointer_large_inputs(oracle):
+    """The host-pointer entry point on inputs of 50-64 MiB: same bits as the oracle, also for the
+    error codes and the reference's capacity quirk."""
+    from mojo_simdjson_amd import synth
+
+    base = synth.workload("minified", 52 << 20).tobytes()
+    assert len(base) > 48 << 20
+    assert_matches_oracle(oracle, base, "52 MiB minified")
+    u8 = synth.workload("utf8", 49 << 20).tobytes()
+    assert_matches_oracle(oracle, u8 + b" " * ((64 << 20) + 5 - len(u8)), "utf8 padded to 64 MiB + 5 bytes")
+    # error codes decided far apart
+    bad = bytearray(base)
+    bad[20 << 20] = 0x01 if base[(20 << 20) - 1:(20 << 20)] else 0x01
+    assert_matches_oracle(oracle, bytes(bad), "control character 20 MiB in")
+    assert_matches_oracle(oracle, base + b'"abc', "string left open at the very end")
+    assert_matches_oracle(oracle, b'"' + base, "everything flipped by a quote in front")
+    # the reference's capacity quirk: all structural, n + 3 > len
+    dense = b"[" * (50 << 20)
+    assert_matches_oracle(oracle, dense, "50 MiB of brackets")
