@@ -50,11 +50,22 @@ def build_stream_shard(d_unit, unit_len, start, length, device):
     return torch.cat(parts)
 
 
-def cpu_baseline(unit, budget_s=10.0):
-    """Reference-faithful CPU port (oracle/stage1_oracle.c, 1 thread) on a bounded sample."""
+def cpu_baseline(unit, budget_s=10.0, timed=True):
+    """Reference-faithful CPU port (oracle/stage1_oracle.c, 1 thread) on a bounded sample.
+
+    The only place bench.py touches oracle/: the timed baseline, and the expected structural count
+    of the unit that the GPU result is checked against (timed=False: only that count)."""
     import ctypes
 
     from tests import helpers
+
+    if not timed:
+        f = helpers.load_oracle_fast()
+        data = unit.tobytes()
+        idx = np.zeros(len(data) + 3, dtype=np.uint32)
+        nn = ctypes.c_uint64(0)
+        rc = f.msj_fast_stage1(data, len(data), idx.ctypes.data, idx.size, ctypes.byref(nn))
+        return None, (int(nn.value) if rc == 0 else None)
 
     o = helpers.load_oracle()
     o.msj_oracle_stage1_repeat.restype = ctypes.c_int32
@@ -194,8 +205,9 @@ def main():
     # ---- expected result (rank 0 computes the unit's count with the oracle: checker only)
     cpu = None
     unit_n = None
-    if rank == 0 and not args.no_cpu_baseline:
-        cpu, unit_n = cpu_baseline(unit)
+    if rank == 0:
+        # timed CPU baseline at N = 1 only; otherwise just the expected count (checker)
+        cpu, unit_n = cpu_baseline(unit, timed=(world == 1 and not args.no_cpu_baseline))
 
     cap = int(shard_len * 0.75) + 1024  # index slots for this shard (density < 0.75 for every workload here)
     d_idx = torch.empty(cap, dtype=torch.int32, device=device)
