@@ -175,6 +175,34 @@ int32_t msj_stage1_shard_device(msj_ctx *ctx, const uint8_t *d_buf, uint64_t len
                                 int32_t has_prefix, int32_t is_final, int32_t no_emit,
                                 uint64_t trailer_len, void *stream, uint32_t flags);
 
+/*
+ * ---- token stream for stage 2 (DERIVED, see below) -------------
+ * msj_tokens_device -- from the structural indices of one segment, two coalesced arrays:
+ *   d_type[i]  = buf[idx[i]]: the byte JsonIterator.advance / peek / last_structural dereference
+ *                one structural at a time (generic/stage2/json_iterator.mojo:256-288);
+ *   d_depth[i] = nesting depth of token i, the running count walk_document keeps by hand
+ *                (+1 at '{' '[', -1 at '}' ']', json_iterator.mojo:84-90,173-180): a bracket
+ *                carries the depth of the container it sits in, so an opening bracket and its
+ *                closing bracket have the same value and everything between them is deeper.
+ * d_result: n, the final / minimum / maximum running depth (after each token): final != 0 is an
+ * unclosed document, minimum < 0 a closing bracket without an opening one, maximum is what the
+ * reference compares with max_depth (DEPTH_ERROR).
+ * These are derived quantities: the reference has no such arrays and no fixture for them, so
+ * the CPU statement the tests compare with is a definition, not a pin.
+ * d_buf / d_idx as produced by msj_stage1_device (offsets < len < 2^32, n < 2^31); d_idx and
+ * d_depth 16-byte aligned, d_type 8-byte aligned.  Asynchronous on `stream`.
+ */
+typedef struct msj_tokens_result {
+    uint64_t n;
+    int32_t final_depth;
+    int32_t min_depth;
+    int32_t max_depth;
+    uint32_t reserved;
+} msj_tokens_result;
+
+int32_t msj_tokens_device(msj_ctx *ctx, const uint8_t *d_buf, uint64_t len, const uint32_t *d_idx, uint64_t n,
+                          uint8_t *d_type, int32_t *d_depth, msj_tokens_result *d_result, void *stream);
+
 /* Tile geometry (for roofline bookkeeping and tests). */
 uint32_t msj_tile_bytes(void);
 

@@ -30,6 +30,13 @@ class MsjCarry(ctypes.Structure):
     ]
 
 
+class MsjTokensResult(ctypes.Structure):
+    """``msj_tokens_result`` (include/msj_stage1.h)."""
+
+    _fields_ = [("n", ctypes.c_uint64), ("final_depth", ctypes.c_int32), ("min_depth", ctypes.c_int32),
+                ("max_depth", ctypes.c_int32), ("reserved", ctypes.c_uint32)]
+
+
 class MsjSegment(ctypes.Structure):
     _fields_ = [
         ("byte_base", ctypes.c_uint64),
@@ -104,6 +111,9 @@ def load():
         ctypes.c_void_p, u8p, ctypes.c_uint64, u32p, ctypes.c_uint64, ctypes.c_void_p,
         ctypes.c_void_p, ctypes.c_uint32,
     ]
+    lib.msj_tokens_device.restype = ctypes.c_int32
+    lib.msj_tokens_device.argtypes = [ctypes.c_void_p, u8p, ctypes.c_uint64, u32p, ctypes.c_uint64,
+                                      ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
     lib.msj_carry_fetch.restype = ctypes.c_int32
     lib.msj_carry_fetch.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.POINTER(MsjCarry), ctypes.c_void_p]
     lib.msj_stage1_shard_device.restype = ctypes.c_int32

@@ -33,6 +33,8 @@ struct msj_ctx {
     uint64_t d_idx_words = 0;
     msj_carry *d_result = nullptr;
     uint32_t grid = 0;            // persistent workgroups per launch (CUs x resident blocks per CU)
+    int32_t *tok_ws = nullptr;    // block aggregates of the token pre-pass
+    uint64_t tok_ws_bytes = 0;
 };
 
 namespace {
@@ -190,6 +192,7 @@ void msj_ctx_destroy(msj_ctx *ctx) {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
     if (ctx->ws) (void)hipFree(ctx->ws);
+    if (ctx->tok_ws) (void)hipFree(ctx->tok_ws);
     if (ctx->carries) (void)hipFree(ctx->carries);
     if (ctx->d_in) (void)hipFree(ctx->d_in);
     if (ctx->d_idx) (void)hipFree(ctx->d_idx);
@@ -218,6 +221,34 @@ int32_t msj_stage1_shard_device(msj_ctx *ctx, const uint8_t *d_buf, uint64_t len
     return enqueue_shard(ctx, d_buf, len, d_idx, idx_capacity, d_carry_in, d_carry_out, d_segments,
                          max_segments, n_segments_out, has_prefix != 0, is_final != 0, no_emit != 0,
                          trailer_len, static_cast<hipStream_t>(stream), flags);
+}
+
+extern "C" uint64_t msj_tokens_workspace_bytes(uint64_t n);
+extern "C" int msj_launch_tokens(const uint8_t *d_buf, const uint32_t *d_idx, uint64_t n, uint8_t *d_type, int32_t *d_depth,
+                                 msj_tokens_result *d_result, int32_t *d_ws, void *stream);
+
+int32_t msj_tokens_device(msj_ctx *ctx, const uint8_t *d_buf, uint64_t len, const uint32_t *d_idx, uint64_t n,
+                          uint8_t *d_type, int32_t *d_depth, msj_tokens_result *d_result, void *stream) {
+    if (!ctx || !d_result) return MSJ_ERR_BAD_ARGUMENT;
+    if (n > 0 && (!d_buf || !d_idx || !d_type || !d_depth)) return MSJ_ERR_BAD_ARGUMENT;
+    if (len > MSJ_MAX_SEGMENT_BYTES || n >= (1ull << 31)) return MSJ_CAPACITY;
+    if ((reinterpret_cast<uintptr_t>(d_idx) & 15u) || (reinterpret_cast<uintptr_t>(d_depth) & 15u) ||
+        (reinterpret_cast<uintptr_t>(d_type) & 7u))
+        return MSJ_ERR_BAD_ARGUMENT;
+    if (!hip_ok(hipSetDevice(ctx->device))) return MSJ_ERR_HIP;
+    const uint64_t need = msj_tokens_workspace_bytes(n);
+    if (need > ctx->tok_ws_bytes) {
+        if (ctx->tok_ws) {
+            (void)hipDeviceSynchronize();
+            (void)hipFree(ctx->tok_ws);
+        }
+        ctx->tok_ws = nullptr;
+        ctx->tok_ws_bytes = 0;
+        if (!hip_ok(hipMalloc(reinterpret_cast<void **>(&ctx->tok_ws), need + need / 4))) return MSJ_MEMALLOC;
+        ctx->tok_ws_bytes = need + need / 4;
+    }
+    return msj_launch_tokens(d_buf, d_idx, n, d_type, d_depth, d_result, ctx->tok_ws, stream) == 0 ? MSJ_SUCCESS
+                                                                                                 : MSJ_ERR_HIP;
 }
 
 int32_t msj_carry_fetch(msj_ctx *ctx, const msj_carry *d_carry, msj_carry *host_out, void *stream) {

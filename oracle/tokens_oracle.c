@@ -1,0 +1,47 @@
+/*
+ * tokens_oracle.c -- CPU definition of the token-stream pre-pass.
+ * TEST INFRASTRUCTURE ONLY, like everything under oracle/.
+ *
+ * PARITY UNPINNED: the reference has no array of type bytes or depths and no fixture for them.
+ * What it has is the code that recomputes both one structural at a time:
+ *   type[i]  = buf[structural_indexes[i]]  -- JsonIterator.peek / advance / last_structural
+ *              (src/mojo_simdjson/generic/stage2/json_iterator.mojo:256-288);
+ *   depth    -- walk_document's running counter, +1 when a container is entered and -1 at
+ *              scope_end (json_iterator.mojo:84-90,173-180).
+ * This file states the quantity the HIP kernels (csrc/tokens_kernel.hip) compute: the plain
+ * bracket nesting depth of every token (the reference skips the counter for empty containers and
+ * stops at the first grammar error; a pre-pass cannot know either, stage 2 still does those
+ * checks).  A bracket has the depth of the container it sits in.
+ */
+#include <stdint.h>
+
+typedef struct {
+    uint64_t n;
+    int32_t final_depth, min_depth, max_depth;
+    uint32_t reserved;
+} msj_tokens_result;
+
+void msj_oracle_tokens(const uint8_t *buf, const uint32_t *idx, uint64_t n, uint8_t *type, int32_t *depth,
+                       msj_tokens_result *res) {
+    int32_t d = 0, mn = 0, mx = 0;
+    for (uint64_t i = 0; i < n; i++) {
+        const uint8_t c = buf[idx[i]];
+        type[i] = c;
+        if (c == '{' || c == '[') {
+            depth[i] = d;
+            d += 1;
+        } else if (c == '}' || c == ']') {
+            d -= 1;
+            depth[i] = d;
+        } else {
+            depth[i] = d;
+        }
+        if (i == 0 || d < mn) mn = d;
+        if (i == 0 || d > mx) mx = d;
+    }
+    res->n = n;
+    res->final_depth = d;
+    res->min_depth = mn;
+    res->max_depth = mx;
+    res->reserved = 0;
+}

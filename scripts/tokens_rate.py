@@ -1,0 +1,38 @@
+#!/usr/bin/env python3
+"""Rate of the token pre-pass (row f1) on the 1 GiB workloads: type byte + nesting depth per structural."""
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from mojo_simdjson_amd import synth  # noqa: E402
+from mojo_simdjson_amd.device import Stage1Device  # noqa: E402
+
+dev = Stage1Device(0)
+torch.cuda.set_device(0)
+for name in ("minified", "utf8", "pretty4"):
+    u = synth.workload(name, 64 << 20)
+    d_buf = torch.from_numpy(u).to(dev.device).repeat((1 << 30) // u.size)
+    nbytes = d_buf.numel()
+    d_idx = torch.empty(int(nbytes * 0.3), dtype=torch.int32, device=dev.device)
+    d_res = dev.new_carry()
+    dev.index(d_buf, d_idx, d_res)
+    n = int(dev.fetch(d_res).count)
+    d_type = torch.empty(n, dtype=torch.uint8, device=dev.device)
+    d_depth = torch.empty(n, dtype=torch.int32, device=dev.device)
+    for _ in range(3):
+        dev.tokens(d_buf, nbytes, d_idx, n, d_type, d_depth)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize()
+    e0.record()
+    for _ in range(10):
+        t, d, res = dev.tokens(d_buf, nbytes, d_idx, n, d_type, d_depth)
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / 10
+    alg = 10 * n  # 4 B index + 1 gathered byte + 1 B type out, then 1 B type in... counted once: 4+1+1+4
+    print(f"{name:9s}: {n} structurals, {ms:.3f} ms, {n / ms / 1e6:.1f} G structurals/s, "
+          f"{alg / ms / 1e6:.0f} GB/s of 10 B/structural ({alg / ms / 1e6 / 8000:.3f} of 8 TB/s), "
+          f"max depth {res.max_depth}, final {res.final_depth}; as input rate {nbytes / ms / 1e6:.0f} GB/s of JSON")
+dev.close()

@@ -44,6 +44,25 @@ def load_oracle_fast():
     return lib
 
 
+TOKENS_SO = os.path.join(ROOT, "oracle", "libmsj_oracle_tokens.so")
+
+
+def oracle_tokens(data, idx):
+    """Definition of the token pre-pass (oracle/tokens_oracle.c): (type uint8[n], depth int32[n], (final, min, max))."""
+    if not os.path.exists(TOKENS_SO):
+        subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle")])
+    lib = ctypes.CDLL(TOKENS_SO)
+    idx = np.ascontiguousarray(idx, dtype=np.uint32)
+    n = idx.size
+    typ = np.zeros(max(n, 1), dtype=np.uint8)
+    dep = np.zeros(max(n, 1), dtype=np.int32)
+    res = (ctypes.c_uint8 * 24)()
+    lib.msj_oracle_tokens(ctypes.c_char_p(bytes(data)), idx.ctypes.data_as(ctypes.c_void_p), ctypes.c_uint64(n),
+                          typ.ctypes.data_as(ctypes.c_void_p), dep.ctypes.data_as(ctypes.c_void_p), res)
+    r = np.frombuffer(bytes(res), dtype=np.int32)
+    return typ[:n], dep[:n], (int(r[2]), int(r[3]), int(r[4]))
+
+
 SENTINEL = 0xDEADBEEF
 
 

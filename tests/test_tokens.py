@@ -1,0 +1,115 @@
+"""Token-stream pre-pass: type byte and nesting depth per structural.
+
+Derived quantities (the reference has no such arrays, oracle/tokens_oracle.c is their definition);
+the CPU part checks that definition by hand, the GPU part the HIP kernels against it."""
+import numpy as np
+import pytest
+
+from tests import helpers
+
+
+def _stage1(oracle, data):
+    code, n, idx = helpers.run_oracle(oracle.msj_oracle_stage1, data)
+    assert n is not None
+    return idx[:n]
+
+
+def test_definition_by_hand():
+    oracle = helpers.load_oracle()
+    doc = b'{"a":[1,{"b":[]}],"c":{}}'
+    idx = _stage1(oracle, doc)
+    typ, dep, (final, mn, mx) = helpers.oracle_tokens(doc, idx)
+    assert bytes(typ) == b'{":[1,{":[]}],":{}}'
+    #                    {  "  :  [  1  ,  {  "  :  [  ]  }  ]  ,  "  :  {  }  }
+    assert list(dep) == [0, 1, 1, 1, 2, 2, 2, 3, 3, 3, 3, 2, 1, 1, 1, 1, 1, 1, 0]
+    assert (final, mn, mx) == (0, 0, 4)
+    typ, dep, (final, mn, mx) = helpers.oracle_tokens(b"]]1[", np.array([0, 1, 2, 3], dtype=np.uint32))
+    assert list(dep) == [-1, -2, -2, -2] and (final, mn, mx) == (-1, -2, -1)
+    typ, dep, res = helpers.oracle_tokens(b"", np.zeros(0, dtype=np.uint32))
+    assert typ.size == 0 and res == (0, 0, 0)
+
+
+@pytest.fixture(scope="module")
+def dev():
+    import torch
+
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from mojo_simdjson_amd.device import Stage1Device
+
+    d = Stage1Device(0)
+    yield d
+    d.close()
+
+
+def _gpu_tokens(dev, data):
+    import torch
+
+    d_buf = torch.from_numpy(np.frombuffer(data, dtype=np.uint8).copy()).to(dev.device)
+    d_idx = torch.empty(len(data) + 3 + 4, dtype=torch.int32, device=dev.device)
+    d_res = dev.new_carry()
+    dev.index(d_buf, d_idx, d_res)
+    r = dev.fetch(d_res)
+    n = int(r.count)
+    t, d, res = dev.tokens(d_buf, len(data), d_idx, n)
+    return d_idx[:n].cpu().numpy().view(np.uint32), t.cpu().numpy(), d.cpu().numpy(), res
+
+
+def _check(dev, data, where):
+    idx, t, d, res = _gpu_tokens(dev, data)
+    wt, wd, (final, mn, mx) = helpers.oracle_tokens(data, idx)
+    assert np.array_equal(t, wt), where
+    if not np.array_equal(d, wd):
+        bad = int(np.argmax(d != wd))
+        raise AssertionError(f"{where}: depth[{bad}] = {d[bad]} != {wd[bad]}")
+    assert (res.n, res.final_depth, res.min_depth, res.max_depth) == (len(idx), final, mn, mx), where
+
+
+@pytest.mark.gpu
+def test_tokens_fixtures_and_shapes(dev):
+    for f in helpers.golden_valid_files():
+        js, _ = helpers.read_fixture(f)
+        _check(dev, js, f)
+    rng = np.random.default_rng(5)
+    alphabet = np.frombuffer(b'{}[]{}[],: "a1', dtype=np.uint8)
+    for n in (1, 2, 7, 8, 9, 2047, 2048, 2049, 4096 * 3 + 5, 100000, 1 << 20):
+        soup = alphabet[rng.integers(0, len(alphabet), n)].tobytes().replace(b'"', b"x")  # no strings: every bracket counts
+        _check(dev, soup, f"bracket soup {n}")
+    _check(dev, b"[" * 300000 + b"]" * 299999, "deep")
+    _check(dev, b"]" * 5000 + b"[" * 7, "underflow")
+    _check(dev, b" ", "no structurals")
+
+
+@pytest.mark.gpu
+def test_tokens_workloads(dev):
+    from mojo_simdjson_amd import synth
+
+    for name in ("minified", "utf8", "pretty4"):
+        _check(dev, synth.workload(name, 8 << 20).tobytes(), name)
+
+
+@pytest.mark.gpu
+def test_tokens_1gib_replicated(dev):
+    """1 GiB: every unit is a complete document, so the depth pattern repeats unit by unit."""
+    import torch
+
+    from mojo_simdjson_amd import synth
+
+    u = synth.workload("minified", 64 << 20)
+    oracle = helpers.load_oracle()
+    idx_u = _stage1(oracle, u.tobytes())
+    wt, wd, (final, mn, mx) = helpers.oracle_tokens(u.tobytes(), idx_u)
+    assert final == 0 and mn == 0
+    reps = 16
+    d_buf = torch.from_numpy(u).to(dev.device).repeat(reps)
+    d_idx = torch.empty(len(idx_u) * reps + 16, dtype=torch.int32, device=dev.device)
+    d_res = dev.new_carry()
+    dev.index(d_buf, d_idx, d_res)
+    n = int(dev.fetch(d_res).count)
+    assert n == len(idx_u) * reps
+    t, d, res = dev.tokens(d_buf, d_buf.numel(), d_idx, n)
+    assert (res.n, res.final_depth, res.min_depth, res.max_depth) == (n, 0, 0, mx)
+    wt_d = torch.from_numpy(wt).to(dev.device)
+    wd_d = torch.from_numpy(wd).to(dev.device)
+    assert torch.equal(t.view(reps, -1), wt_d.expand(reps, -1))
+    assert torch.equal(d.view(reps, -1), wd_d.expand(reps, -1))
