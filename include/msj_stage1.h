@@ -184,6 +184,10 @@ int32_t msj_stage1_shard_device(msj_ctx *ctx, const uint8_t *d_buf, uint64_t len
  *                (+1 at '{' '[', -1 at '}' ']', json_iterator.mojo:84-90,173-180): a bracket
  *                carries the depth of the container it sits in, so an opening bracket and its
  *                closing bracket have the same value and everything between them is deeper.
+ *   d_match[i] (optional, may be NULL) = for a bracket, the index of the other end of its
+ *                container -- what start_container / end_container keep on a stack
+ *                (generic/stage2/tape_builder.mojo:235-272); 0xFFFFFFFF for every other token and
+ *                for a bracket without a partner.
  * d_result: n, the final / minimum / maximum running depth (after each token): final != 0 is an
  * unclosed document, minimum < 0 a closing bracket without an opening one, maximum is what the
  * reference compares with max_depth (DEPTH_ERROR).
@@ -197,11 +201,12 @@ typedef struct msj_tokens_result {
     int32_t final_depth;
     int32_t min_depth;
     int32_t max_depth;
-    uint32_t reserved;
+    uint32_t reserved; /* number of opening brackets */
 } msj_tokens_result;
 
 int32_t msj_tokens_device(msj_ctx *ctx, const uint8_t *d_buf, uint64_t len, const uint32_t *d_idx, uint64_t n,
-                          uint8_t *d_type, int32_t *d_depth, msj_tokens_result *d_result, void *stream);
+                          uint8_t *d_type, int32_t *d_depth, uint32_t *d_match, msj_tokens_result *d_result,
+                          void *stream);
 
 /* Tile geometry (for roofline bookkeeping and tests). */
 uint32_t msj_tile_bytes(void);

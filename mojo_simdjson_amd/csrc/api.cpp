@@ -223,12 +223,13 @@ int32_t msj_stage1_shard_device(msj_ctx *ctx, const uint8_t *d_buf, uint64_t len
                          trailer_len, static_cast<hipStream_t>(stream), flags);
 }
 
-extern "C" uint64_t msj_tokens_workspace_bytes(uint64_t n);
+extern "C" uint64_t msj_tokens_workspace_bytes(uint64_t n, int with_match);
 extern "C" int msj_launch_tokens(const uint8_t *d_buf, const uint32_t *d_idx, uint64_t n, uint8_t *d_type, int32_t *d_depth,
-                                 msj_tokens_result *d_result, int32_t *d_ws, void *stream);
+                                 uint32_t *d_match, msj_tokens_result *d_result, int32_t *d_ws, void *stream);
 
 int32_t msj_tokens_device(msj_ctx *ctx, const uint8_t *d_buf, uint64_t len, const uint32_t *d_idx, uint64_t n,
-                          uint8_t *d_type, int32_t *d_depth, msj_tokens_result *d_result, void *stream) {
+                          uint8_t *d_type, int32_t *d_depth, uint32_t *d_match, msj_tokens_result *d_result,
+                          void *stream) {
     if (!ctx || !d_result) return MSJ_ERR_BAD_ARGUMENT;
     if (n > 0 && (!d_buf || !d_idx || !d_type || !d_depth)) return MSJ_ERR_BAD_ARGUMENT;
     if (len > MSJ_MAX_SEGMENT_BYTES || n >= (1ull << 31)) return MSJ_CAPACITY;
@@ -236,7 +237,7 @@ int32_t msj_tokens_device(msj_ctx *ctx, const uint8_t *d_buf, uint64_t len, cons
         (reinterpret_cast<uintptr_t>(d_type) & 7u))
         return MSJ_ERR_BAD_ARGUMENT;
     if (!hip_ok(hipSetDevice(ctx->device))) return MSJ_ERR_HIP;
-    const uint64_t need = msj_tokens_workspace_bytes(n);
+    const uint64_t need = msj_tokens_workspace_bytes(n, d_match != nullptr);
     if (need > ctx->tok_ws_bytes) {
         if (ctx->tok_ws) {
             (void)hipDeviceSynchronize();
@@ -247,7 +248,7 @@ int32_t msj_tokens_device(msj_ctx *ctx, const uint8_t *d_buf, uint64_t len, cons
         if (!hip_ok(hipMalloc(reinterpret_cast<void **>(&ctx->tok_ws), need + need / 4))) return MSJ_MEMALLOC;
         ctx->tok_ws_bytes = need + need / 4;
     }
-    return msj_launch_tokens(d_buf, d_idx, n, d_type, d_depth, d_result, ctx->tok_ws, stream) == 0 ? MSJ_SUCCESS
+    return msj_launch_tokens(d_buf, d_idx, n, d_type, d_depth, d_match, d_result, ctx->tok_ws, stream) == 0 ? MSJ_SUCCESS
                                                                                                  : MSJ_ERR_HIP;
 }
 

@@ -55,6 +55,7 @@ __device__ __forceinline__ Agg shfl_up(const Agg &a, int off) {
 __global__ __launch_bounds__(kThreads) void gather_reduce(const uint8_t *__restrict__ buf, const uint32_t *__restrict__ idx,
                                                           uint64_t n, uint8_t *__restrict__ type, int32_t *__restrict__ block_agg) {
     __shared__ Agg wave_agg[kThreads / 64];
+    __shared__ int wave_opens[kThreads / 64];
     const uint64_t base = (uint64_t)blockIdx.x * kBlock + (uint64_t)threadIdx.x * kPer;
     uint32_t off[kPer];
     if (base + kPer <= n) {  // 32 bytes of indices per thread, two 16-byte loads
@@ -78,11 +79,13 @@ __global__ __launch_bounds__(kThreads) void gather_reduce(const uint8_t *__restr
             if (base + k < n) type[base + k] = (uint8_t)c[k];
     }
     Agg a = {0, kNone, -kNone};
-    int run = 0;
+    int run = 0, opens = 0;
 #pragma unroll
     for (int k = 0; k < kPer; k++) {
         if (base + k < n) {
-            run += delta_of(c[k]);
+            const int dk = delta_of(c[k]);
+            opens += dk > 0;
+            run += dk;
             a.mn = min(a.mn, run);
             a.mx = max(a.mx, run);
         }
@@ -95,15 +98,25 @@ __global__ __launch_bounds__(kThreads) void gather_reduce(const uint8_t *__restr
         const Agg p = shfl_up(a, o);
         if (lane >= o) a = combine(p, a);
     }
-    if (lane == 63) wave_agg[threadIdx.x >> 6] = a;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) opens += __shfl_xor(opens, o);  // opening brackets in the wave
+    if (lane == 63) {
+        wave_agg[threadIdx.x >> 6] = a;
+        wave_opens[threadIdx.x >> 6] = opens;
+    }
     __syncthreads();
     if (threadIdx.x == 0) {
         Agg t = wave_agg[0];
+        int no = wave_opens[0];
 #pragma unroll
-        for (int w = 1; w < kThreads / 64; w++) t = combine(t, wave_agg[w]);
-        block_agg[3 * (uint64_t)blockIdx.x + 0] = t.sum;
-        block_agg[3 * (uint64_t)blockIdx.x + 1] = t.mn;
-        block_agg[3 * (uint64_t)blockIdx.x + 2] = t.mx;
+        for (int w = 1; w < kThreads / 64; w++) {
+            t = combine(t, wave_agg[w]);
+            no += wave_opens[w];
+        }
+        block_agg[4 * (uint64_t)blockIdx.x + 0] = t.sum;
+        block_agg[4 * (uint64_t)blockIdx.x + 1] = t.mn;
+        block_agg[4 * (uint64_t)blockIdx.x + 2] = t.mx;
+        block_agg[4 * (uint64_t)blockIdx.x + 3] = no;
     }
 }
 
@@ -111,42 +124,76 @@ __global__ __launch_bounds__(kThreads) void gather_reduce(const uint8_t *__restr
 //     thread folds kScanPer consecutive block aggregates serially (so a pass covers 8 192 blocks).
 constexpr int kScanPer = 8;
 __global__ __launch_bounds__(1024) void scan_blocks(const int32_t *__restrict__ block_agg, uint32_t nblocks, int32_t *__restrict__ block_start,
-                                                    msj_tokens_result *__restrict__ result, uint64_t n) {
+                                                    uint32_t *__restrict__ open_start, msj_tokens_result *__restrict__ result, uint64_t n) {
     __shared__ Agg wave_agg[16];
+    __shared__ uint32_t wave_opens[16];
     __shared__ Agg carry;
-    if (threadIdx.x == 0) carry = Agg{0, kNone, -kNone};
+    __shared__ uint32_t carry_opens;
+    if (threadIdx.x == 0) {
+        carry = Agg{0, kNone, -kNone};
+        carry_opens = 0;
+    }
     __syncthreads();
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     for (uint32_t b0 = 0; b0 < nblocks; b0 += 1024 * kScanPer) {
         const uint32_t first = b0 + threadIdx.x * kScanPer;
         Agg own[kScanPer];
+        uint32_t own_opens[kScanPer];
         Agg a = {0, kNone, -kNone};
+        uint32_t no = 0;
 #pragma unroll
         for (int k = 0; k < kScanPer; k++) {
             const uint32_t b = first + k;
             own[k] = Agg{0, kNone, -kNone};
-            if (b < nblocks) own[k] = Agg{block_agg[3 * (uint64_t)b], block_agg[3 * (uint64_t)b + 1], block_agg[3 * (uint64_t)b + 2]};
+            own_opens[k] = 0;
+            if (b < nblocks) {
+                const int4 q = *reinterpret_cast<const int4 *>(block_agg + 4 * (uint64_t)b);
+                own[k] = Agg{q.x, q.y, q.z};
+                own_opens[k] = (uint32_t)q.w;
+            }
             a = combine(a, own[k]);
+            no += own_opens[k];
         }
         const Agg mine = a;
+        const uint32_t mine_opens = no;
 #pragma unroll
         for (int o = 1; o < 64; o <<= 1) {
             const Agg p = shfl_up(a, o);
-            if (lane >= o) a = combine(p, a);
+            const uint32_t po = __shfl_up(no, o);
+            if (lane >= o) {
+                a = combine(p, a);
+                no += po;
+            }
         }
-        if (lane == 63) wave_agg[wave] = a;
+        if (lane == 63) {
+            wave_agg[wave] = a;
+            wave_opens[wave] = no;
+        }
         __syncthreads();
         Agg before = carry;  // everything in front of this wave
-        for (int w = 0; w < wave; w++) before = combine(before, wave_agg[w]);
+        uint32_t before_opens = carry_opens;
+        for (int w = 0; w < wave; w++) {
+            before = combine(before, wave_agg[w]);
+            before_opens += wave_opens[w];
+        }
         const Agg incl = combine(before, a);
+        const uint32_t incl_opens = before_opens + no;
         int32_t run = incl.sum - mine.sum;  // depth at this thread's first block
+        uint32_t ro = incl_opens - mine_opens;
 #pragma unroll
         for (int k = 0; k < kScanPer; k++) {
-            if (first + k < nblocks) block_start[first + k] = run;
+            if (first + k < nblocks) {
+                block_start[first + k] = run;
+                open_start[first + k] = ro;
+            }
             run += own[k].sum;
+            ro += own_opens[k];
         }
         __syncthreads();
-        if (threadIdx.x == 1023) carry = incl;  // the last thread's inclusive value covers the whole pass
+        if (threadIdx.x == 1023) {  // the last thread's inclusive values cover the whole pass
+            carry = incl;
+            carry_opens = incl_opens;
+        }
         __syncthreads();
     }
     if (threadIdx.x == 0) {
@@ -154,14 +201,18 @@ __global__ __launch_bounds__(1024) void scan_blocks(const int32_t *__restrict__ 
         result->final_depth = carry.sum;
         result->min_depth = n ? carry.mn : 0;
         result->max_depth = n ? carry.mx : 0;
-        result->reserved = 0;
+        result->reserved = carry_opens;  // number of opening brackets (the matching pass runs over exactly these)
     }
 }
 
 // (3) depth of every token
 __global__ __launch_bounds__(kThreads) void apply_depth(const uint8_t *__restrict__ type, uint64_t n,
-                                                        const int32_t *__restrict__ block_start, int32_t *__restrict__ depth) {
+                                                        const int32_t *__restrict__ block_start, int32_t *__restrict__ depth,
+                                                        int32_t *__restrict__ min8, int32_t *__restrict__ min64,
+                                                        int32_t *__restrict__ min512, const uint32_t *__restrict__ open_start,
+                                                        uint32_t *__restrict__ opens) {
     __shared__ int wave_sum[kThreads / 64];
+    __shared__ int wave_no[kThreads / 64];
     const uint64_t base = (uint64_t)blockIdx.x * kBlock + (uint64_t)threadIdx.x * kPer;
     uint32_t c[kPer];
     if (base + kPer <= n) {
@@ -175,24 +226,38 @@ __global__ __launch_bounds__(kThreads) void apply_depth(const uint8_t *__restric
 #pragma unroll
         for (int k = 0; k < kPer; k++) c[k] = (base + k < n) ? type[base + k] : (uint32_t)' ';
     }
-    int d[kPer], run = 0;
+    int d[kPer], run = 0, no = 0;
 #pragma unroll
     for (int k = 0; k < kPer; k++) {
         d[k] = delta_of(c[k]);
         run += d[k];
+        no += d[k] > 0;
     }
-    // exclusive prefix of the thread sums inside the block
+    // exclusive prefix of the thread sums (depth deltas, opening brackets) inside the block
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    int incl = run;
+    int incl = run, incl_no = no;
 #pragma unroll
     for (int o = 1; o < 64; o <<= 1) {
-        const int p = __shfl_up(incl, o);
-        if (lane >= o) incl += p;
+        const int p = __shfl_up(incl, o), q = __shfl_up(incl_no, o);
+        if (lane >= o) {
+            incl += p;
+            incl_no += q;
+        }
     }
-    if (lane == 63) wave_sum[wave] = incl;
+    if (lane == 63) {
+        wave_sum[wave] = incl;
+        wave_no[wave] = incl_no;
+    }
     __syncthreads();
     int before = block_start[blockIdx.x] + incl - run;
     for (int w = 0; w < wave; w++) before += wave_sum[w];
+    if (opens) {  // the token indices of all opening brackets, in order (work list of match_brackets)
+        uint32_t slot = open_start[blockIdx.x] + (uint32_t)(incl_no - no);
+        for (int w = 0; w < wave; w++) slot += (uint32_t)wave_no[w];
+#pragma unroll
+        for (int k = 0; k < kPer; k++)
+            if (d[k] > 0) opens[slot++] = (uint32_t)(base + k);
+    }
     int out[kPer];
 #pragma unroll
     for (int k = 0; k < kPer; k++) {
@@ -207,26 +272,179 @@ __global__ __launch_bounds__(kThreads) void apply_depth(const uint8_t *__restric
         for (int k = 0; k < kPer; k++)
             if (base + k < n) depth[base + k] = out[k];
     }
+    if (min8) {  // the three lowest levels of the 8-ary min tree used for bracket matching
+        int m = kNone;
+#pragma unroll
+        for (int k = 0; k < kPer; k++)
+            if (base + k < n) m = min(m, out[k]);
+        if (base < n) min8[base >> 3] = m;                      // 8 tokens = this thread
+        m = min(m, __shfl_xor(m, 1));
+        m = min(m, __shfl_xor(m, 2));
+        m = min(m, __shfl_xor(m, 4));
+        if ((threadIdx.x & 7) == 0 && base < n) min64[base >> 6] = m;    // 64 tokens = 8 threads
+        m = min(m, __shfl_xor(m, 8));
+        m = min(m, __shfl_xor(m, 16));
+        m = min(m, __shfl_xor(m, 32));
+        if ((threadIdx.x & 63) == 0 && base < n) min512[base >> 9] = m;  // 512 tokens = this wave
+    }
+}
+
+// ---- bracket matching: match[i] = index of the other end of the container a bracket opens or
+// closes (what start_container / end_container keep on a stack, generic/stage2/tape_builder.mojo:
+// 235-272), 0xFFFFFFFF for every other token and for brackets without a partner.
+// The partner of an opening bracket at token i (depth d) is the first j > i with depth[j] <= d:
+// everything inside the container is deeper.  An 8-ary min tree over depth[] answers that in
+// O(8 * levels) with levels ~ log8(container size): scan to the end of the group, climb while
+// nothing qualifies, descend into the first node whose minimum does.
+constexpr int kFanShift = 3;
+constexpr uint32_t kFanMask = (1u << kFanShift) - 1u;
+constexpr int kMaxLevels = 12;  // 8^11 > 2^32
+struct MinTree {
+    const int32_t *lv[kMaxLevels];  // lv[0] = depth, lv[k][g] = min of lv[k-1][8g .. 8g+7]
+    uint32_t cnt[kMaxLevels];
+    int nlev;
+};
+
+// level k from level k-1 (the levels above the three that apply_depth writes are tiny)
+__global__ __launch_bounds__(256) void build_level(const int32_t *__restrict__ in, uint32_t n_in, int32_t *__restrict__ out, uint32_t n_out) {
+    const uint32_t o = blockIdx.x * 256u + threadIdx.x;
+    if (o >= n_out) return;
+    int m = kNone;
+    for (uint32_t k = 0; k <= kFanMask; k++) {
+        const uint32_t i = (o << kFanShift) + k;
+        if (i < n_in) m = min(m, in[i]);
+    }
+    out[o] = m;
+}
+
+// the 8 entries of group g at one level (levels >= 1 are padded to a multiple of 8 with kNone;
+// level 0 is the caller's depth array and is read with a guard at its end)
+__device__ __forceinline__ void load_group(const MinTree &t, int lev, uint32_t g, int v[8]) {
+    const int32_t *p = t.lv[lev] + ((uint64_t)g << kFanShift);
+    if (lev > 0 || ((uint64_t)g << kFanShift) + 8u <= t.cnt[0]) {
+        const int4 a = *reinterpret_cast<const int4 *>(p);
+        const int4 b = *reinterpret_cast<const int4 *>(p + 4);
+        v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w;
+        v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+    } else {
+#pragma unroll
+        for (int k = 0; k < 8; k++) v[k] = (((uint64_t)g << kFanShift) + k < t.cnt[0]) ? p[k] : kNone;
+    }
+}
+// first k >= from with v[k] <= target, 8 if none
+__device__ __forceinline__ uint32_t first_le(const int v[8], uint32_t from, int target) {
+    uint32_t m = 0;
+#pragma unroll
+    for (int k = 0; k < 8; k++) m |= (uint32_t)(v[k] <= target) << k;
+    m &= 0xFFu << from;
+    return m ? (uint32_t)__builtin_ctz(m) : 8u;
+}
+
+// one thread per OPENING bracket (a dense work list: with one thread per token only a few lanes of
+// a wave would walk the tree, each through a chain of dependent loads)
+__global__ __launch_bounds__(256) void match_brackets(const uint8_t *__restrict__ type, const uint32_t *__restrict__ opens,
+                                                      const msj_tokens_result *__restrict__ result, const MinTree t,
+                                                      uint32_t *__restrict__ match) {
+    const uint64_t w = (uint64_t)blockIdx.x * 256u + threadIdx.x;
+    if (w >= result->reserved) return;
+    const uint32_t i = opens[w];
+    const int target = t.lv[0][i];
+    uint32_t pos = i + 1u;
+    int lev = 0;
+    int v[8];
+    bool found = false;
+    for (;;) {  // climb: one aligned 32-byte read per level
+        const uint32_t g = pos >> kFanShift;
+        if (((uint64_t)g << kFanShift) >= t.cnt[lev]) break;
+        load_group(t, lev, g, v);
+        const uint32_t k = first_le(v, pos & kFanMask, target);
+        if (k < 8u) {
+            pos = (g << kFanShift) + k;
+            found = true;
+            break;
+        }
+        if (lev + 1 == t.nlev) break;
+        pos = g + 1u;  // the rest of this group holds nothing: next node one level up
+        lev++;
+    }
+    if (!found) return;
+    while (lev > 0) {  // descend: the first child that qualifies
+        lev--;
+        load_group(t, lev, pos, v);
+        pos = (pos << kFanShift) + first_le(v, 0u, target);
+    }
+    const uint32_t cj = type[pos];
+    if (cj == '}' || cj == ']') {
+        match[i] = pos;
+        match[pos] = i;
+    }
 }
 
 }  // namespace msj_tokens
 
-// workspace: 3 int32 per block (aggregates) + 1 int32 per block (start depth)
-extern "C" uint64_t msj_tokens_workspace_bytes(uint64_t n) {
+// workspace: 4 int32 per block (aggregates) + start depth + start slot in the list of opening
+// brackets per block, then (matching only) the min tree and that list (one uint32 per token at most)
+static uint64_t tree_words(uint64_t n) {  // every level padded to a multiple of 8 entries
+    uint64_t w = 0, c = n;
+    while (c > 8) {
+        c = (c + 7) / 8;
+        w += (c + 7) & ~7ull;
+    }
+    return w;
+}
+static uint64_t head_words(uint64_t n) {
     const uint64_t nb = (n + msj_tokens::kBlock - 1) / msj_tokens::kBlock;
-    return (nb ? nb : 1) * 4 * sizeof(int32_t);
+    return (6 * (nb ? nb : 1) + 7u) & ~7ull;
+}
+extern "C" uint64_t msj_tokens_workspace_bytes(uint64_t n, int with_match) {
+    return (head_words(n) + (with_match ? tree_words(n) + 64 + n : 0)) * sizeof(int32_t);
 }
 
 extern "C" int msj_launch_tokens(const uint8_t *d_buf, const uint32_t *d_idx, uint64_t n, uint8_t *d_type, int32_t *d_depth,
-                                 msj_tokens_result *d_result, int32_t *d_ws, void *stream) {
+                                 uint32_t *d_match, msj_tokens_result *d_result, int32_t *d_ws, void *stream) {
     using namespace msj_tokens;
     hipStream_t s = static_cast<hipStream_t>(stream);
     const uint64_t nb64 = (n + kBlock - 1) / kBlock;
     if (nb64 > 0x7FFFFFFFull) return (int)hipErrorInvalidValue;
     const uint32_t nb = (uint32_t)nb64;
-    int32_t *agg = d_ws, *start = d_ws + 3 * (uint64_t)(nb ? nb : 1);
+    const uint64_t nbs = nb ? nb : 1;
+    int32_t *agg = d_ws, *start = d_ws + 4 * nbs;
+    uint32_t *open_start = reinterpret_cast<uint32_t *>(d_ws + 5 * nbs);
+    int32_t *tree = d_ws + head_words(n);  // 32-byte aligned inside the workspace
+    const bool want_match = d_match != nullptr && n > 0;
+    uint32_t *opens = want_match ? reinterpret_cast<uint32_t *>(tree + tree_words(n) + 64) : nullptr;
     if (nb) hipLaunchKernelGGL(gather_reduce, dim3(nb), dim3(kThreads), 0, s, d_buf, d_idx, n, d_type, agg);
-    hipLaunchKernelGGL(scan_blocks, dim3(1), dim3(1024), 0, s, agg, nb, start, d_result, n);
-    if (nb) hipLaunchKernelGGL(apply_depth, dim3(nb), dim3(kThreads), 0, s, d_type, n, start, d_depth);
+    hipLaunchKernelGGL(scan_blocks, dim3(1), dim3(1024), 0, s, agg, nb, start, open_start, d_result, n);
+    // levels of the min tree: 1..3 come out of apply_depth, the rest from build_level
+    MinTree t;
+    t.lv[0] = d_depth;
+    t.cnt[0] = (uint32_t)n;
+    t.nlev = 1;
+    int32_t *lvl[kMaxLevels] = {nullptr};
+    if (want_match) {
+        int32_t *p = tree;
+        while (t.cnt[t.nlev - 1] > 8 && t.nlev < kMaxLevels) {
+            const uint32_t c_out = (t.cnt[t.nlev - 1] + 7u) / 8u;
+            lvl[t.nlev] = p;
+            t.lv[t.nlev] = p;
+            t.cnt[t.nlev] = c_out;
+            p += (c_out + 7u) & ~7u;
+            t.nlev++;
+        }
+    }
+    // apply_depth writes levels 1..3 unconditionally when asked to: give it scratch for the ones a short input lacks
+    int32_t *l1 = want_match ? (t.nlev > 1 ? lvl[1] : tree) : nullptr;
+    int32_t *l2 = want_match ? (t.nlev > 2 ? lvl[2] : tree + tree_words(n) + 8) : nullptr;
+    int32_t *l3 = want_match ? (t.nlev > 3 ? lvl[3] : tree + tree_words(n) + 40) : nullptr;
+    if (want_match)  // padding entries of the tree levels must never qualify: 0x7F7F7F7F
+        (void)hipMemsetAsync(tree, 0x7F, (tree_words(n) + 64) * sizeof(int32_t), s);
+    if (nb) hipLaunchKernelGGL(apply_depth, dim3(nb), dim3(kThreads), 0, s, d_type, n, start, d_depth, l1, l2, l3, open_start, opens);
+    if (want_match) {
+        for (int k = 4; k < t.nlev; k++)
+            hipLaunchKernelGGL(build_level, dim3((t.cnt[k] + 255u) / 256u), dim3(256), 0, s, t.lv[k - 1], t.cnt[k - 1], lvl[k], t.cnt[k]);
+        // closing brackets without a partner keep this value
+        (void)hipMemsetAsync(d_match, 0xFF, n * sizeof(uint32_t), s);
+        hipLaunchKernelGGL(match_brackets, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, s, d_type, opens, d_result, t, d_match);
+    }
     return (int)hipGetLastError();
 }

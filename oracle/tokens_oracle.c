@@ -14,6 +14,7 @@
  * checks).  A bracket has the depth of the container it sits in.
  */
 #include <stdint.h>
+#include <stdlib.h>
 
 typedef struct {
     uint64_t n;
@@ -44,4 +45,27 @@ void msj_oracle_tokens(const uint8_t *buf, const uint32_t *idx, uint64_t n, uint
     res->min_depth = mn;
     res->max_depth = mx;
     res->reserved = 0;
+}
+
+/* match[i]: for a bracket, the index of the other end of its container -- the stack start_container /
+ * end_container keep (generic/stage2/tape_builder.mojo:235-272); 0xFFFFFFFF for every other token and
+ * for a bracket without a partner (a closing bracket on an empty stack, an opening one never closed).
+ * Like the depth, bracket KINDS are not compared here (stage 2's state machine does that). */
+int msj_oracle_match(const uint8_t *type, uint64_t n, uint32_t *match) {
+    uint32_t *stack = (uint32_t *)malloc((size_t)(n ? n : 1) * sizeof(uint32_t));
+    if (!stack) return -1;
+    uint64_t top = 0;
+    for (uint64_t i = 0; i < n; i++) {
+        const uint8_t c = type[i];
+        match[i] = 0xFFFFFFFFu;
+        if (c == '{' || c == '[') {
+            stack[top++] = (uint32_t)i;
+        } else if ((c == '}' || c == ']') && top > 0) {
+            const uint32_t o = stack[--top];
+            match[i] = o;
+            match[o] = (uint32_t)i;
+        }
+    }
+    free(stack);
+    return 0;
 }

@@ -21,6 +21,7 @@ for name in ("minified", "utf8", "pretty4"):
     n = int(dev.fetch(d_res).count)
     d_type = torch.empty(n, dtype=torch.uint8, device=dev.device)
     d_depth = torch.empty(n, dtype=torch.int32, device=dev.device)
+    d_match = torch.empty(n, dtype=torch.int32, device=dev.device)
     for _ in range(3):
         dev.tokens(d_buf, nbytes, d_idx, n, d_type, d_depth)
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -35,4 +36,13 @@ for name in ("minified", "utf8", "pretty4"):
     print(f"{name:9s}: {n} structurals, {ms:.3f} ms, {n / ms / 1e6:.1f} G structurals/s, "
           f"{alg / ms / 1e6:.0f} GB/s of 10 B/structural ({alg / ms / 1e6 / 8000:.3f} of 8 TB/s), "
           f"max depth {res.max_depth}, final {res.final_depth}; as input rate {nbytes / ms / 1e6:.0f} GB/s of JSON")
+    dev.tokens(d_buf, nbytes, d_idx, n, d_type, d_depth, d_match)
+    torch.cuda.synchronize()
+    e0.record()
+    for _ in range(10):
+        dev.tokens(d_buf, nbytes, d_idx, n, d_type, d_depth, d_match)
+    e1.record()
+    torch.cuda.synchronize()
+    ms2 = e0.elapsed_time(e1) / 10
+    print(f"           with bracket matching: {ms2:.3f} ms ({n / ms2 / 1e6:.1f} G structurals/s)")
 dev.close()

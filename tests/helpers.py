@@ -63,6 +63,16 @@ def oracle_tokens(data, idx):
     return typ[:n], dep[:n], (int(r[2]), int(r[3]), int(r[4]))
 
 
+def oracle_match(typ):
+    """Partner index of every bracket (oracle/tokens_oracle.c: msj_oracle_match), uint32, 0xFFFFFFFF = none."""
+    lib = ctypes.CDLL(TOKENS_SO)
+    typ = np.ascontiguousarray(typ, dtype=np.uint8)
+    m = np.zeros(max(typ.size, 1), dtype=np.uint32)
+    assert lib.msj_oracle_match(typ.ctypes.data_as(ctypes.c_void_p), ctypes.c_uint64(typ.size),
+                                m.ctypes.data_as(ctypes.c_void_p)) == 0
+    return m[:typ.size]
+
+
 SENTINEL = 0xDEADBEEF
 
 

@@ -27,6 +27,10 @@ def test_definition_by_hand():
     assert list(dep) == [-1, -2, -2, -2] and (final, mn, mx) == (-1, -2, -1)
     typ, dep, res = helpers.oracle_tokens(b"", np.zeros(0, dtype=np.uint32))
     assert typ.size == 0 and res == (0, 0, 0)
+    N = 0xFFFFFFFF
+    assert list(helpers.oracle_match(np.frombuffer(b'{":[1,{":[]}],":{}}', dtype=np.uint8))) == \
+        [18, N, N, 12, N, N, 11, N, N, 10, 9, 6, 3, N, N, N, 17, 16, 0]
+    assert list(helpers.oracle_match(np.frombuffer(b"][]][", dtype=np.uint8))) == [N, 2, 1, N, N]
 
 
 @pytest.fixture(scope="module")
@@ -51,13 +55,17 @@ def _gpu_tokens(dev, data):
     dev.index(d_buf, d_idx, d_res)
     r = dev.fetch(d_res)
     n = int(r.count)
-    t, d, res = dev.tokens(d_buf, len(data), d_idx, n)
-    return d_idx[:n].cpu().numpy().view(np.uint32), t.cpu().numpy(), d.cpu().numpy(), res
+    t, d, res, m = dev.tokens(d_buf, len(data), d_idx, n, match=True)
+    return d_idx[:n].cpu().numpy().view(np.uint32), t.cpu().numpy(), d.cpu().numpy(), res, m.cpu().numpy().view(np.uint32)
 
 
 def _check(dev, data, where):
-    idx, t, d, res = _gpu_tokens(dev, data)
+    idx, t, d, res, m = _gpu_tokens(dev, data)
     wt, wd, (final, mn, mx) = helpers.oracle_tokens(data, idx)
+    wm = helpers.oracle_match(wt)
+    if not np.array_equal(m, wm):
+        bad = int(np.argmax(m != wm))
+        raise AssertionError(f"{where}: match[{bad}] = {m[bad]} != {wm[bad]}")
     assert np.array_equal(t, wt), where
     if not np.array_equal(d, wd):
         bad = int(np.argmax(d != wd))
@@ -107,8 +115,13 @@ def test_tokens_1gib_replicated(dev):
     dev.index(d_buf, d_idx, d_res)
     n = int(dev.fetch(d_res).count)
     assert n == len(idx_u) * reps
-    t, d, res = dev.tokens(d_buf, d_buf.numel(), d_idx, n)
+    t, d, res, m = dev.tokens(d_buf, d_buf.numel(), d_idx, n, match=True)
     assert (res.n, res.final_depth, res.min_depth, res.max_depth) == (n, 0, 0, mx)
+    wm = helpers.oracle_match(wt).astype(np.int64)
+    wm_d = torch.from_numpy(wm).to(dev.device)
+    k = torch.arange(reps, device=dev.device, dtype=torch.int64)[:, None] * len(idx_u)
+    want_m = torch.where(wm_d[None, :] == 0xFFFFFFFF, wm_d[None, :], wm_d[None, :] + k)  # partners stay inside their unit
+    assert torch.equal(m.view(reps, -1).to(torch.int64) & 0xFFFFFFFF, want_m)
     wt_d = torch.from_numpy(wt).to(dev.device)
     wd_d = torch.from_numpy(wd).to(dev.device)
     assert torch.equal(t.view(reps, -1), wt_d.expand(reps, -1))
