@@ -237,8 +237,10 @@ def main():
         spec = sh.speculate(rank > 0, d_shard, shard_len, host_halo=host_halo, host_head=host_head)
 
         def submit():
+            # after the first verified run the exact carry-in of this (unchanged) shard is known: a
+            # refuted guess costs one re-run once, not one per step
             return sh.submit(d_shard, shard_len, d_idx, total_len, has_prefix=(rank > 0), flags=flags,
-                             speculation=spec)
+                             speculation=sh.last_spec or spec)
 
         def step():
             return sh.result(submit())

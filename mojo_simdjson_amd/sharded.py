@@ -247,6 +247,7 @@ class ShardedStage1:
         self.dev, self.rank, self.world, self.group = dev, rank, world, group
         self.always_gather = always_gather
         self.reruns = 0
+        self.last_spec = None  # the carry-in that the last verified run of this rank actually used
         self._slots = None
         self._next = 0
 
@@ -363,6 +364,7 @@ class ShardedStage1:
                 spec = tuple(true_in[first_wrong])
                 self.reruns += 1
             self._launch(sl, spec, a)
+        self.last_spec = tuple(sl["spec"])  # exact by now: a caller re-submitting the same shard can pass it
         c = carries[self.rank]
         total = sum(int(x.count) for x in carries)
         code = global_code(int(carries[-1].in_string), any(int(x.unescaped_error) for x in carries), total,
