@@ -157,7 +157,9 @@ int32_t msj_carry_fetch(msj_ctx *ctx, const msj_carry *d_carry, msj_carry *host_
  * filled in on the device).
  *   d_carry_in : device msj_carry with the exact state at the shard's first
  *                byte (zeroed for the start of the document).
- *   d_carry_out: device msj_carry receiving the state after the last byte.
+ *   d_carry_out: device msj_carry receiving the state after the last byte (a shard may end
+ *                anywhere, also inside a multi-byte character or right after a backslash; only its
+ *                base must be 16-byte aligned).
  *   has_prefix : non-zero when d_buf[-64..0) is readable and holds the 64
  *                stream bytes preceding the shard (used for the UTF-8
  *                continuation check across the shard boundary).

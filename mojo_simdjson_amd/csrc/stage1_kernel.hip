@@ -377,7 +377,7 @@ __device__ __forceinline__ Pending compute_tile(const KernelArgs &a, const uint3
     const uint64_t Pm = __ballot(tr == 64u);
     const uint64_t add_a = G | Pm, add_b = G;
     const uint64_t add_s = add_a + add_b + tile_e_in;
-    const uint32_t tile_e_out = (uint32_t)(((add_a & add_b) | ((add_a | add_b) & ~add_s)) >> 63);
+    uint32_t tile_e_out = (uint32_t)(((add_a & add_b) | ((add_a | add_b) & ~add_s)) >> 63);
     const uint64_t carries = add_s ^ add_a ^ add_b;
     const uint32_t lane_e_in = (uint32_t)(carries >> lane) & 1u;
     MSJ_STAMP(tile, 3);
@@ -396,7 +396,7 @@ __device__ __forceinline__ Pending compute_tile(const KernelArgs &a, const uint3
     const uint64_t nqs = lut3<MSJ_TT(~TA & ~TB)>(nonscalar, quote, quote);  // scalar & ~quote
     const uint32_t my_ps = (uint32_t)(nqs >> 63);
     const uint32_t prev_ps = dpp_shift_up1(my_ps, tile_ps_in);
-    const uint32_t tile_ps_out = bcast(my_ps, 63);
+    uint32_t tile_ps_out = bcast(my_ps, 63);
 
     const uint64_t lane_in = (uint64_t)(-(int64_t)lane_par);  // all-ones: inside a string
     // in_string / string_tail assuming the TILE starts outside a string
@@ -409,6 +409,15 @@ __device__ __forceinline__ Pending compute_tile(const KernelArgs &a, const uint3
     // (json_scanner.mojo:24-26, json_string_scanner.mojo:40-44)
     r.T0 = lut3<MSJ_TT(TA & ~(TB ^ TC))>(potential, in_string0, quote);  // if tile s_in = 0
     r.T1 = lut3<MSJ_TT(TA & (TB ^ TC))>(potential, in_string0, quote);   // if tile s_in = 1
+    const bool partial = tile * kTileBytes + kTileBytes > len;  // uniform: the launch's last tile, cut short
+    if (partial) {
+        // the carries OUT of a shard that does not end on a tile are the state after its last BYTE,
+        // not after the space padding: an unescaped backslash there escapes the next shard's first
+        // byte, a non-quote scalar there makes it a continuation
+        const uint32_t lastpos = len - 1u - tile * kTileBytes, ll = lastpos >> 6, lb = lastpos & 63u;
+        tile_e_out = bcast((uint32_t)((cls.backslash & ~escaped) >> lb) & 1u, (int)ll);
+        tile_ps_out = bcast((uint32_t)(nqs >> lb) & 1u, (int)ll);
+    }
     const bool err0 = (cls.ctrl & in_string0) != 0;   // json_structural_indexer.mojo:143-145
     const bool err1 = (cls.ctrl & ~in_string0) != 0;
     MSJ_STAMP(tile, 4);
@@ -429,7 +438,11 @@ __device__ __forceinline__ Pending compute_tile(const KernelArgs &a, const uint3
         sh8.pED = wave_shl_in<1>(u8p.isED, (c >> 7) & 1u);
         sh8.pF0 = wave_shl_in<1>(u8p.isF0, (c >> 8) & 1u);
         sh8.pF4 = wave_shl_in<1>(u8p.isF4, (c >> 9) & 1u);
-        u8err = utf8_errors_shifted(p, u8p, sh8) != 0;
+        uint64_t u8bad = utf8_errors_shifted(p, u8p, sh8);
+        // a character cut by the end of a NON-final shard continues in the next one (which checks it
+        // from its window bytes); only at the end of the stream is the missing continuation an error
+        if (partial && !(a.flags & kFlagFinal)) u8bad &= valid;
+        u8err = u8bad != 0;
         // a sequence still open at the end of the tile (the last lane's top lead bits)
         tile_pend = ((bcast((uint32_t)(u8p.lead234 >> 32), 63) >> 31) | (bcast((uint32_t)(u8p.lead34 >> 32), 63) >> 30) |
                      (bcast((uint32_t)(u8p.lead4 >> 32), 63) >> 29)) ? 1u : 0u;

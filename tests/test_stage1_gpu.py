@@ -272,6 +272,7 @@ def test_shard_chain_equals_whole(torch_mod, dev, oracle):
         cin = cout
     res = dev.fetch(cin)
     assert res.code == 0 and res.count == n and res.bytes == len(b)
+    assert res.utf8_error == 0  # cuts inside multi-byte characters are not errors
     got = d_idx.cpu().numpy().view(np.uint32)
     # shard-relative offsets: add each shard's byte base back before comparing
     bases = np.zeros(n + 3, dtype=np.uint32)
@@ -617,3 +618,51 @@ def test_host_pointer_large_inputs(oracle):
     # the reference's capacity quirk: all structural, n + 3 > len
     dense = b"[" * (50 << 20)
     assert_matches_oracle(oracle, dense, "50 MiB of brackets")
+
+
+def test_shard_carry_out_at_any_length(torch_mod, dev, oracle):
+    """A non-final shard may end anywhere, not only on a 4 KiB tile: its carry-out
+    (next_is_escaped, prev_scalar, in_string, count) is the state after its LAST BYTE, and a
+    multi-byte character cut by the end is the next shard's business, not an error."""
+    torch = torch_mod
+    from mojo_simdjson_amd.sharded import boundary_carry
+
+    doc = ('{"k\\\\":"v\\"x\\\\\\"y", "e":"\u00e9\u20ac\U0001F600 z", "n":[12345,true,null,"\\\\"],"s":"abc def"}' * 400).encode()
+    code, n, idx = helpers.run_oracle(oracle.msj_oracle_stage1, doc)
+    assert code == 0
+    d_all = torch.from_numpy(np.frombuffer(doc, dtype=np.uint8).copy()).to(dev.device)
+    d_idx = torch.empty(len(doc) + 8, dtype=torch.int32, device=dev.device)
+    unit = len(doc) // 400
+    zero = dev.new_carry()
+    for cut in list(range(3 * unit, 3 * unit + unit)) + [4096, 4097, 8191, 8192 + 63, 8192 + 64, 20000]:
+        cout = dev.new_carry()
+        dev.shard(d_all, cut, d_idx, zero, cout, is_final=False)
+        c = dev.fetch(cout)
+        e, ps = boundary_carry([doc[:cut]], [True])
+        want_n = int(np.searchsorted(idx[:n], cut))
+        # in_string after `cut` bytes: parity of the unescaped quotes (the oracle counts them as structurals
+        # only when they open a string, so recompute from the bytes)
+        esc = False
+        ins = 0
+        for ch in doc[:cut]:
+            if esc:
+                esc = False
+            elif ch == 0x5C:
+                esc = True
+            elif ch == 0x22:
+                ins ^= 1
+        assert (int(c.next_is_escaped), int(c.prev_scalar), int(c.in_string), int(c.count), int(c.utf8_error)) == \
+            (e, ps, ins, want_n, 0), (cut, doc[max(0, cut - 12):cut])
+        # ... and continuing from that carry gives the whole document
+        if cut % 97 == 0:
+            # the second shard in its own 16-byte aligned buffer, behind a 64-byte halo
+            d_tail = torch.empty(64 + len(doc) - cut, dtype=torch.uint8, device=dev.device)
+            d_tail.copy_(d_all[cut - 64:])
+            cfin = dev.new_carry()
+            dev.shard(d_tail[64:], len(doc) - cut, d_idx, cout, cfin, has_prefix=True, is_final=True,
+                      trailer_len=len(doc))
+            r = dev.fetch(cfin)
+            assert (int(r.code), int(r.count), int(r.utf8_error)) == (0, n, 0), cut
+            got = d_idx[:n].cpu().numpy().view(np.uint32).astype(np.int64)
+            got[want_n:] += cut  # shard-relative offsets
+            assert np.array_equal(got, idx[:n].astype(np.int64)), cut
