@@ -115,6 +115,9 @@ def load():
     lib.msj_tokens_device.argtypes = [ctypes.c_void_p, u8p, ctypes.c_uint64, u32p, ctypes.c_uint64,
                                       ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
                                       ctypes.c_void_p]
+    lib.msj_token_spans_device.restype = ctypes.c_int32
+    lib.msj_token_spans_device.argtypes = [ctypes.c_void_p, u8p, ctypes.c_uint64, u32p, ctypes.c_uint64,
+                                           ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
     lib.msj_carry_fetch.restype = ctypes.c_int32
     lib.msj_carry_fetch.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.POINTER(MsjCarry), ctypes.c_void_p]
     lib.msj_stage1_shard_device.restype = ctypes.c_int32

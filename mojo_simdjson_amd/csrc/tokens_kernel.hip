@@ -448,3 +448,105 @@ extern "C" int msj_launch_tokens(const uint8_t *d_buf, const uint32_t *d_idx, ui
     }
     return (int)hipGetLastError();
 }
+
+// ---- token spans (first version) ---------------------------
+// For a string token the offset of its closing quote and whether the body holds a backslash -- the
+// scan parse_string does byte by byte before it can copy (generic/stage2/string_parsing.mojo:
+// 334-386); for a number token the offset one past its last character and whether it is written as a
+// float ('.', 'e' or 'E' present) -- what parse_number finds out while it accumulates digits
+// (include/generic/number_parsing.mojo:22-80).  One thread per structural, reading the bytes
+// after it; spans longer than kSpanCap bytes are left to stage 2 (flag MSJ_SPAN_LONG).
+// DERIVED quantities, like the token stream above: defined by the CPU statement the tests use.
+namespace msj_tokens {
+constexpr uint32_t kSpanCap = 1024;
+
+__global__ __launch_bounds__(256) void token_spans(const uint8_t *__restrict__ buf, uint64_t len, const uint32_t *__restrict__ idx,
+                                                   uint64_t n, uint32_t *__restrict__ end, uint8_t *__restrict__ flags) {
+    const uint64_t i = (uint64_t)blockIdx.x * 256u + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t start = idx[i];
+    const uint32_t c = buf[start];
+    uint32_t e = 0, f = 0;
+    if (c == '"') {
+        f = MSJ_SPAN_STRING;
+        uint64_t j = (uint64_t)start + 1;
+        const uint64_t stop = (j + kSpanCap < len) ? j + kSpanCap : len;
+        bool closed = false;
+        while (j < stop) {
+            // eight bytes at a time while the aligned word is wholly inside [j, stop) territory and holds
+            // no backslash: the first quote in it (lowest flagged byte of the zero-byte test) ends the string
+            const uint64_t wbase = j & ~7ull;
+            if (wbase + 8 <= len) {
+                const uint2 w2 = *reinterpret_cast<const uint2 *>(buf + wbase);
+                const uint64_t w = ((uint64_t)w2.y << 32) | w2.x;
+                const uint64_t live = ~0ull << (8 * (j - wbase));  // bytes at and after j
+                const uint64_t xq = w ^ 0x2222222222222222ull, xb = w ^ 0x5C5C5C5C5C5C5C5Cull;
+                // exact per-byte zero test (no carries between bytes: bytes in front of j are masked
+                // out afterwards, and a borrow out of one of them must not flag its neighbour)
+                constexpr uint64_t k7f = 0x7F7F7F7F7F7F7F7Full;
+                const uint64_t zq = ~(((xq & k7f) + k7f) | xq | k7f) & live;
+                const uint64_t zb = ~(((xb & k7f) + k7f) | xb | k7f) & live;
+                if (zb == 0) {
+                    if (zq != 0) {
+                        const uint64_t pos = wbase + ((uint64_t)__builtin_ctzll(zq) >> 3);
+                        if (pos < stop) {
+                            j = pos;
+                            closed = true;
+                        } else {
+                            j = stop;
+                        }
+                        break;
+                    }
+                    j = wbase + 8;
+                    continue;
+                }
+                // a backslash somewhere in this word: byte by byte up to it (and over the pair)
+            }
+            const uint32_t b = buf[j];
+            if (b == '\\') {
+                f |= MSJ_SPAN_ESCAPED;
+                j += 2;
+                continue;
+            }
+            if (b == '"') {
+                closed = true;
+                break;
+            }
+            j++;
+        }
+        if (closed) {
+            e = (uint32_t)j;
+        } else if (j >= len) {
+            e = (uint32_t)len;  // never closed (stage 1 reports UNCLOSED_STRING for such input)
+            f |= MSJ_SPAN_OPEN;
+        } else {
+            f |= MSJ_SPAN_LONG;
+        }
+    } else if (c == '-' || (c >= '0' && c <= '9')) {
+        f = MSJ_SPAN_NUMBER;
+        uint64_t j = (uint64_t)start + 1;
+        const uint64_t stop = (j + kSpanCap < len) ? j + kSpanCap : len;
+        for (; j < stop; j++) {
+            const uint32_t b = buf[j];
+            if (b == '.' || b == 'e' || b == 'E')
+                f |= MSJ_SPAN_FLOAT;
+            else if (!((b >= '0' && b <= '9') || b == '+' || b == '-'))
+                break;
+        }
+        if (j == stop && stop < len)
+            f |= MSJ_SPAN_LONG;
+        else
+            e = (uint32_t)j;
+    }
+    end[i] = e;
+    flags[i] = (uint8_t)f;
+}
+}  // namespace msj_tokens
+
+extern "C" int msj_launch_token_spans(const uint8_t *d_buf, uint64_t len, const uint32_t *d_idx, uint64_t n, uint32_t *d_end,
+                                      uint8_t *d_flags, void *stream) {
+    if (n == 0) return 0;
+    hipLaunchKernelGGL(msj_tokens::token_spans, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream),
+                       d_buf, len, d_idx, n, d_end, d_flags);
+    return (int)hipGetLastError();
+}

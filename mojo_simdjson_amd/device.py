@@ -110,6 +110,18 @@ class Stage1Device:
             return d_type[:n], d_depth[:n], res, d_match[:n]
         return d_type[:n], d_depth[:n], res
 
+    def token_spans(self, d_buf, length, d_idx, n):
+        """Closing quote / escape flag of every string token, end / float flag of every number token
+        (``msj_token_spans_device``).  Returns (d_end int32[n] viewed as uint32, d_flags uint8[n]); asynchronous."""
+        n = int(n)
+        d_end = torch.empty(max(n, 1), dtype=torch.int32, device=self.device)
+        d_flags = torch.empty(max(n, 1), dtype=torch.uint8, device=self.device)
+        rc = self.lib.msj_token_spans_device(self.ctx, _ptr(d_buf), int(length), _ptr(d_idx), n, _ptr(d_end),
+                                             _ptr(d_flags), self._stream())
+        if rc != 0:
+            raise RuntimeError(f"msj_token_spans_device failed: {rc}")
+        return d_end[:n], d_flags[:n]
+
     def fetch(self, d_carry):
         """Blocking read-back of a device ``msj_carry``."""
         out = _lib.MsjCarry()

@@ -69,3 +69,43 @@ int msj_oracle_match(const uint8_t *type, uint64_t n, uint32_t *match) {
     free(stack);
     return 0;
 }
+
+/* Token spans (rows f2 / f4): the same statement as csrc/tokens_kernel.hip::token_spans, byte by byte.
+ * String: parse_string's scan for the closing quote and for backslashes (generic/stage2/
+ * string_parsing.mojo:334-386); number: the characters parse_number walks over
+ * (include/generic/number_parsing.mojo:22-80).  Spans over 1024 bytes are flagged, not scanned. */
+void msj_oracle_token_spans(const uint8_t *buf, uint64_t len, const uint32_t *idx, uint64_t n, uint32_t *end, uint8_t *flags) {
+    const uint64_t cap = 1024;
+    for (uint64_t i = 0; i < n; i++) {
+        const uint64_t start = idx[i];
+        const uint8_t c = buf[start];
+        uint32_t e = 0, f = 0;
+        if (c == '"') {
+            f = 1;
+            uint64_t j = start + 1;
+            const uint64_t stop = (j + cap < len) ? j + cap : len;
+            int closed = 0;
+            while (j < stop) {
+                if (buf[j] == '\\') { f |= 2; j += 2; continue; }
+                if (buf[j] == '"') { closed = 1; break; }
+                j++;
+            }
+            if (closed) e = (uint32_t)j;
+            else if (j >= len) { e = (uint32_t)len; f |= 16; }
+            else f |= 128;
+        } else if (c == '-' || (c >= '0' && c <= '9')) {
+            f = 4;
+            uint64_t j = start + 1;
+            const uint64_t stop = (j + cap < len) ? j + cap : len;
+            for (; j < stop; j++) {
+                const uint8_t b = buf[j];
+                if (b == '.' || b == 'e' || b == 'E') f |= 8;
+                else if (!((b >= '0' && b <= '9') || b == '+' || b == '-')) break;
+            }
+            if (j == stop && stop < len) f |= 128;
+            else e = (uint32_t)j;
+        }
+        end[i] = e;
+        flags[i] = (uint8_t)f;
+    }
+}

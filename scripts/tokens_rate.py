@@ -45,4 +45,13 @@ for name in ("minified", "utf8", "pretty4"):
     torch.cuda.synchronize()
     ms2 = e0.elapsed_time(e1) / 10
     print(f"           with bracket matching: {ms2:.3f} ms ({n / ms2 / 1e6:.1f} G structurals/s)")
+    dev.token_spans(d_buf, nbytes, d_idx, n)
+    torch.cuda.synchronize()
+    e0.record()
+    for _ in range(10):
+        dev.token_spans(d_buf, nbytes, d_idx, n)
+    e1.record()
+    torch.cuda.synchronize()
+    ms3 = e0.elapsed_time(e1) / 10
+    print(f"           token spans (strings, numbers): {ms3:.3f} ms ({n / ms3 / 1e6:.1f} G structurals/s, {nbytes / ms3 / 1e6:.0f} GB/s of JSON)")
 dev.close()

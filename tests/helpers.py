@@ -73,6 +73,17 @@ def oracle_match(typ):
     return m[:typ.size]
 
 
+def oracle_token_spans(data, idx):
+    """(end uint32[n], flags uint8[n]) per oracle/tokens_oracle.c: msj_oracle_token_spans."""
+    lib = ctypes.CDLL(TOKENS_SO)
+    idx = np.ascontiguousarray(idx, dtype=np.uint32)
+    end = np.zeros(max(idx.size, 1), dtype=np.uint32)
+    flags = np.zeros(max(idx.size, 1), dtype=np.uint8)
+    lib.msj_oracle_token_spans(ctypes.c_char_p(bytes(data)), ctypes.c_uint64(len(data)), idx.ctypes.data_as(ctypes.c_void_p),
+                               ctypes.c_uint64(idx.size), end.ctypes.data_as(ctypes.c_void_p), flags.ctypes.data_as(ctypes.c_void_p))
+    return end[:idx.size], flags[:idx.size]
+
+
 SENTINEL = 0xDEADBEEF
 
 

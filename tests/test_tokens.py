@@ -33,6 +33,23 @@ def test_definition_by_hand():
     assert list(helpers.oracle_match(np.frombuffer(b"][]][", dtype=np.uint8))) == [N, 2, 1, N, N]
 
 
+def test_span_definition_by_hand():
+    oracle = helpers.load_oracle()
+    doc = b'{"a\\"b":-12.5e3,"c":[7,"x"],"d":"\\\\"}'
+    idx = _stage1(oracle, doc)
+    end, flags = helpers.oracle_token_spans(doc, idx)
+    toks = [(chr(doc[i]), int(e), int(f)) for i, e, f in zip(idx, end, flags)]
+    #       0{ 1" 2a 3\ 4" 5b 6" 7: 8- .. 14"3" 15, 16" 17c 18" 19: 20[ 21"7" 22, 23" 24x 25" 26] 27, 28" 29d 30" 31: 32" 33\ 34\ 35" 36}
+    assert toks == [("{", 0, 0), ('"', 6, 3), (":", 0, 0), ("-", 15, 12), (",", 0, 0), ('"', 18, 1), (":", 0, 0),
+                    ("[", 0, 0), ("7", 22, 4), (",", 0, 0), ('"', 25, 1), ("]", 0, 0), (",", 0, 0), ('"', 30, 1),
+                    (":", 0, 0), ('"', 35, 3), ("}", 0, 0)], toks
+    # an unclosed string, a string and a number beyond the scan cap
+    d2 = b'["' + b"a" * 2000 + b'",' + b"1" * 2000 + b',"zz'
+    idx2 = np.array([0, 1, 2003, 2004, 4004, 4005], dtype=np.uint32)
+    end, flags = helpers.oracle_token_spans(d2, idx2)
+    assert list(zip(end.tolist(), flags.tolist())) == [(0, 0), (0, 129), (0, 0), (0, 132), (0, 0), (len(d2), 17)]
+
+
 @pytest.fixture(scope="module")
 def dev():
     import torch
@@ -86,6 +103,35 @@ def test_tokens_fixtures_and_shapes(dev):
     _check(dev, b"[" * 300000 + b"]" * 299999, "deep")
     _check(dev, b"]" * 5000 + b"[" * 7, "underflow")
     _check(dev, b" ", "no structurals")
+
+
+def _check_spans(dev, data, where):
+    import torch
+
+    d_buf = torch.from_numpy(np.frombuffer(data, dtype=np.uint8).copy()).to(dev.device)
+    d_idx = torch.empty(len(data) + 3 + 4, dtype=torch.int32, device=dev.device)
+    d_res = dev.new_carry()
+    dev.index(d_buf, d_idx, d_res)
+    n = int(dev.fetch(d_res).count)
+    e, f = dev.token_spans(d_buf, len(data), d_idx, n)
+    idx = d_idx[:n].cpu().numpy().view(np.uint32)
+    we, wf = helpers.oracle_token_spans(data, idx)
+    assert np.array_equal(f.cpu().numpy(), wf), where
+    assert np.array_equal(e.cpu().numpy().view(np.uint32), we), where
+
+
+@pytest.mark.gpu
+def test_token_spans(dev):
+    from mojo_simdjson_amd import synth
+
+    for f in helpers.golden_valid_files():
+        js, _ = helpers.read_fixture(f)
+        _check_spans(dev, js, f)
+    for name in ("minified", "utf8", "pretty4"):
+        _check_spans(dev, synth.workload(name, 8 << 20).tobytes(), name)
+    _check_spans(dev, b'["' + b"a" * 5000 + b'", ' + b"9" * 3000 + b', "tail\\', "long spans and an escape at the very end")
+    _check_spans(dev, b'"' + b"\\" * 600 + b'"', "cap reached inside an escape")
+    _check_spans(dev, b"-", "one byte")
 
 
 @pytest.mark.gpu
