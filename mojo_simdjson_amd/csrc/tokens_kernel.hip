@@ -449,94 +449,124 @@ extern "C" int msj_launch_tokens(const uint8_t *d_buf, const uint32_t *d_idx, ui
     return (int)hipGetLastError();
 }
 
-// ---- token spans (first version) ---------------------------
+// ---- token spans --------------------------------------------
 // For a string token the offset of its closing quote and whether the body holds a backslash -- the
 // scan parse_string does byte by byte before it can copy (generic/stage2/string_parsing.mojo:
 // 334-386); for a number token the offset one past its last character and whether it is written as a
 // float ('.', 'e' or 'E' present) -- what parse_number finds out while it accumulates digits
-// (include/generic/number_parsing.mojo:22-80).  One thread per structural, reading the bytes
-// after it; spans longer than kSpanCap bytes are left to stage 2 (flag MSJ_SPAN_LONG).
+// (include/generic/number_parsing.mojo:22-80).  One thread per structural.
+// The closing quote needs no scan of the body: in stage 1's output the next structural after an
+// opening quote is the first byte after the closing quote that is not whitespace (an operator, a
+// quote and a scalar that follows a quote are all structural), so the closing quote is the last
+// non-blank byte in front of the next structural.  The backslash flag is a scan of the body with
+// independent 8-byte reads (bodies over kSpanCap bytes: MSJ_SPAN_LONG, flag left to stage 2).
 // DERIVED quantities, like the token stream above: defined by the CPU statement the tests use.
 namespace msj_tokens {
 constexpr uint32_t kSpanCap = 1024;
+constexpr uint64_t k7f = 0x7F7F7F7F7F7F7F7Full;
+// bit 7 of every byte of x that is zero; exact (no carries between bytes)
+__device__ __forceinline__ uint64_t zero_bytes(uint64_t x) { return ~(((x & k7f) + k7f) | x | k7f); }
+__device__ __forceinline__ uint64_t load8(const uint8_t *p) {
+    const uint2 w = *reinterpret_cast<const uint2 *>(p);
+    return ((uint64_t)w.y << 32) | w.x;
+}
+__device__ __forceinline__ bool is_blank(uint32_t b) { return b == 0x20u || b == 0x09u || b == 0x0Au || b == 0x0Du; }
 
 __global__ __launch_bounds__(256) void token_spans(const uint8_t *__restrict__ buf, uint64_t len, const uint32_t *__restrict__ idx,
                                                    uint64_t n, uint32_t *__restrict__ end, uint8_t *__restrict__ flags) {
     const uint64_t i = (uint64_t)blockIdx.x * 256u + threadIdx.x;
     if (i >= n) return;
-    const uint32_t start = idx[i];
+    const uint64_t start = idx[i];
+    const uint64_t next = (i + 1 < n) ? (uint64_t)idx[i + 1] : len;
     const uint32_t c = buf[start];
     uint32_t e = 0, f = 0;
     if (c == '"') {
         f = MSJ_SPAN_STRING;
-        uint64_t j = (uint64_t)start + 1;
-        const uint64_t stop = (j + kSpanCap < len) ? j + kSpanCap : len;
+        uint64_t q = next;  // exclusive end of the candidate region
+        while (q > start + 1 && is_blank(buf[q - 1])) q--;
         bool closed = false;
-        while (j < stop) {
-            // eight bytes at a time while the aligned word is wholly inside [j, stop) territory and holds
-            // no backslash: the first quote in it (lowest flagged byte of the zero-byte test) ends the string
-            const uint64_t wbase = j & ~7ull;
-            if (wbase + 8 <= len) {
-                const uint2 w2 = *reinterpret_cast<const uint2 *>(buf + wbase);
-                const uint64_t w = ((uint64_t)w2.y << 32) | w2.x;
-                const uint64_t live = ~0ull << (8 * (j - wbase));  // bytes at and after j
-                const uint64_t xq = w ^ 0x2222222222222222ull, xb = w ^ 0x5C5C5C5C5C5C5C5Cull;
-                // exact per-byte zero test (no carries between bytes: bytes in front of j are masked
-                // out afterwards, and a borrow out of one of them must not flag its neighbour)
-                constexpr uint64_t k7f = 0x7F7F7F7F7F7F7F7Full;
-                const uint64_t zq = ~(((xq & k7f) + k7f) | xq | k7f) & live;
-                const uint64_t zb = ~(((xb & k7f) + k7f) | xb | k7f) & live;
-                if (zb == 0) {
-                    if (zq != 0) {
-                        const uint64_t pos = wbase + ((uint64_t)__builtin_ctzll(zq) >> 3);
-                        if (pos < stop) {
-                            j = pos;
-                            closed = true;
-                        } else {
-                            j = stop;
-                        }
-                        break;
-                    }
-                    j = wbase + 8;
-                    continue;
-                }
-                // a backslash somewhere in this word: byte by byte up to it (and over the pair)
-            }
-            const uint32_t b = buf[j];
-            if (b == '\\') {
-                f |= MSJ_SPAN_ESCAPED;
-                j += 2;
-                continue;
-            }
-            if (b == '"') {
-                closed = true;
-                break;
-            }
-            j++;
+        if (q > start + 1 && buf[q - 1] == '"') {
+            uint64_t k = q - 1;  // unescaped iff an even number of backslashes stands right in front of it
+            while (k > start + 1 && buf[k - 1] == '\\') k--;
+            closed = (((q - 1) - k) & 1u) == 0;
         }
-        if (closed) {
-            e = (uint32_t)j;
-        } else if (j >= len) {
-            e = (uint32_t)len;  // never closed (stage 1 reports UNCLOSED_STRING for such input)
+        if (!closed) {
+            e = (uint32_t)len;  // only the last token can be like this (stage 1 reports UNCLOSED_STRING)
             f |= MSJ_SPAN_OPEN;
         } else {
-            f |= MSJ_SPAN_LONG;
+            const uint64_t close = q - 1;
+            e = (uint32_t)close;
+            const uint64_t b0 = start + 1;  // body = [b0, close)
+            if (close - b0 > kSpanCap) {
+                f |= MSJ_SPAN_LONG;
+            } else if (close > b0) {
+                uint64_t acc = 0;
+                const uint64_t w0 = b0 & ~7ull, w1 = (close - 1) & ~7ull;  // first and last aligned word
+                if (w1 + 8 <= len) {
+                    for (uint64_t w = w0; w <= w1; w += 8) {
+                        uint64_t z = zero_bytes(load8(buf + w) ^ 0x5C5C5C5C5C5C5C5Cull);
+                        if (w == w0) z &= ~0ull << (8 * (b0 - w0));
+                        if (w == w1) z &= ~0ull >> (8 * (7 - ((close - 1) - w1)));
+                        acc |= z;
+                    }
+                } else {  // the last word would reach past the buffer: byte by byte
+                    for (uint64_t j = b0; j < close; j++) acc |= (buf[j] == '\\');
+                }
+                if (acc) f |= MSJ_SPAN_ESCAPED;
+            }
         }
     } else if (c == '-' || (c >= '0' && c <= '9')) {
         f = MSJ_SPAN_NUMBER;
-        uint64_t j = (uint64_t)start + 1;
-        const uint64_t stop = (j + kSpanCap < len) ? j + kSpanCap : len;
-        for (; j < stop; j++) {
-            const uint32_t b = buf[j];
-            if (b == '.' || b == 'e' || b == 'E')
-                f |= MSJ_SPAN_FLOAT;
-            else if (!((b >= '0' && b <= '9') || b == '+' || b == '-'))
-                break;
+        // the four aligned words that hold the next 25..32 bytes, requested together (numbers are short:
+        // no chain of dependent loads); bytes past the buffer read as blanks = the number ends there
+        const uint64_t w0 = start & ~7ull;
+        uint64_t W[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const uint64_t wa = w0 + 8u * k;
+            if (wa + 8 <= len) {
+                W[k] = load8(buf + wa);
+            } else {
+                W[k] = 0x2020202020202020ull;
+                for (uint64_t b = wa; b < len; b++) W[k] = (W[k] & ~(0xFFull << (8 * (b - wa)))) | ((uint64_t)buf[b] << (8 * (b - wa)));
+            }
         }
-        if (j == stop && stop < len)
-            f |= MSJ_SPAN_LONG;
-        else
-            e = (uint32_t)j;
+        bool done = false;
+        uint64_t j = start + 1;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+#pragma unroll
+            for (int b = 0; b < 8; b++) {
+                const uint64_t pos = w0 + 8u * k + b;
+                if (!done && pos == j) {
+                    const uint32_t ch = (uint32_t)(W[k] >> (8 * b)) & 0xFFu;
+                    if (ch == '.' || ch == 'e' || ch == 'E') {
+                        f |= MSJ_SPAN_FLOAT;
+                        j++;
+                    } else if ((ch >= '0' && ch <= '9') || ch == '+' || ch == '-') {
+                        j++;
+                    } else {
+                        done = true;
+                    }
+                }
+            }
+        }
+        if (j > len) j = len;
+        if (!done && j < len) {  // longer than the four words: byte by byte from memory
+            const uint64_t stop = (start + 1 + kSpanCap < len) ? start + 1 + kSpanCap : len;
+            for (; j < stop; j++) {
+                const uint32_t b = buf[j];
+                if (b == '.' || b == 'e' || b == 'E')
+                    f |= MSJ_SPAN_FLOAT;
+                else if (!((b >= '0' && b <= '9') || b == '+' || b == '-'))
+                    break;
+            }
+            if (j == stop && stop < len) {
+                f |= MSJ_SPAN_LONG;
+                j = 0;
+            }
+        }
+        e = (uint32_t)j;
     }
     end[i] = e;
     flags[i] = (uint8_t)f;

@@ -70,10 +70,12 @@ int msj_oracle_match(const uint8_t *type, uint64_t n, uint32_t *match) {
     return 0;
 }
 
-/* Token spans (rows f2 / f4): the same statement as csrc/tokens_kernel.hip::token_spans, byte by byte.
- * String: parse_string's scan for the closing quote and for backslashes (generic/stage2/
- * string_parsing.mojo:334-386); number: the characters parse_number walks over
- * (include/generic/number_parsing.mojo:22-80).  Spans over 1024 bytes are flagged, not scanned. */
+/* Token spans (rows f2 / f4), the plain statement: scan forward from the opening quote like
+ * parse_string does (generic/stage2/string_parsing.mojo:334-386) -- the first quote that is not behind a
+ * backslash closes the string, any backslash on the way sets the flag; walk over the characters
+ * parse_number accepts (include/generic/number_parsing.mojo:22-80).  (The HIP kernel finds the closing
+ * quote from the NEXT structural instead; the tests check that this is the same thing.)
+ * Bodies over 1024 bytes: end still reported, backslash flag not (LONG); numbers over 1024: LONG, end 0. */
 void msj_oracle_token_spans(const uint8_t *buf, uint64_t len, const uint32_t *idx, uint64_t n, uint32_t *end, uint8_t *flags) {
     const uint64_t cap = 1024;
     for (uint64_t i = 0; i < n; i++) {
@@ -83,16 +85,18 @@ void msj_oracle_token_spans(const uint8_t *buf, uint64_t len, const uint32_t *id
         if (c == '"') {
             f = 1;
             uint64_t j = start + 1;
-            const uint64_t stop = (j + cap < len) ? j + cap : len;
-            int closed = 0;
-            while (j < stop) {
-                if (buf[j] == '\\') { f |= 2; j += 2; continue; }
+            int closed = 0, esc = 0;
+            while (j < len) {
+                if (buf[j] == '\\') { esc = 1; j += 2; continue; }
                 if (buf[j] == '"') { closed = 1; break; }
                 j++;
             }
-            if (closed) e = (uint32_t)j;
-            else if (j >= len) { e = (uint32_t)len; f |= 16; }
-            else f |= 128;
+            if (!closed) { e = (uint32_t)len; f |= 16; }
+            else {
+                e = (uint32_t)j;
+                if (j - (start + 1) > cap) f |= 128;
+                else if (esc) f |= 2;
+            }
         } else if (c == '-' || (c >= '0' && c <= '9')) {
             f = 4;
             uint64_t j = start + 1;

@@ -47,7 +47,7 @@ def test_span_definition_by_hand():
     d2 = b'["' + b"a" * 2000 + b'",' + b"1" * 2000 + b',"zz'
     idx2 = np.array([0, 1, 2003, 2004, 4004, 4005], dtype=np.uint32)
     end, flags = helpers.oracle_token_spans(d2, idx2)
-    assert list(zip(end.tolist(), flags.tolist())) == [(0, 0), (0, 129), (0, 0), (0, 132), (0, 0), (len(d2), 17)]
+    assert list(zip(end.tolist(), flags.tolist())) == [(0, 0), (2002, 129), (0, 0), (0, 132), (0, 0), (len(d2), 17)]
 
 
 @pytest.fixture(scope="module")
@@ -132,6 +132,14 @@ def test_token_spans(dev):
     _check_spans(dev, b'["' + b"a" * 5000 + b'", ' + b"9" * 3000 + b', "tail\\', "long spans and an escape at the very end")
     _check_spans(dev, b'"' + b"\\" * 600 + b'"', "cap reached inside an escape")
     _check_spans(dev, b"-", "one byte")
+    _check_spans(dev, b'["a"  ,"b\\"" , "c\\\\"  ]  ', "blanks between the closing quote and the next structural")
+    # the closing quote is found from the NEXT structural: byte soups (valid or not) must agree with the forward scan
+    rng = np.random.default_rng(9)
+    alphabets = [b'{}[],: \n"\\ab1', b'""\\\\ a,', b'"abc\\" \t:1e5-', b'"\\" \r\n"x']
+    for k in range(300):
+        a = np.frombuffer(alphabets[k % len(alphabets)], dtype=np.uint8)
+        n = int(rng.integers(1, 3000))
+        _check_spans(dev, a[rng.integers(0, len(a), n)].tobytes(), f"soup {k}")
 
 
 @pytest.mark.gpu
