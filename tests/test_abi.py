@@ -69,3 +69,17 @@ def test_error_values_match_reference():
     assert (errors.SUCCESS, errors.CAPACITY, errors.UTF8_ERROR, errors.EMPTY,
             errors.UNESCAPED_CHARS, errors.UNCLOSED_STRING, errors.UNEXPECTED_ERROR) == \
         (0, 1, 11, 13, 14, 15, 24)
+
+
+def test_cpp_mirror_compiles():
+    """The C++ mirror of the reference facade and the C++ twin of its test build against the C ABI
+    (no GPU needed to compile and link; tests/test_stage1_gpu.py runs it)."""
+    import subprocess
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = os.path.join(root, "tests", "_build")
+    os.makedirs(out, exist_ok=True)
+    libdir = os.path.join(root, "mojo_simdjson_amd")
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-Wall", "-I" + os.path.join(root, "include"),
+                           os.path.join(root, "tests", "cpp", "test_stage_1.cpp"), "-o", os.path.join(out, "test_stage_1"),
+                           "-L" + libdir, "-lmsj_stage1", "-Wl,-rpath," + libdir])

@@ -666,3 +666,29 @@ def test_shard_carry_out_at_any_length(torch_mod, dev, oracle):
             got = d_idx[:n].cpu().numpy().view(np.uint32).astype(np.int64)
             got[want_n:] += cut  # shard-relative offsets
             assert np.array_equal(got, idx[:n].astype(np.int64)), cut
+
+
+def _build_cpp_twin():
+    import subprocess
+
+    out = os.path.join(helpers.ROOT, "tests", "_build")
+    os.makedirs(out, exist_ok=True)
+    exe = os.path.join(out, "test_stage_1")
+    libdir = os.path.join(helpers.ROOT, "mojo_simdjson_amd")
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-I" + os.path.join(helpers.ROOT, "include"),
+                           os.path.join(helpers.ROOT, "tests", "cpp", "test_stage_1.cpp"), "-o", exe,
+                           "-L" + libdir, "-lmsj_stage1", "-Wl,-rpath," + libdir])
+    return exe
+
+
+def test_cpp_mirror_runs_the_reference_test():
+    """tests/cpp/test_stage_1.cpp = the reference's tests/test_stage_1.mojo in C++, on the C++ mirror of
+    DomParserImplementation (include/dom_parser_implementation.hpp) and the C ABI: same fixtures, same checks."""
+    import subprocess
+
+    exe = _build_cpp_twin()
+    env = dict(os.environ)
+    env["LD_LIBRARY_PATH"] = "/opt/rocm/lib:" + env.get("LD_LIBRARY_PATH", "")
+    r = subprocess.run([exe, os.path.join(helpers.ROOT, "tests", "golden", "jsons_for_test")], capture_output=True,
+                       text=True, timeout=300, env=env)
+    assert r.returncode == 0 and "test_stage_1 ok" in r.stdout, r.stdout[-3000:] + r.stderr[-2000:]
