@@ -539,15 +539,21 @@ __device__ __forceinline__ void copy_out(const KernelArgs &a, const Emit &e, con
     uint32_t *out = a.idx + (e.base - e.shift);     // out[v] <-> stage[v]; 16-byte aligned
     const uint32_t q_lo = (e.shift + 3u) >> 2;        // first quad with all four elements valid
     const uint32_t q_hi = e.vend >> 2;                // one past the last full quad
-    for (uint32_t q = q_lo + lane; q < q_hi; q += 64u)
-        *reinterpret_cast<uint4 *>(out + 4u * q) = *reinterpret_cast<const uint4 *>(stage + 4u * q);
-    // head (elements shift .. 4*q_lo) and tail (4*q_hi .. vend): < 8 elements in total
-    if (lane < 4u) {
-        const uint32_t vh = lane;  // head quad is quad 0
-        if (vh >= e.shift && vh < 4u * q_lo && vh < e.vend) out[vh] = stage[vh];
-    } else if (lane < 8u) {
-        const uint32_t vt = 4u * q_hi + (lane - 4u);
-        if (vt < e.vend && vt >= 4u * q_lo) out[vt] = stage[vt];
+    // at most kStageWords / 256 = 4 rounds of 64 quads: one address per lane, the rounds are
+    // immediate offsets of the LDS read and of the store
+    const uint32_t q0 = q_lo + lane;
+    const uint4 *src = reinterpret_cast<const uint4 *>(stage) + q0;
+    uint4 *dst = reinterpret_cast<uint4 *>(out) + q0;
+#pragma unroll
+    for (uint32_t k = 0; k < kStageWords / 256u; k++)
+        if (q0 + 64u * k < q_hi) dst[64u * k] = src[64u * k];
+    // head (elements shift .. 4*q_lo) and tail (4*q_hi .. vend): < 8 elements in total, one
+    // element per lane of the first eight
+    if (lane < 8u) {
+        const bool head = lane < 4u;
+        const uint32_t v = head ? lane : 4u * q_hi + (lane - 4u);
+        const bool ok = head ? (v >= e.shift && v < 4u * q_lo && v < e.vend) : (v < e.vend && v >= 4u * q_lo);
+        if (ok) out[v] = stage[v];
     }
 }
 
