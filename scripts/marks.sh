@@ -23,6 +23,6 @@ for i,l in enumerate(lines):
     elif re.match(r"\s+s_",l): cur[4]+=1
     elif re.match(r"\s+(ds_|global_|buffer_|flat_)",l): cur[5]+=1
 tot=[0,0,0]
-for s in sec[:14]:
+for s in sec[:40]:
     print(f"mark {s[0]:>3s} line {s[1]:6d}: valu {s[2]:4d} units {s[3]:4d} salu {s[4]:4d} (br {s[6]:3d}) mem {s[5]:3d}  {s[7].most_common(5)}")
 PY
