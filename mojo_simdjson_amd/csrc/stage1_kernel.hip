@@ -141,7 +141,7 @@ struct Shared {
     // per lane T0|T1 masks and the packed exclusive count scan; per slot a few words
     uint4 pend_masks[kWaves][kPendSlots][64];
     uint32_t pend_excl[kWaves][kPendSlots][64];
-    uint32_t pend_meta[kWaves][kPendSlots][4];  // tile (~0 = empty), tile_cnt, in_cnt, in_s
+    uint32_t pend_meta[kWaves][kPendSlots][4] __attribute__((aligned(16)));  // tile (~0 = empty), tile_cnt, in_cnt, in_s
 };
 
 // Bounded poll of one descriptor until its status is non-zero.
@@ -489,7 +489,8 @@ __device__ __forceinline__ Emit prepare_emit(const KernelArgs &a, Shared &sh, co
                                              const uint64_t rpre_word, const uint64_t count0,
                                              uint32_t &timeout) {
     Emit e;
-    e.tile = uniform32(sh.pend_meta[wave][slot][0]);
+    const uint4 meta = *reinterpret_cast<const uint4 *>(sh.pend_meta[wave][slot]);  // tile, tile_cnt, in_cnt, in_s
+    e.tile = uniform32(meta.x);
     e.live = e.tile != 0xFFFFFFFFu;
     e.staged = false;
     e.staged16 = false;
@@ -499,9 +500,9 @@ __device__ __forceinline__ Emit prepare_emit(const KernelArgs &a, Shared &sh, co
     if (!e.live) return e;
     const uint4 m = sh.pend_masks[wave][slot][lane];
     const uint32_t excl = sh.pend_excl[wave][slot][lane];
-    const uint32_t tile_cnt = uniform32(sh.pend_meta[wave][slot][1]);
-    const uint32_t in_cnt = uniform32(sh.pend_meta[wave][slot][2]);
-    const uint32_t in_s = uniform32(sh.pend_meta[wave][slot][3]);
+    const uint32_t tile_cnt = uniform32(meta.y);
+    const uint32_t in_cnt = uniform32(meta.z);
+    const uint32_t in_s = uniform32(meta.w);
     // the range's prefix (resolver) + the tile's position inside the range (local fold)
     const uint32_t q = (uint32_t)(rpre_word >> 61) & 1u;
     const uint32_t s_in = (in_s >> q) & 1u;
@@ -956,12 +957,8 @@ __device__ __forceinline__ void worker_wave(const KernelArgs &a, Shared &sh, con
             sh.pend_masks[wave][slot][lane] = make_uint4((uint32_t)now[j].T0, (uint32_t)(now[j].T0 >> 32),
                                                          (uint32_t)now[j].T1, (uint32_t)(now[j].T1 >> 32));
             sh.pend_excl[wave][slot][lane] = now[j].excl;
-            if (lane == 0) {
-                sh.pend_meta[wave][slot][0] = now[j].tile;
-                sh.pend_meta[wave][slot][1] = now[j].tile_cnt;
-                sh.pend_meta[wave][slot][2] = in_cnt[j];
-                sh.pend_meta[wave][slot][3] = in_state[j];
-            }
+            if (lane == 0)
+                *reinterpret_cast<uint4 *>(sh.pend_meta[wave][slot]) = make_uint4(now[j].tile, now[j].tile_cnt, in_cnt[j], in_state[j]);
         }
         lo_cur = lo_next;
         r++;
