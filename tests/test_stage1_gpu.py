@@ -692,3 +692,39 @@ def test_cpp_mirror_runs_the_reference_test():
     r = subprocess.run([exe, os.path.join(helpers.ROOT, "tests", "golden", "jsons_for_test")], capture_output=True,
                        text=True, timeout=300, env=env)
     assert r.returncode == 0 and "test_stage_1 ok" in r.stdout, r.stdout[-3000:] + r.stderr[-2000:]
+
+
+def test_abi_argument_errors(torch_mod, dev):
+    """What the C entry points refuse (include/msj_stage1.h): null / misaligned pointers, lengths beyond one
+    uint32 segment, token pre-pass limits.  Negative codes never collide with the reference's."""
+    import ctypes
+
+    torch = torch_mod
+    lib = dev.lib
+    d_buf = torch.zeros(4096 + 16, dtype=torch.uint8, device=dev.device)
+    d_idx = torch.zeros(4096 + 16, dtype=torch.int32, device=dev.device)
+    d_res = dev.new_carry()
+    p = lambda t, off=0: ctypes.c_void_p(t.data_ptr() + off)
+    ok = lib.msj_stage1_device(dev.ctx, p(d_buf), 64, p(d_idx), 100, p(d_res), None, 0)
+    assert ok == 0
+    assert lib.msj_stage1_device(dev.ctx, p(d_buf, 1), 64, p(d_idx), 100, p(d_res), None, 0) == -1      # input not 16-byte aligned
+    assert lib.msj_stage1_device(dev.ctx, p(d_buf), 64, p(d_idx, 4), 100, p(d_res), None, 0) == -1      # index buffer not 16-byte aligned
+    assert lib.msj_stage1_device(dev.ctx, p(d_buf), 64, None, 100, p(d_res), None, 0) == -1             # no index buffer
+    assert lib.msj_stage1_device(dev.ctx, p(d_buf), 64, p(d_idx), 100, None, None, 0) == -1             # no result
+    assert lib.msj_stage1_device(None, p(d_buf), 64, p(d_idx), 100, p(d_res), None, 0) == -1            # no context
+    assert lib.msj_stage1_device(dev.ctx, p(d_buf), 0, p(d_idx), 100, p(d_res), None, 0) == 13          # EMPTY, :91-92
+    assert lib.msj_stage1_device(dev.ctx, p(d_buf), 1 << 32, p(d_idx), 100, p(d_res), None, 0) == 1    # CAPACITY, base.mojo:2
+    n = ctypes.c_uint64(0)
+    assert lib.msj_stage1(None, 5, p(d_idx), 8, ctypes.byref(n), None, 0) == -1
+    assert lib.msj_stage1(b"[1]", 3, None, 8, ctypes.byref(n), None, 0) == -1
+    host_idx = (ctypes.c_uint32 * 8)()
+    assert lib.msj_stage1(b"[1]", 3, host_idx, 8, None, None, 0) == -1
+    assert lib.msj_stage1(b"", 0, host_idx, 8, ctypes.byref(n), None, 0) == 13
+    d_t = torch.zeros(64, dtype=torch.uint8, device=dev.device)
+    d_d = torch.zeros(64, dtype=torch.int32, device=dev.device)
+    d_r = torch.zeros(24, dtype=torch.uint8, device=dev.device)
+    assert lib.msj_tokens_device(dev.ctx, p(d_buf), 64, p(d_idx), 4, p(d_t), p(d_d, 4), None, p(d_r), None) == -1   # depth not 16-byte aligned
+    assert lib.msj_tokens_device(dev.ctx, p(d_buf), 64, p(d_idx), 1 << 31, p(d_t), p(d_d), None, p(d_r), None) == 1  # too many tokens
+    assert lib.msj_tokens_device(dev.ctx, p(d_buf), 64, p(d_idx), 0, None, None, None, p(d_r), None) == 0            # nothing to do is fine
+    assert lib.msj_token_spans_device(dev.ctx, p(d_buf), 64, p(d_idx), 4, None, None, None) == -1
+    torch.cuda.synchronize()
