@@ -262,16 +262,17 @@ def main():
         for _ in range(args.steps):
             last = step()
     else:
-        # steps are independent passes: keep one submission in flight, so that the host side of
-        # step k's stitch (wait for the all-gathered carries, verify the chain) overlaps with
-        # step k+1's kernel; all K results are in hand before the closing barrier
-        pending = None
+        # steps are independent passes: keep up to two submissions in flight, so that the stitch of
+        # step k (the RCCL all-gather, which may only get compute units once the persistent kernel of
+        # step k+1 drains, then the host-side verification) overlaps with the kernels of steps k+1 and
+        # k+2; all K results are in hand before the closing barrier
+        pending = []
         for _ in range(args.steps):
-            ticket = submit()
-            if pending is not None:
-                last = sh.result(pending)
-            pending = ticket
-        last = sh.result(pending)
+            pending.append(submit())
+            if len(pending) >= sh.DEPTH:
+                last = sh.result(pending.pop(0))
+        while pending:
+            last = sh.result(pending.pop(0))
     ev1.record()
     barrier()
     dt = time.perf_counter() - t0

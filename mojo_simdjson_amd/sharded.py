@@ -239,7 +239,7 @@ class ShardedStage1:
     and verifies them.  ``run`` = ``result(submit(...))``.
     """
 
-    DEPTH = 2  # submissions in flight
+    DEPTH = 3  # submissions that may be in flight (slots for their carries)
 
     def __init__(self, dev, rank, world, group=None, always_gather=False):
         """always_gather: take the collective path even for world == 1 (lets a one-GPU box
