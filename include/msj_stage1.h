@@ -65,6 +65,9 @@ extern "C" {
 /* flags */
 #define MSJ_FLAG_STRICT_UTF8 1u /* return 11 when the input is not valid UTF-8 */
 #define MSJ_FLAG_NO_UTF8 2u     /* skip UTF-8 validation entirely (verdict = 0) */
+/* The first n (0..15) bytes of the buffer read as blanks: a window of a document stream starts at
+ * a document, its 16-byte aligned base a few bytes earlier (msj_documents_device, resume_offset). */
+#define MSJ_FLAG_SKIP(n) (((uint32_t)(n) & 15u) << 24)
 
 /* SIMDJSON_MAXSIZE_BYTES, src/mojo_simdjson/include/base.mojo:2: indices are
  * uint32, so one segment of input is limited to this many bytes. */
@@ -227,6 +230,43 @@ int32_t msj_tokens_device(msj_ctx *ctx, const uint8_t *d_buf, uint64_t len, cons
 #define MSJ_SPAN_LONG 128u   /* string body over 1024 bytes: backslash flag not computed; number over 1024: not scanned */
 int32_t msj_token_spans_device(msj_ctx *ctx, const uint8_t *d_buf, uint64_t len, const uint32_t *d_idx, uint64_t n,
                                uint32_t *d_end, uint8_t *d_flags, void *stream);
+
+/*
+ * ---- multi-document mode (DERIVED) -----------------------------
+ * The reference left upstream simdjson's streaming modes out
+ * (generic/stage1/json_structural_indexer.mojo:153,169; generic/stage2/tape_builder.mojo:25 "TODO: add
+ * streaming").  msj_documents_device splits the token stream of one window of a stream of concatenated
+ * documents (NDJSON, or no separator at all) into documents: a document starts at every token that sits
+ * at depth 0 and is not a closing bracket.
+ *   d_doc_first[k] = token index (into d_idx / d_type / d_depth) of the first token of document k,
+ *                    ascending; at most `capacity` are stored, n_documents counts all of them
+ *   d_result:  n_documents      documents that START in the window
+ *              n_complete       ... of which complete: all, or all but the last.  The last one is
+ *                               complete if it is a container closed before the window ends; a closed
+ *                               string (d_carry->in_string tells); any other scalar when is_final, or
+ *                               when the window ends in a blank -- a number or literal that touches
+ *                               the end of a window may go on in the next one
+ *              tokens_complete  tokens covered by the complete documents: n, or the index of the first
+ *                               token of the cut document (what upstream's find_next_document_index
+ *                               returns for the window)
+ *              resume_offset    byte offset (relative to the window) of that token = where the next
+ *                               window has to start; len when nothing is cut
+ * d_buf / len: the window; is_final: it is the end of the stream.  d_type / d_depth as written by
+ * msj_tokens_device for the same d_idx; d_carry (optional, may be NULL):
+ * the carry_out of the window's msj_stage1_shard_device call, read on the device.  A window of a
+ * stream is indexed with msj_stage1_shard_device(..., is_final = 0): nothing is an error yet at its end.
+ * Asynchronous on `stream`.
+ */
+typedef struct msj_documents_result {
+    uint64_t n_documents;
+    uint64_t n_complete;
+    uint64_t tokens_complete;
+    uint64_t resume_offset;
+} msj_documents_result;
+
+int32_t msj_documents_device(msj_ctx *ctx, const uint8_t *d_buf, uint64_t len, int32_t is_final, const uint32_t *d_idx,
+                             uint64_t n, const uint8_t *d_type, const int32_t *d_depth, const msj_carry *d_carry,
+                             uint32_t *d_doc_first, uint64_t capacity, msj_documents_result *d_result, void *stream);
 
 /* Tile geometry (for roofline bookkeeping and tests). */
 uint32_t msj_tile_bytes(void);

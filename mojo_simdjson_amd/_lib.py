@@ -37,6 +37,13 @@ class MsjTokensResult(ctypes.Structure):
                 ("max_depth", ctypes.c_int32), ("reserved", ctypes.c_uint32)]
 
 
+class MsjDocumentsResult(ctypes.Structure):
+    """``msj_documents_result`` (include/msj_stage1.h)."""
+
+    _fields_ = [("n_documents", ctypes.c_uint64), ("n_complete", ctypes.c_uint64),
+                ("tokens_complete", ctypes.c_uint64), ("resume_offset", ctypes.c_uint64)]
+
+
 class MsjSegment(ctypes.Structure):
     _fields_ = [
         ("byte_base", ctypes.c_uint64),
@@ -118,6 +125,10 @@ def load():
     lib.msj_token_spans_device.restype = ctypes.c_int32
     lib.msj_token_spans_device.argtypes = [ctypes.c_void_p, u8p, ctypes.c_uint64, u32p, ctypes.c_uint64,
                                            ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
+    lib.msj_documents_device.restype = ctypes.c_int32
+    lib.msj_documents_device.argtypes = [ctypes.c_void_p, u8p, ctypes.c_uint64, ctypes.c_int32, u32p, ctypes.c_uint64,
+                                         ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
+                                         ctypes.c_uint64, ctypes.c_void_p, ctypes.c_void_p]
     lib.msj_carry_fetch.restype = ctypes.c_int32
     lib.msj_carry_fetch.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.POINTER(MsjCarry), ctypes.c_void_p]
     lib.msj_stage1_shard_device.restype = ctypes.c_int32

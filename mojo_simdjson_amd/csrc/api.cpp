@@ -35,6 +35,8 @@ struct msj_ctx {
     uint32_t grid = 0;            // persistent workgroups per launch (CUs x resident blocks per CU)
     int32_t *tok_ws = nullptr;    // block aggregates of the token pre-pass
     uint64_t tok_ws_bytes = 0;
+    void *doc_ws = nullptr;       // block counts of the document split
+    uint64_t doc_ws_bytes = 0;
 };
 
 namespace {
@@ -117,6 +119,7 @@ int32_t enqueue_shard(msj_ctx *ctx, const uint8_t *d_buf, uint64_t len, uint32_t
         if (is_final && s + 1 == nseg) a.flags |= msj::kFlagFinal;
         if (has_prefix || s > 0) a.flags |= msj::kFlagHasPrefix;
         if (no_emit) a.flags |= msj::kFlagNoEmit;
+        if (s == 0) a.flags |= flags & (15u << msj::kFlagSkipShift);
         a.stamps = g_stamps;
         // ticket + descriptors must read as "not ready" at launch: this launch's buffer is clean
         // already in the steady state; the other one is cleaned by this launch if its dirt has
@@ -193,6 +196,7 @@ void msj_ctx_destroy(msj_ctx *ctx) {
     (void)hipSetDevice(ctx->device);
     if (ctx->ws) (void)hipFree(ctx->ws);
     if (ctx->tok_ws) (void)hipFree(ctx->tok_ws);
+    if (ctx->doc_ws) (void)hipFree(ctx->doc_ws);
     if (ctx->carries) (void)hipFree(ctx->carries);
     if (ctx->d_in) (void)hipFree(ctx->d_in);
     if (ctx->d_idx) (void)hipFree(ctx->d_idx);
@@ -262,6 +266,36 @@ int32_t msj_token_spans_device(msj_ctx *ctx, const uint8_t *d_buf, uint64_t len,
     if (len > MSJ_MAX_SEGMENT_BYTES) return MSJ_CAPACITY;
     if (!hip_ok(hipSetDevice(ctx->device))) return MSJ_ERR_HIP;
     return msj_launch_token_spans(d_buf, len, d_idx, n, d_end, d_flags, stream) == 0 ? MSJ_SUCCESS : MSJ_ERR_HIP;
+}
+
+extern "C" uint64_t msj_documents_workspace_bytes(uint64_t n);
+extern "C" int msj_launch_documents(const uint8_t *d_buf, uint64_t len, int is_final, const uint32_t *d_idx, uint64_t n,
+                                    const uint8_t *d_type, const int32_t *d_depth, const msj_carry *d_carry, uint32_t *d_doc_first, uint64_t capacity,
+                                    msj_documents_result *d_result, void *d_ws, void *stream);
+
+int32_t msj_documents_device(msj_ctx *ctx, const uint8_t *d_buf, uint64_t len, int32_t is_final, const uint32_t *d_idx,
+                             uint64_t n, const uint8_t *d_type, const int32_t *d_depth, const msj_carry *d_carry,
+                             uint32_t *d_doc_first, uint64_t capacity, msj_documents_result *d_result, void *stream) {
+    if (!ctx || !d_result) return MSJ_ERR_BAD_ARGUMENT;
+    if (n > 0 && (!d_buf || !d_idx || !d_type || !d_depth)) return MSJ_ERR_BAD_ARGUMENT;
+    if (capacity > 0 && !d_doc_first) return MSJ_ERR_BAD_ARGUMENT;
+    if (len > MSJ_MAX_SEGMENT_BYTES || n >= (1ull << 31)) return MSJ_CAPACITY;
+    if ((reinterpret_cast<uintptr_t>(d_depth) & 15u) || (reinterpret_cast<uintptr_t>(d_type) & 7u)) return MSJ_ERR_BAD_ARGUMENT;
+    if (!hip_ok(hipSetDevice(ctx->device))) return MSJ_ERR_HIP;
+    const uint64_t need = msj_documents_workspace_bytes(n);
+    if (need > ctx->doc_ws_bytes) {
+        if (ctx->doc_ws) {
+            (void)hipDeviceSynchronize();
+            (void)hipFree(ctx->doc_ws);
+        }
+        ctx->doc_ws = nullptr;
+        ctx->doc_ws_bytes = 0;
+        if (!hip_ok(hipMalloc(&ctx->doc_ws, need + need / 4))) return MSJ_MEMALLOC;
+        ctx->doc_ws_bytes = need + need / 4;
+    }
+    return msj_launch_documents(d_buf, len, is_final, d_idx, n, d_type, d_depth, d_carry, d_doc_first, capacity, d_result, ctx->doc_ws, stream) == 0
+               ? MSJ_SUCCESS
+               : MSJ_ERR_HIP;
 }
 
 int32_t msj_carry_fetch(msj_ctx *ctx, const msj_carry *d_carry, msj_carry *host_out, void *stream) {

@@ -33,6 +33,7 @@ constexpr uint32_t kFlagNoUtf8 = 2u;       // == MSJ_FLAG_NO_UTF8
 constexpr uint32_t kFlagFinal = 4u;        // last segment of the stream: trailer + return code
 constexpr uint32_t kFlagHasPrefix = 8u;    // buf[-64..0) holds the preceding stream bytes
 constexpr uint32_t kFlagNoEmit = 16u;      // summary pass: no index writes
+constexpr uint32_t kFlagSkipShift = 24u;   // bits 24..27 == MSJ_FLAG_SKIP(n): the first n < 16 bytes of the launch read as blanks
 
 struct KernelArgs {
     const uint8_t *buf;       // segment base, 16-byte aligned, device memory

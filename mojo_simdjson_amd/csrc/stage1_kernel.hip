@@ -304,6 +304,10 @@ __device__ __forceinline__ Pending compute_tile(const KernelArgs &a, const uint3
         valid = ~0ull;
     else
         valid = (1ull << (len - blk_off)) - 1ull;
+    // a window of a document stream starts at a document, its 16-byte aligned base up to 15 bytes
+    // earlier: those bytes (the end of the previous document) read as blanks
+    const uint32_t skip = tile == 0 ? (a.flags >> kFlagSkipShift) & 15u : 0u;  // uniform
+    if (skip && lane == 0) valid &= ~0ull << skip;
 
     // ---- carries into the tile from the 64 bytes in front of it (wave-uniform; apart from
     //      one compare + ballot for the backslash run this is scalar code on byte[-1..-3])
@@ -362,7 +366,7 @@ __device__ __forceinline__ Pending compute_tile(const KernelArgs &a, const uint3
     uint64_t p[8];
     bitplanes(x, p);
     Classes cls;
-    if (tile * kTileBytes + kTileBytes <= len) {  // uniform: every byte of the tile is input
+    if (tile * kTileBytes + kTileBytes <= len && !skip) {  // uniform: every byte of the tile is input
         cls = classify(p, ~0ull);
     } else {
 #pragma unroll

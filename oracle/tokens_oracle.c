@@ -113,3 +113,111 @@ void msj_oracle_token_spans(const uint8_t *buf, uint64_t len, const uint32_t *id
         flags[i] = (uint8_t)f;
     }
 }
+
+/*
+ * ---- multi-document mode -------------------------------------------
+ * PARITY UNPINNED: the reference has no streaming mode (json_structural_indexer.mojo:153,169 and
+ * tape_builder.mojo:25 "TODO: add streaming" mark where upstream simdjson's was left out).
+ *
+ * msj_oracle_documents is the DEFINITION of what csrc/documents_kernel.hip computes, as one forward
+ * walk: a document starts at every token at depth 0 that is not a closing bracket; the last one is
+ * complete if it is a container whose closing bracket -- a closing bracket at depth 0 -- comes after
+ * it, a closed string, or another scalar that cannot go on in the next window (the window is the end
+ * of the stream, or it ends in a blank).
+ *
+ * msj_oracle_find_next_document_index restates the published algorithm of upstream simdjson (the
+ * C++ library the reference ports; src/generic/stage1/find_next_document_index.h, with the
+ * streaming_partial step of json_structural_indexer::finish in front of it): a backward walk over
+ * the structurals that counts brackets until it meets the start of the last document.  The CPU
+ * tests check that both agree on well-formed streams cut at arbitrary points (with is_final = 1:
+ * upstream counts a number that touches the end of a window as complete); on malformed input
+ * they differ by design (upstream stops at the first plausible boundary, the definition above
+ * follows the depth).
+ */
+typedef struct {
+    uint64_t n_documents, n_complete, tokens_complete, resume_offset;
+} msj_documents_result;
+
+void msj_oracle_documents(const uint8_t *buf, uint64_t len, int is_final, const uint32_t *idx, uint64_t n,
+                          const uint8_t *type, const int32_t *depth, int open_string, uint32_t *doc_first, uint64_t capacity, msj_documents_result *res) {
+    uint64_t docs = 0, last_start = 0, last_close = 0;
+    int have_close = 0;
+    for (uint64_t i = 0; i < n; i++) {
+        const int closing = type[i] == '}' || type[i] == ']';
+        if (depth[i] != 0) continue;
+        if (closing) {
+            last_close = i;
+            have_close = 1;
+        } else {
+            if (docs < capacity) doc_first[docs] = (uint32_t)i;
+            docs++;
+            last_start = i;
+        }
+    }
+    res->n_documents = docs;
+    if (docs == 0) {
+        res->n_complete = 0;
+        res->tokens_complete = n;
+        res->resume_offset = len;
+        return;
+    }
+    int complete;
+    if (type[last_start] == '{' || type[last_start] == '[')
+        complete = have_close && last_close > last_start;
+    else if (last_start + 1 < n)
+        complete = 1; /* something follows the scalar */
+    else if (open_string)
+        complete = 0; /* the window ends inside the string this token opens */
+    else if (type[last_start] == '"' || is_final)
+        complete = 1;
+    else /* a number or a literal that touches the end of the window may go on in the next one */
+        complete = buf[len - 1] == ' ' || buf[len - 1] == '\n' || buf[len - 1] == '\r' || buf[len - 1] == '\t';
+    res->n_complete = docs - (complete ? 0 : 1);
+    res->tokens_complete = complete ? n : last_start;
+    res->resume_offset = complete ? len : idx[last_start];
+}
+
+/* returns the number of structurals that belong to complete documents (upstream: the new
+ * n_structural_indexes of a streaming_partial window); *error = 1 where upstream returns an error
+ * (nothing left after dropping the unclosed string's quote) */
+uint64_t msj_oracle_find_next_document_index(const uint8_t *buf, const uint32_t *idx, uint64_t n, int open_string, int *error) {
+    *error = 0;
+    if (open_string) {  /* the quote that opens the unclosed string is not part of this window */
+        if (n == 0) {
+            *error = 1;
+            return 0;
+        }
+        n--;
+    }
+    if (n == 0) {
+        *error = 1;
+        return 0;
+    }
+    int64_t arr_cnt = 0, obj_cnt = 0;
+    for (uint64_t i = n - 1; i > 0; i--) {
+        const uint8_t b = buf[idx[i]];
+        if (b == ':' || b == ',') continue;
+        if (b == '}') {
+            obj_cnt--;
+            continue;
+        }
+        if (b == ']') {
+            arr_cnt--;
+            continue;
+        }
+        if (b == '{') obj_cnt++;
+        if (b == '[') arr_cnt++;
+        const uint8_t a = buf[idx[i - 1]];
+        if (a == '{' || a == '[' || a == ':' || a == ',') continue;
+        /* token i starts a document */
+        if (arr_cnt == 0 && obj_cnt == 0) return n; /* and that document is complete */
+        return i;
+    }
+    const uint8_t f = buf[idx[0]];
+    if (f == '}') obj_cnt--;
+    if (f == ']') arr_cnt--;
+    if (f == '{') obj_cnt++;
+    if (f == '[') arr_cnt++;
+    if (arr_cnt == 0 && obj_cnt == 0) return n;
+    return 0;
+}

@@ -84,6 +84,54 @@ def oracle_token_spans(data, idx):
     return end[:idx.size], flags[:idx.size]
 
 
+def oracle_documents(data, idx, typ, dep, open_string=False, capacity=None, is_final=False):
+    """Definition of the document split (oracle/tokens_oracle.c: msj_oracle_documents):
+    (doc_first uint32[min(n_documents, capacity)], (n_documents, n_complete, tokens_complete, resume_offset))."""
+    lib = ctypes.CDLL(TOKENS_SO)
+    idx = np.ascontiguousarray(idx, dtype=np.uint32)
+    typ = np.ascontiguousarray(typ, dtype=np.uint8)
+    dep = np.ascontiguousarray(dep, dtype=np.int32)
+    n = idx.size
+    cap = n if capacity is None else capacity
+    first = np.zeros(max(cap, 1), dtype=np.uint32)
+    res = (ctypes.c_uint64 * 4)()
+    lib.msj_oracle_documents(ctypes.c_char_p(bytes(data)), ctypes.c_uint64(len(data)), ctypes.c_int(int(is_final)),
+                             idx.ctypes.data_as(ctypes.c_void_p), ctypes.c_uint64(n), typ.ctypes.data_as(ctypes.c_void_p),
+                             dep.ctypes.data_as(ctypes.c_void_p), ctypes.c_int(int(open_string)),
+                             first.ctypes.data_as(ctypes.c_void_p), ctypes.c_uint64(cap), res)
+    r = tuple(int(v) for v in res)
+    return first[: min(r[0], cap)], r
+
+
+def oracle_find_next_document_index(data, idx, open_string=False):
+    """Upstream simdjson's backward scan, restated (oracle/tokens_oracle.c): (kept structurals, error)."""
+    lib = ctypes.CDLL(TOKENS_SO)
+    lib.msj_oracle_find_next_document_index.restype = ctypes.c_uint64
+    idx = np.ascontiguousarray(idx, dtype=np.uint32)
+    err = ctypes.c_int(0)
+    keep = lib.msj_oracle_find_next_document_index(ctypes.c_char_p(bytes(data)), idx.ctypes.data_as(ctypes.c_void_p),
+                                                   ctypes.c_uint64(idx.size), ctypes.c_int(int(open_string)), ctypes.byref(err))
+    return int(keep), int(err.value)
+
+
+def oracle_window(fn, data):
+    """Structural indices of a WINDOW of a stream (nothing is an error yet at its end): the stage-1 oracle
+    on the window, with the string it may end in closed by hand (bytes inside a string are never structural,
+    the closing quote is not either).  -> (idx uint32[n], open_string)."""
+    data = bytes(data)
+    for k, tail in enumerate((b"", b'"', b'\\"')):
+        rc, n, idx = run_oracle(fn, data + tail)
+        if rc == 15:
+            continue
+        if rc == 13:
+            return np.zeros(0, dtype=np.uint32), k > 0
+        assert rc == 0, rc
+        keep = idx[:n]
+        assert n == 0 or keep[-1] < len(data)
+        return keep.copy(), k > 0
+    raise AssertionError("window does not close")
+
+
 SENTINEL = 0xDEADBEEF
 
 
