@@ -19,6 +19,7 @@
 // start.  HBM-bound: 4 B index + the gathered byte + 1 B type out, then 1 B type in + 4 B depth
 // out per structural.
 #include <hip/hip_runtime.h>
+#include <stdlib.h>
 #include <stdint.h>
 
 #include "../../include/msj_stage1.h"
@@ -472,49 +473,66 @@ __device__ __forceinline__ uint64_t load8(const uint8_t *p) {
 }
 __device__ __forceinline__ bool is_blank(uint32_t b) { return b == 0x20u || b == 0x09u || b == 0x0Au || b == 0x0Du; }
 
-__global__ __launch_bounds__(256) void token_spans(const uint8_t *__restrict__ buf, uint64_t len, const uint32_t *__restrict__ idx,
-                                                   uint64_t n, uint32_t *__restrict__ end, uint8_t *__restrict__ flags) {
-    const uint64_t i = (uint64_t)blockIdx.x * 256u + threadIdx.x;
-    if (i >= n) return;
-    const uint64_t start = idx[i];
-    const uint64_t next = (i + 1 < n) ? (uint64_t)idx[i + 1] : len;
-    const uint32_t c = buf[start];
-    uint32_t e = 0, f = 0;
+// where the bytes come from: global memory, or the workgroup's stretch of the buffer staged in LDS
+struct FromGlobal {
+    const uint8_t *buf;
+    uint64_t len;
+    __device__ __forceinline__ uint32_t byte(uint64_t pos) const { return buf[pos]; }
+    // aligned 8-byte word; bytes past the buffer read as blanks
+    __device__ __forceinline__ uint64_t word(uint64_t wa) const {
+        if (wa + 8 <= len) return load8(buf + wa);
+        uint64_t w = 0x2020202020202020ull;
+        for (uint64_t b = wa; b < len; b++) w = (w & ~(0xFFull << (8 * (b - wa)))) | ((uint64_t)buf[b] << (8 * (b - wa)));
+        return w;
+    }
+};
+struct FromLds {
+    const uint8_t *lds;  // lds[0] = byte `lo` of the buffer; staged [lo, hi_al), blanks past the buffer
+    uint64_t lo, hi_al;
+    __device__ __forceinline__ uint32_t byte(uint64_t pos) const { return lds[pos - lo]; }
+    __device__ __forceinline__ uint64_t word(uint64_t wa) const {
+        if (wa + 8 > hi_al) return 0x2020202020202020ull;  // past the next structural: never part of this token
+        const uint2 w = *reinterpret_cast<const uint2 *>(lds + (wa - lo));
+        return ((uint64_t)w.y << 32) | w.x;
+    }
+};
+
+// token [start, next): next = offset of the next structural (len for the last token)
+template <class Src>
+__device__ __forceinline__ void span_of(const Src &src, uint64_t start, uint64_t next, uint64_t len, uint32_t &e, uint32_t &f) {
+    const uint32_t c = src.byte(start);
+    e = 0;
+    f = 0;
     if (c == '"') {
         f = MSJ_SPAN_STRING;
         uint64_t q = next;  // exclusive end of the candidate region
-        while (q > start + 1 && is_blank(buf[q - 1])) q--;
+        while (q > start + 1 && is_blank(src.byte(q - 1))) q--;
         bool closed = false;
-        if (q > start + 1 && buf[q - 1] == '"') {
+        if (q > start + 1 && src.byte(q - 1) == '"') {
             uint64_t k = q - 1;  // unescaped iff an even number of backslashes stands right in front of it
-            while (k > start + 1 && buf[k - 1] == '\\') k--;
+            while (k > start + 1 && src.byte(k - 1) == '\\') k--;
             closed = (((q - 1) - k) & 1u) == 0;
         }
-        if (!closed) {
-            e = (uint32_t)len;  // only the last token can be like this (stage 1 reports UNCLOSED_STRING)
-            f |= MSJ_SPAN_OPEN;
-        } else {
+        if (closed) {
             const uint64_t close = q - 1;
-            e = (uint32_t)close;
             const uint64_t b0 = start + 1;  // body = [b0, close)
             if (close - b0 > kSpanCap) {
                 f |= MSJ_SPAN_LONG;
             } else if (close > b0) {
                 uint64_t acc = 0;
                 const uint64_t w0 = b0 & ~7ull, w1 = (close - 1) & ~7ull;  // first and last aligned word
-                if (w1 + 8 <= len) {
-                    for (uint64_t w = w0; w <= w1; w += 8) {
-                        uint64_t z = zero_bytes(load8(buf + w) ^ 0x5C5C5C5C5C5C5C5Cull);
-                        if (w == w0) z &= ~0ull << (8 * (b0 - w0));
-                        if (w == w1) z &= ~0ull >> (8 * (7 - ((close - 1) - w1)));
-                        acc |= z;
-                    }
-                } else {  // the last word would reach past the buffer: byte by byte
-                    for (uint64_t j = b0; j < close; j++) acc |= (buf[j] == '\\');
+                for (uint64_t w = w0; w <= w1; w += 8) {
+                    uint64_t z = zero_bytes(src.word(w) ^ 0x5C5C5C5C5C5C5C5Cull);
+                    if (w == w0) z &= ~0ull << (8 * (b0 - w0));
+                    if (w == w1) z &= ~0ull >> (8 * (7 - ((close - 1) - w1)));
+                    acc |= z;
                 }
                 if (acc) f |= MSJ_SPAN_ESCAPED;
             }
+        } else {
+            f |= MSJ_SPAN_OPEN;  // only the last token can be like this (stage 1 reports UNCLOSED_STRING)
         }
+        e = closed ? (uint32_t)(q - 1) : (uint32_t)len;
     } else if (c == '-' || (c >= '0' && c <= '9')) {
         f = MSJ_SPAN_NUMBER;
         // the four aligned words that hold the next 25..32 bytes, requested together (numbers are short:
@@ -522,15 +540,7 @@ __global__ __launch_bounds__(256) void token_spans(const uint8_t *__restrict__ b
         const uint64_t w0 = start & ~7ull;
         uint64_t W[4];
 #pragma unroll
-        for (int k = 0; k < 4; k++) {
-            const uint64_t wa = w0 + 8u * k;
-            if (wa + 8 <= len) {
-                W[k] = load8(buf + wa);
-            } else {
-                W[k] = 0x2020202020202020ull;
-                for (uint64_t b = wa; b < len; b++) W[k] = (W[k] & ~(0xFFull << (8 * (b - wa)))) | ((uint64_t)buf[b] << (8 * (b - wa)));
-            }
-        }
+        for (int k = 0; k < 4; k++) W[k] = src.word(w0 + 8u * k);
         bool done = false;
         uint64_t j = start + 1;
 #pragma unroll
@@ -552,10 +562,10 @@ __global__ __launch_bounds__(256) void token_spans(const uint8_t *__restrict__ b
             }
         }
         if (j > len) j = len;
-        if (!done && j < len) {  // longer than the four words: byte by byte from memory
+        if (!done && j < len) {  // longer than the four words: byte by byte (never past the next structural)
             const uint64_t stop = (start + 1 + kSpanCap < len) ? start + 1 + kSpanCap : len;
             for (; j < stop; j++) {
-                const uint32_t b = buf[j];
+                const uint32_t b = src.byte(j);
                 if (b == '.' || b == 'e' || b == 'E')
                     f |= MSJ_SPAN_FLOAT;
                 else if (!((b >= '0' && b <= '9') || b == '+' || b == '-'))
@@ -568,6 +578,155 @@ __global__ __launch_bounds__(256) void token_spans(const uint8_t *__restrict__ b
         }
         e = (uint32_t)j;
     }
+}
+
+// One thread per structural, kSpanTokens per workgroup.  The workgroup's tokens cover one contiguous
+// stretch of the buffer, [idx[first], idx[first of the next workgroup]].  It is staged in LDS with
+// coalesced 16-byte reads, and while a thread holds its 16 bytes it classifies them ONCE: one bit per
+// byte for "can be part of a number" ([0-9+-.eE]), "makes it a float" ([.eE]) and "backslash".  A
+// token then needs a handful of LDS reads: the end of a number is the first clear bit behind its
+// start, its float flag and a string's escape flag are "any bit set in a range".  Work per byte
+// instead of work per token times its length.  A stretch over kSpanLds bytes (long strings) takes
+// the per-token path from global memory (span_of) instead.
+constexpr uint32_t kSpanTokens = 256;
+constexpr uint32_t kSpanLds = 16384;
+constexpr uint32_t kSpanMaskWords = kSpanLds / 32 + 2;  // one bit per staged byte, + the word a window may reach into
+
+// bit 7 of every byte of x that equals c / that is an ASCII digit; exact (no carries between bytes)
+__device__ __forceinline__ uint32_t eq_bytes(uint32_t x, uint32_t c) {
+    const uint32_t z = x ^ (c * 0x01010101u);
+    return ~(((z & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | z) & 0x80808080u;
+}
+__device__ __forceinline__ uint32_t digit_bytes(uint32_t x) {
+    const uint32_t d = x ^ 0x30303030u;  // '0'..'9' -> 0..9
+    return ~(((d & 0x7F7F7F7Fu) + 0x76767676u) | d) & 0x80808080u;  // low 7 bits < 10 and bit 7 clear
+}
+// bits 7, 15, 23, 31 -> bits 0..3
+__device__ __forceinline__ uint32_t nibble_of(uint32_t m) { return (((m >> 7) * 0x01020408u) >> 24) & 0xFu; }
+
+// 32 bits of a bitmap starting at bit `pos`
+__device__ __forceinline__ uint32_t bits_at(const uint32_t *map, uint32_t pos) {
+    const uint32_t w = pos >> 5;
+    return __funnelshift_r(map[w], map[w + 1], pos & 31u);
+}
+// any bit set in [b0, b1)?  b1 > b0
+__device__ __forceinline__ bool any_bits(const uint32_t *map, uint32_t b0, uint32_t b1) {
+    const uint32_t w0 = b0 >> 5, w1 = (b1 - 1u) >> 5;
+    uint32_t acc = 0;
+    for (uint32_t w = w0; w <= w1; w++) {
+        uint32_t m = map[w];
+        if (w == w0) m &= ~0u << (b0 & 31u);
+        if (w == w1) m &= ~0u >> (31u - ((b1 - 1u) & 31u));
+        acc |= m;
+    }
+    return acc != 0;
+}
+
+__global__ __launch_bounds__(kSpanTokens) void token_spans(const uint8_t *__restrict__ buf, uint64_t len, const uint32_t *__restrict__ idx,
+                                                           uint64_t n, uint32_t *__restrict__ end, uint8_t *__restrict__ flags, uint32_t lds_limit) {
+    __shared__ __attribute__((aligned(16))) uint8_t stage[kSpanLds];
+    __shared__ uint32_t m_num[kSpanMaskWords], m_flt[kSpanMaskWords], m_bs[kSpanMaskWords];
+    const uint64_t first = (uint64_t)blockIdx.x * kSpanTokens;
+    const uint64_t i = first + threadIdx.x;
+    const uint64_t after = first + kSpanTokens < n ? first + kSpanTokens : n;  // first token of the next workgroup
+    // uniform: the stretch [lo, hi) -- through the byte at the next workgroup's first structural
+    const uint64_t lo = (uint64_t)idx[first] & ~15ull;
+    const uint64_t hi = after < n ? (uint64_t)idx[after] + 1u : len;
+    const uint64_t hi_al = (hi + 15u) & ~15ull;
+    const bool staged = hi_al - lo <= lds_limit;  // lds_limit <= kSpanLds
+    if (!staged) {
+        if (i >= n) return;
+        const uint64_t start = idx[i];
+        const uint64_t next = (i + 1 < n) ? (uint64_t)idx[i + 1] : len;
+        uint32_t e, f;
+        span_of(FromGlobal{buf, len}, start, next, len, e, f);
+        end[i] = e;
+        flags[i] = (uint8_t)f;
+        return;
+    }
+    const uint32_t span = (uint32_t)(hi_al - lo);
+    for (uint32_t o = 16u * threadIdx.x; o < span; o += 16u * kSpanTokens) {
+        const uint64_t g = lo + o;
+        uint32_t w[4];
+        if (g + 16 <= len) {
+            const uint4 v = *reinterpret_cast<const uint4 *>(buf + g);
+            w[0] = v.x, w[1] = v.y, w[2] = v.z, w[3] = v.w;
+        } else {  // the buffer ends inside this piece: blanks behind it
+            w[0] = w[1] = w[2] = w[3] = 0x20202020u;
+            for (uint64_t b = g; b < len; b++) {
+                const uint32_t k = (uint32_t)(b - g);
+                const uint32_t sh = 8u * (k & 3u), v = (uint32_t)buf[b] << sh, keep = ~(0xFFu << sh);
+                if ((k >> 2) == 0) w[0] = (w[0] & keep) | v;
+                if ((k >> 2) == 1) w[1] = (w[1] & keep) | v;
+                if ((k >> 2) == 2) w[2] = (w[2] & keep) | v;
+                if ((k >> 2) == 3) w[3] = (w[3] & keep) | v;
+            }
+        }
+        *reinterpret_cast<uint4 *>(stage + o) = make_uint4(w[0], w[1], w[2], w[3]);
+        uint32_t num = 0, flt = 0, bs = 0;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const uint32_t x = w[k];
+            const uint32_t fl = eq_bytes(x, '.') | eq_bytes(x | 0x20202020u, 'e');
+            const uint32_t nu = fl | digit_bytes(x) | eq_bytes(x, '+') | eq_bytes(x, '-');
+            num |= nibble_of(nu) << (4 * k);
+            flt |= nibble_of(fl) << (4 * k);
+            bs |= nibble_of(eq_bytes(x, '\\')) << (4 * k);
+        }
+        reinterpret_cast<uint16_t *>(m_num)[o >> 4] = (uint16_t)num;
+        reinterpret_cast<uint16_t *>(m_flt)[o >> 4] = (uint16_t)flt;
+        reinterpret_cast<uint16_t *>(m_bs)[o >> 4] = (uint16_t)bs;
+    }
+    __syncthreads();
+    if (i >= n) return;
+    // offsets relative to lo from here on (< kSpanLds)
+    const uint64_t start = idx[i];
+    const uint32_t rs = (uint32_t)(start - lo);
+    const uint32_t rn = (i + 1 < n) ? (uint32_t)((uint64_t)idx[i + 1] - lo) : (uint32_t)(len - lo);
+    const uint32_t rlen = (len - lo < (uint64_t)span) ? (uint32_t)(len - lo) : span;  // end of the buffer within the stretch
+    const uint32_t c = stage[rs];
+    uint32_t e = 0, f = 0;
+    if (c == '"') {
+        f = MSJ_SPAN_STRING;
+        uint32_t q = rn;  // exclusive end of the candidate region
+        while (q > rs + 1 && is_blank(stage[q - 1])) q--;
+        bool closed = false;
+        if (q > rs + 1 && stage[q - 1] == '"') {
+            uint32_t k = q - 1;  // unescaped iff an even number of backslashes stands right in front of it
+            while (k > rs + 1 && stage[k - 1] == '\\') k--;
+            closed = (((q - 1) - k) & 1u) == 0;
+        }
+        if (closed) {
+            const uint32_t b0 = rs + 1, close = q - 1;  // body = [b0, close)
+            if (close - b0 > kSpanCap)
+                f |= MSJ_SPAN_LONG;
+            else if (close > b0 && any_bits(m_bs, b0, close))
+                f |= MSJ_SPAN_ESCAPED;
+        } else {
+            f |= MSJ_SPAN_OPEN;  // only the last token can be like this (stage 1 reports UNCLOSED_STRING)
+        }
+        e = closed ? (uint32_t)(lo + (q - 1)) : (uint32_t)len;
+    } else if (c == '-' || (c >= '0' && c <= '9')) {
+        f = MSJ_SPAN_NUMBER;
+        // the first byte behind the start that cannot be part of a number = the first clear bit: always
+        // at or before the next structural, which is staged -- except at the end of the buffer (rlen)
+        const uint32_t stop = (rs + 1 + kSpanCap < rlen) ? rs + 1 + kSpanCap : rlen;
+        uint32_t p = rs + 1;
+        while (p < stop) {
+            const uint32_t run = ~bits_at(m_num, p);
+            if (run) {
+                p += __ffs(run) - 1u;
+                break;
+            }
+            p += 32;
+        }
+        if (p > stop) p = stop;
+        if (p > rs + 1 && any_bits(m_flt, rs + 1, p)) f |= MSJ_SPAN_FLOAT;
+        if (p == stop && lo + stop < len)  // kSpanCap characters and still no end
+            f |= MSJ_SPAN_LONG;
+        else
+            e = (uint32_t)(lo + p);
+    }
     end[i] = e;
     flags[i] = (uint8_t)f;
 }
@@ -576,7 +735,11 @@ __global__ __launch_bounds__(256) void token_spans(const uint8_t *__restrict__ b
 extern "C" int msj_launch_token_spans(const uint8_t *d_buf, uint64_t len, const uint32_t *d_idx, uint64_t n, uint32_t *d_end,
                                       uint8_t *d_flags, void *stream) {
     if (n == 0) return 0;
-    hipLaunchKernelGGL(msj_tokens::token_spans, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream),
-                       d_buf, len, d_idx, n, d_end, d_flags);
+    // MSJ_SPANS_LDS_LIMIT (tests): stretches over this many bytes take the global-memory path
+    const char *env = getenv("MSJ_SPANS_LDS_LIMIT");
+    const unsigned long lim = env ? strtoul(env, nullptr, 10) : msj_tokens::kSpanLds;
+    const uint32_t lds_limit = (uint32_t)(lim < msj_tokens::kSpanLds ? lim : msj_tokens::kSpanLds);
+    hipLaunchKernelGGL(msj_tokens::token_spans, dim3((uint32_t)((n + msj_tokens::kSpanTokens - 1) / msj_tokens::kSpanTokens)), dim3(msj_tokens::kSpanTokens), 0,
+                       static_cast<hipStream_t>(stream), d_buf, len, d_idx, n, d_end, d_flags, lds_limit);
     return (int)hipGetLastError();
 }

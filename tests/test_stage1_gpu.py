@@ -727,4 +727,10 @@ def test_abi_argument_errors(torch_mod, dev):
     assert lib.msj_tokens_device(dev.ctx, p(d_buf), 64, p(d_idx), 1 << 31, p(d_t), p(d_d), None, p(d_r), None) == 1  # too many tokens
     assert lib.msj_tokens_device(dev.ctx, p(d_buf), 64, p(d_idx), 0, None, None, None, p(d_r), None) == 0            # nothing to do is fine
     assert lib.msj_token_spans_device(dev.ctx, p(d_buf), 64, p(d_idx), 4, None, None, None) == -1
+    d_docs = torch.zeros(32, dtype=torch.uint8, device=dev.device)
+    assert lib.msj_documents_device(dev.ctx, p(d_buf), 64, 0, p(d_idx), 4, p(d_t), p(d_d), None, None, 0, None, None) == -1        # no result
+    assert lib.msj_documents_device(dev.ctx, p(d_buf), 64, 0, p(d_idx), 4, p(d_t), p(d_d), None, None, 8, p(d_docs), None) == -1  # capacity without a list
+    assert lib.msj_documents_device(dev.ctx, p(d_buf), 64, 0, p(d_idx), 4, p(d_t), p(d_d, 4), None, None, 0, p(d_docs), None) == -1
+    assert lib.msj_documents_device(dev.ctx, None, 64, 0, p(d_idx), 4, p(d_t), p(d_d), None, None, 0, p(d_docs), None) == -1
+    assert lib.msj_documents_device(dev.ctx, None, 0, 1, None, 0, None, None, None, None, 0, p(d_docs), None) == 0                # an empty window is fine
     torch.cuda.synchronize()

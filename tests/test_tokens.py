@@ -121,8 +121,14 @@ def _check_spans(dev, data, where):
 
 
 @pytest.mark.gpu
-def test_token_spans(dev):
+@pytest.mark.parametrize("lds_limit", ["", "0", "4096"])
+def test_token_spans(dev, lds_limit, monkeypatch):
+    """Both paths of the kernel: the workgroup's stretch staged in LDS with per-byte class bitmaps (default),
+    and the per-token path from global memory that long stretches take (forced by a limit of 0; 4096 mixes them)."""
     from mojo_simdjson_amd import synth
+
+    if lds_limit:
+        monkeypatch.setenv("MSJ_SPANS_LDS_LIMIT", lds_limit)
 
     for f in helpers.golden_valid_files():
         js, _ = helpers.read_fixture(f)
@@ -132,6 +138,14 @@ def test_token_spans(dev):
     _check_spans(dev, b'["' + b"a" * 5000 + b'", ' + b"9" * 3000 + b', "tail\\', "long spans and an escape at the very end")
     _check_spans(dev, b'"' + b"\\" * 600 + b'"', "cap reached inside an escape")
     _check_spans(dev, b"-", "one byte")
+    # numbers around the cap of 1 024 characters, at the end of the buffer, on and off the 16-byte grid
+    for digits in (1, 15, 16, 31, 32, 33, 63, 64, 65, 1023, 1024, 1025, 1026, 2000):
+        for tail in (b"", b" ", b",1]", b"e5 ", b"." + b"0" * 20):
+            for pad in (0, 5, 13):
+                _check_spans(dev, b" " * pad + b"[" + b"7" * digits + tail, f"number of {digits} digits + {tail!r} at {pad}")
+    _check_spans(dev, b"[" + b"1.5e+3," * 4000 + b"-0.25E-7]", "floats over several workgroups")
+    # a long string in the middle of many short tokens: its workgroup reads from global memory, the others stage
+    _check_spans(dev, b"[" + b'"a\\b",12,' * 3000 + b'"' + b"x" * 40000 + b'",' + b'"cd",3.5,' * 3000 + b"0]", "mixed paths")
     _check_spans(dev, b'["a"  ,"b\\"" , "c\\\\"  ]  ', "blanks between the closing quote and the next structural")
     # the closing quote is found from the NEXT structural: byte soups (valid or not) must agree with the forward scan
     rng = np.random.default_rng(9)
