@@ -588,8 +588,10 @@ __device__ __forceinline__ void span_of(const Src &src, uint64_t start, uint64_t
 // start, its float flag and a string's escape flag are "any bit set in a range".  Work per byte
 // instead of work per token times its length.  A stretch over kSpanLds bytes (long strings) takes
 // the per-token path from global memory (span_of) instead.
-constexpr uint32_t kSpanTokens = 256;
-constexpr uint32_t kSpanLds = 16384;
+constexpr uint32_t kSpanThreads = 256;
+constexpr int kSpanPer = 2;  // tokens per thread
+constexpr uint32_t kSpanTokens = kSpanThreads * kSpanPer;  // per workgroup
+constexpr uint32_t kSpanLds = 12288;  // + four bitmaps of 1.5 KiB: 8 workgroups (32 waves) per CU
 constexpr uint32_t kSpanMaskWords = kSpanLds / 32 + 2;  // one bit per staged byte, + the word a window may reach into
 
 // bit 7 of every byte of x that equals c / that is an ASCII digit; exact (no carries between bytes)
@@ -602,7 +604,7 @@ __device__ __forceinline__ uint32_t digit_bytes(uint32_t x) {
     return ~(((d & 0x7F7F7F7Fu) + 0x76767676u) | d) & 0x80808080u;  // low 7 bits < 10 and bit 7 clear
 }
 // bits 7, 15, 23, 31 -> bits 0..3
-__device__ __forceinline__ uint32_t nibble_of(uint32_t m) { return (((m >> 7) * 0x01020408u) >> 24) & 0xFu; }
+__device__ __forceinline__ uint32_t nibble_of(uint32_t m) { return ((((m & 0x80808080u) >> 7) * 0x01020408u) >> 24) & 0xFu; }
 
 // 32 bits of a bitmap starting at bit `pos`
 __device__ __forceinline__ uint32_t bits_at(const uint32_t *map, uint32_t pos) {
@@ -622,74 +624,34 @@ __device__ __forceinline__ bool any_bits(const uint32_t *map, uint32_t b0, uint3
     return acc != 0;
 }
 
-__global__ __launch_bounds__(kSpanTokens) void token_spans(const uint8_t *__restrict__ buf, uint64_t len, const uint32_t *__restrict__ idx,
-                                                           uint64_t n, uint32_t *__restrict__ end, uint8_t *__restrict__ flags, uint32_t lds_limit) {
-    __shared__ __attribute__((aligned(16))) uint8_t stage[kSpanLds];
-    __shared__ uint32_t m_num[kSpanMaskWords], m_flt[kSpanMaskWords], m_bs[kSpanMaskWords];
-    const uint64_t first = (uint64_t)blockIdx.x * kSpanTokens;
-    const uint64_t i = first + threadIdx.x;
-    const uint64_t after = first + kSpanTokens < n ? first + kSpanTokens : n;  // first token of the next workgroup
-    // uniform: the stretch [lo, hi) -- through the byte at the next workgroup's first structural
-    const uint64_t lo = (uint64_t)idx[first] & ~15ull;
-    const uint64_t hi = after < n ? (uint64_t)idx[after] + 1u : len;
-    const uint64_t hi_al = (hi + 15u) & ~15ull;
-    const bool staged = hi_al - lo <= lds_limit;  // lds_limit <= kSpanLds
-    if (!staged) {
-        if (i >= n) return;
-        const uint64_t start = idx[i];
-        const uint64_t next = (i + 1 < n) ? (uint64_t)idx[i + 1] : len;
-        uint32_t e, f;
-        span_of(FromGlobal{buf, len}, start, next, len, e, f);
-        end[i] = e;
-        flags[i] = (uint8_t)f;
-        return;
-    }
-    const uint32_t span = (uint32_t)(hi_al - lo);
-    for (uint32_t o = 16u * threadIdx.x; o < span; o += 16u * kSpanTokens) {
-        const uint64_t g = lo + o;
-        uint32_t w[4];
-        if (g + 16 <= len) {
-            const uint4 v = *reinterpret_cast<const uint4 *>(buf + g);
-            w[0] = v.x, w[1] = v.y, w[2] = v.z, w[3] = v.w;
-        } else {  // the buffer ends inside this piece: blanks behind it
-            w[0] = w[1] = w[2] = w[3] = 0x20202020u;
-            for (uint64_t b = g; b < len; b++) {
-                const uint32_t k = (uint32_t)(b - g);
-                const uint32_t sh = 8u * (k & 3u), v = (uint32_t)buf[b] << sh, keep = ~(0xFFu << sh);
-                if ((k >> 2) == 0) w[0] = (w[0] & keep) | v;
-                if ((k >> 2) == 1) w[1] = (w[1] & keep) | v;
-                if ((k >> 2) == 2) w[2] = (w[2] & keep) | v;
-                if ((k >> 2) == 3) w[3] = (w[3] & keep) | v;
-            }
-        }
-        *reinterpret_cast<uint4 *>(stage + o) = make_uint4(w[0], w[1], w[2], w[3]);
-        uint32_t num = 0, flt = 0, bs = 0;
-#pragma unroll
-        for (int k = 0; k < 4; k++) {
-            const uint32_t x = w[k];
-            const uint32_t fl = eq_bytes(x, '.') | eq_bytes(x | 0x20202020u, 'e');
-            const uint32_t nu = fl | digit_bytes(x) | eq_bytes(x, '+') | eq_bytes(x, '-');
-            num |= nibble_of(nu) << (4 * k);
-            flt |= nibble_of(fl) << (4 * k);
-            bs |= nibble_of(eq_bytes(x, '\\')) << (4 * k);
-        }
-        reinterpret_cast<uint16_t *>(m_num)[o >> 4] = (uint16_t)num;
-        reinterpret_cast<uint16_t *>(m_flt)[o >> 4] = (uint16_t)flt;
-        reinterpret_cast<uint16_t *>(m_bs)[o >> 4] = (uint16_t)bs;
-    }
-    __syncthreads();
-    if (i >= n) return;
+// one token from the staged stretch; offsets relative to lo (< kSpanLds)
+__device__ __forceinline__ void staged_token(const uint8_t *stage, const uint32_t *m_num, const uint32_t *m_flt, const uint32_t *m_bs,
+                                             const uint32_t *m_ink, uint64_t lo, uint32_t span, uint64_t len, uint64_t start, uint64_t next,
+                                             uint32_t &e_out, uint32_t &f_out) {
     // offsets relative to lo from here on (< kSpanLds)
-    const uint64_t start = idx[i];
     const uint32_t rs = (uint32_t)(start - lo);
-    const uint32_t rn = (i + 1 < n) ? (uint32_t)((uint64_t)idx[i + 1] - lo) : (uint32_t)(len - lo);
+    const uint32_t rn = (uint32_t)(next - lo);
     const uint32_t rlen = (len - lo < (uint64_t)span) ? (uint32_t)(len - lo) : span;  // end of the buffer within the stretch
     const uint32_t c = stage[rs];
     uint32_t e = 0, f = 0;
     if (c == '"') {
         f = MSJ_SPAN_STRING;
-        uint32_t q = rn;  // exclusive end of the candidate region
-        while (q > rs + 1 && is_blank(stage[q - 1])) q--;
+        // exclusive end of the candidate region: behind the last non-blank byte in (rs, rn) -- pretty-printed
+        // input has a line break and its indentation between a value and the closing bracket
+        uint32_t q = rs + 1;
+        if (rn > rs + 1) {
+            const uint32_t w0 = (rs + 1) >> 5;
+            for (uint32_t w = (rn - 1) >> 5;; w--) {
+                uint32_t m = m_ink[w];
+                if (w == (rn - 1) >> 5) m &= ~0u >> (31u - ((rn - 1) & 31u));
+                if (w == w0) m &= ~0u << ((rs + 1) & 31u);
+                if (m) {
+                    q = 32u * w + 32u - __clz(m);
+                    break;
+                }
+                if (w == w0) break;
+            }
+        }
         bool closed = false;
         if (q > rs + 1 && stage[q - 1] == '"') {
             uint32_t k = q - 1;  // unescaped iff an even number of backslashes stands right in front of it
@@ -727,8 +689,87 @@ __global__ __launch_bounds__(kSpanTokens) void token_spans(const uint8_t *__rest
         else
             e = (uint32_t)(lo + p);
     }
-    end[i] = e;
-    flags[i] = (uint8_t)f;
+    e_out = e;
+    f_out = f;
+}
+
+__global__ __launch_bounds__(kSpanThreads) void token_spans(const uint8_t *__restrict__ buf, uint64_t len, const uint32_t *__restrict__ idx,
+                                                           uint64_t n, uint32_t *__restrict__ end, uint8_t *__restrict__ flags, uint32_t lds_limit) {
+    __shared__ __attribute__((aligned(16))) uint8_t stage[kSpanLds];
+    __shared__ uint32_t m_num[kSpanMaskWords], m_flt[kSpanMaskWords], m_bs[kSpanMaskWords], m_ink[kSpanMaskWords];
+    const uint64_t first = (uint64_t)blockIdx.x * kSpanTokens;
+    uint64_t tok[kSpanPer];  // this thread's tokens: threadIdx.x, threadIdx.x + kSpanThreads, ...
+#pragma unroll
+    for (int k = 0; k < kSpanPer; k++) tok[k] = first + threadIdx.x + (uint32_t)k * kSpanThreads;
+    const uint64_t after = first + kSpanTokens < n ? first + kSpanTokens : n;  // first token of the next workgroup
+    // uniform: the stretch [lo, hi) -- through the byte at the next workgroup's first structural
+    const uint64_t lo = (uint64_t)idx[first] & ~15ull;
+    const uint64_t hi = after < n ? (uint64_t)idx[after] + 1u : len;
+    const uint64_t hi_al = (hi + 15u) & ~15ull;
+    // this thread's tokens, requested together with the stretch bounds (not behind the barrier below)
+    uint64_t start[kSpanPer], next[kSpanPer];
+#pragma unroll
+    for (int k = 0; k < kSpanPer; k++) {
+        start[k] = tok[k] < n ? (uint64_t)idx[tok[k]] : 0;
+        next[k] = (tok[k] + 1 < n) ? (uint64_t)idx[tok[k] + 1] : len;
+    }
+    const bool staged = hi_al - lo <= lds_limit;  // lds_limit <= kSpanLds
+    if (!staged) {
+        for (int k = 0; k < kSpanPer; k++) {
+            if (tok[k] >= n) break;
+            uint32_t e, f;
+            span_of(FromGlobal{buf, len}, start[k], next[k], len, e, f);
+            end[tok[k]] = e;
+            flags[tok[k]] = (uint8_t)f;
+        }
+        return;
+    }
+    const uint32_t span = (uint32_t)(hi_al - lo);
+    for (uint32_t o = 16u * threadIdx.x; o < span; o += 16u * kSpanThreads) {
+        const uint64_t g = lo + o;
+        uint32_t w[4];
+        if (g + 16 <= len) {
+            const uint4 v = *reinterpret_cast<const uint4 *>(buf + g);
+            w[0] = v.x, w[1] = v.y, w[2] = v.z, w[3] = v.w;
+        } else {  // the buffer ends inside this piece: blanks behind it
+            w[0] = w[1] = w[2] = w[3] = 0x20202020u;
+            for (uint64_t b = g; b < len; b++) {
+                const uint32_t k = (uint32_t)(b - g);
+                const uint32_t sh = 8u * (k & 3u), v = (uint32_t)buf[b] << sh, keep = ~(0xFFu << sh);
+                if ((k >> 2) == 0) w[0] = (w[0] & keep) | v;
+                if ((k >> 2) == 1) w[1] = (w[1] & keep) | v;
+                if ((k >> 2) == 2) w[2] = (w[2] & keep) | v;
+                if ((k >> 2) == 3) w[3] = (w[3] & keep) | v;
+            }
+        }
+        *reinterpret_cast<uint4 *>(stage + o) = make_uint4(w[0], w[1], w[2], w[3]);
+        uint32_t num = 0, flt = 0, bs = 0, ink = 0;  // ink: not a blank
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const uint32_t x = w[k];
+            const uint32_t fl = eq_bytes(x, '.') | eq_bytes(x | 0x20202020u, 'e');
+            const uint32_t nu = fl | digit_bytes(x) | eq_bytes(x, '+') | eq_bytes(x, '-');
+            num |= nibble_of(nu) << (4 * k);
+            flt |= nibble_of(fl) << (4 * k);
+            bs |= nibble_of(eq_bytes(x, '\\')) << (4 * k);
+            ink |= nibble_of(~(eq_bytes(x, 0x20) | eq_bytes(x, 0x0A) | eq_bytes(x, 0x0D) | eq_bytes(x, 0x09))) << (4 * k);
+        }
+        reinterpret_cast<uint16_t *>(m_num)[o >> 4] = (uint16_t)num;
+        reinterpret_cast<uint16_t *>(m_flt)[o >> 4] = (uint16_t)flt;
+        reinterpret_cast<uint16_t *>(m_bs)[o >> 4] = (uint16_t)bs;
+        reinterpret_cast<uint16_t *>(m_ink)[o >> 4] = (uint16_t)ink;
+    }
+    __syncthreads();
+    uint32_t e[kSpanPer], f[kSpanPer];
+#pragma unroll
+    for (int k = 0; k < kSpanPer; k++)
+        if (tok[k] < n) staged_token(stage, m_num, m_flt, m_bs, m_ink, lo, span, len, start[k], next[k], e[k], f[k]);
+#pragma unroll
+    for (int k = 0; k < kSpanPer; k++)
+        if (tok[k] < n) {
+            end[tok[k]] = e[k];
+            flags[tok[k]] = (uint8_t)f[k];
+        }
 }
 }  // namespace msj_tokens
 
@@ -739,7 +780,7 @@ extern "C" int msj_launch_token_spans(const uint8_t *d_buf, uint64_t len, const 
     const char *env = getenv("MSJ_SPANS_LDS_LIMIT");
     const unsigned long lim = env ? strtoul(env, nullptr, 10) : msj_tokens::kSpanLds;
     const uint32_t lds_limit = (uint32_t)(lim < msj_tokens::kSpanLds ? lim : msj_tokens::kSpanLds);
-    hipLaunchKernelGGL(msj_tokens::token_spans, dim3((uint32_t)((n + msj_tokens::kSpanTokens - 1) / msj_tokens::kSpanTokens)), dim3(msj_tokens::kSpanTokens), 0,
+    hipLaunchKernelGGL(msj_tokens::token_spans, dim3((uint32_t)((n + msj_tokens::kSpanTokens - 1) / msj_tokens::kSpanTokens)), dim3(msj_tokens::kSpanThreads), 0,
                        static_cast<hipStream_t>(stream), d_buf, len, d_idx, n, d_end, d_flags, lds_limit);
     return (int)hipGetLastError();
 }
