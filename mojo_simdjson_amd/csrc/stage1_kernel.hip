@@ -307,7 +307,6 @@ __device__ __forceinline__ Pending compute_tile(const KernelArgs &a, const uint3
     // a window of a document stream starts at a document, its 16-byte aligned base up to 15 bytes
     // earlier: those bytes (the end of the previous document) read as blanks
     const uint32_t skip = tile == 0 ? (a.flags >> kFlagSkipShift) & 15u : 0u;  // uniform
-    if (skip && lane == 0) valid &= ~0ull << skip;
 
     // ---- carries into the tile from the 64 bytes in front of it (wave-uniform; apart from
     //      one compare + ballot for the backslash run this is scalar code on byte[-1..-3])
@@ -369,6 +368,7 @@ __device__ __forceinline__ Pending compute_tile(const KernelArgs &a, const uint3
     if (tile * kTileBytes + kTileBytes <= len && !skip) {  // uniform: every byte of the tile is input
         cls = classify(p, ~0ull);
     } else {
+        if (lane == 0) valid &= ~0ull << skip;
 #pragma unroll
         for (int k = 0; k < 8; k++) p[k] &= valid;
         cls = classify(p, valid);
