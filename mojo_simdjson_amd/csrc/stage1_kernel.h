@@ -11,8 +11,8 @@ constexpr int kWaves = 4;                          // wave64 per workgroup (each
 constexpr int kThreads = kWaves * 64;
 constexpr uint32_t kTileBytes = 64u * 64u;         // 4 KiB of input per wave: 64 lanes x one 64-byte block
 // Workspace header: kTicketShards range-ticket counters, one per 4 KiB (a single word sustains
-// only ~80 returning atomics per microsecond chip-wide; shard c hands out ranges c, c + S, ...),
-// the role ticket in the second word; the descriptor arrays follow.
+// only ~80 returning atomics per microsecond chip-wide; shard c hands out ranges c, c + S, ...;
+// shard 0's first draw makes the resolver); the descriptor arrays follow.
 constexpr uint32_t kTicketShards = 8;
 constexpr uint32_t kTicketStrideWords = 512;       // in 8-byte words
 constexpr uint32_t kDescOffset = kTicketShards * kTicketStrideWords;  // ws[kDescOffset..] = agg[], ragg[], rpre[]

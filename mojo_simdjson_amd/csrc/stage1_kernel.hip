@@ -134,7 +134,7 @@ struct Shared {
     uint64_t tagg[2][kRange]; // worker workgroups: the range's tile aggregates, in tile order
     // resolver hand-off between its waves
     uint32_t rs_seq, rs_s, rs_cnt, rs_err, rs_u8, rs_poison;
-    uint32_t pad[1];
+    uint32_t shard;          // worker workgroups: the ticket shard they draw from
     // per-wave index staging for coalesced stores
     uint32_t stage[kWaves][kStageWords] __attribute__((aligned(16)));
     // computed-but-not-yet-emitted tiles (two ranges deep), per wave and slot:
@@ -216,6 +216,10 @@ __device__ __forceinline__ uint32_t ticket_request(unsigned int *ctr, uint32_t l
 __device__ __forceinline__ uint32_t ticket_value(uint32_t reg) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     return bcast(reg, 0);
+}
+// range of a shard's k-th draw (shard 0's draw 0 is the resolver's: no range)
+__device__ __forceinline__ uint32_t ticket_range(uint32_t k, uint32_t shard, uint32_t shards) {
+    return (k - (shard == 0u ? 1u : 0u)) * shards + shard;
 }
 
 // BitIndexer.write_index (json_structural_indexer.mojo:39-44) for one 32-bit half mask:
@@ -755,14 +759,12 @@ __device__ __forceinline__ Emit no_emit() {
 // publishes a range's prefix as soon as every earlier range is in (partial progress).
 __device__ __forceinline__ void worker_wave(const KernelArgs &a, Shared &sh, const uint32_t lane,
                                             const uint32_t wave) {
-    // Ticket shard of this workgroup: its arrival number mod (shards in use), so that whichever
-    // workgroups are resident cover every shard; a shard's k-th draw is range k * shards + shard.
-    // Every range is DRAWN, including the first one: handing range w to worker w up front
-    // would save an atomic at start-up, but a workgroup that is not resident yet (a GPU shared
-    // with other kernels) would then own a range everybody else waits for.
+    // Ticket shard and first range: drawn at the kernel's entry (stage1_kernel), one atomic for both.
+    // A shard's k-th draw is range k * shards + shard; shard 0's first draw made the resolver, so its
+    // numbering starts one later (ticket_range).
     const uint32_t workers = gridDim.x - 1u;
     const uint32_t shards = workers < kTicketShards ? workers : kTicketShards;
-    const uint32_t shard = (uniform32(sh.role) - 1u) % shards;
+    const uint32_t shard = uniform32(sh.shard);
     unsigned int *ticket_ctr = reinterpret_cast<unsigned int *>(a.ws + (uint64_t)shard * kTicketStrideWords);
     uint32_t *stage = sh.stage[wave];
     const uint32_t tid = threadIdx.x;
@@ -770,12 +772,7 @@ __device__ __forceinline__ void worker_wave(const KernelArgs &a, Shared &sh, con
     const uint32_t nranges = (ntiles + kRange - 1u) / kRange;
     uint64_t *ragg = a.ws + kDescOffset + ntiles;
     const uint64_t *rpre = ragg + nranges;
-    if (tid == 0) {
-        sh.range_lo[0] = (atomicAdd(ticket_ctr, 1u) * shards + shard) * kRange;
-        sh.range_seq = 0;
-    }
-    if (lane < kPendSlots) sh.pend_meta[wave][lane][0] = 0xFFFFFFFFu;  // all slots empty
-    __syncthreads();
+    if (lane < kPendSlots) sh.pend_meta[wave][lane][0] = 0xFFFFFFFFu;  // all slots empty (read by this wave only)
     MSJ_RSTAMP(a.ntiles + 4096u + blockIdx.x, 2, tid == 0);
     // LDS words every lane reads identically: uniform (tile indices and all control flow stay scalar)
     uint32_t lo_cur = uniform32(sh.range_lo[0]);
@@ -850,7 +847,7 @@ __device__ __forceinline__ void worker_wave(const KernelArgs &a, Shared &sh, con
         // wave 0 passes the next range's ticket on (drawn a compute phase ago) ...
         if (wave == 0) {
             const uint32_t v = ticket_value(req_reg);
-            if (lane == 0) sh.range_lo[par] = (v * shards + shard) * kRange;
+            if (lane == 0) sh.range_lo[par] = ticket_range(v, shard, shards) * kRange;
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             if (lane == 0) *range_seq = r + 1u;
         }
@@ -1030,7 +1027,6 @@ __device__ void resolver(const KernelArgs &a, Shared &sh) {
     const uint32_t nchunks = (ntiles + kResolveChunk - 1) / kResolveChunk;
     if (a.ws_clean && tid < kTicketShards) {
         a.ws_clean[(uint64_t)tid * kTicketStrideWords] = 0ull;  // ticket counters
-        if (tid == 0) a.ws_clean[1] = 0ull;                       // role ticket
     }
     if (tid == 0) {
         sh.rs_seq = 0;
@@ -1262,14 +1258,26 @@ __device__ void resolver(const KernelArgs &a, Shared &sh) {
 __global__ __launch_bounds__(kThreads, 4) void stage1_kernel(const KernelArgs a) {
     __shared__ Shared sh;
     const uint32_t tid = threadIdx.x;
-    // The first workgroup to get here becomes the resolver (it is running, so the workers that
-    // wait on its output can always make progress); every wave of every other workgroup is a
-    // worker.  Arrival order, not blockIdx: with other kernels on the GPU, block 0 is not
-    // necessarily resident first (measured: four processes sharing one GPU time out with a
-    // static resolver), and a shard chosen by blockIdx can be left without a resident worker.
-    // The price is 1 024 atomics on one word at start-up (6 us median, 13 us for the last).
+    // ONE atomic per workgroup at start-up gives it its job.  A workgroup belongs to a ticket shard
+    // by its blockIdx -- blocks 8k .. 8k+7 (one per XCD) share a shard, so every shard has members on
+    // every XCD and a starved XCD (other kernels on the GPU) leaves no shard unserved -- and draws
+    // from that shard's counter.  The first draw from shard 0 makes the resolver: arrival order, not
+    // blockIdx (with other kernels on the GPU block 0 is not necessarily resident first; measured:
+    // four processes sharing one GPU time out with a static resolver), and it is running, so the
+    // workers that wait on its output can always make progress.  Every other draw is a range of
+    // tiles: ranges are DRAWN, the first one too (handing range w to worker w up front would give
+    // ranges to workgroups that are not resident yet, and everybody waits for them).
     MSJ_RSTAMP(a.ntiles + 4096u + blockIdx.x, 0, tid == 0);  // workgroup started
-    if (tid == 0) sh.role = atomicAdd(reinterpret_cast<unsigned int *>(a.ws) + 2, 1u);
+    if (tid == 0) {
+        const uint32_t workers = gridDim.x - 1u;
+        const uint32_t shards = workers < kTicketShards ? workers : kTicketShards;
+        const uint32_t shard = (gridDim.x >= 8u * kTicketShards ? blockIdx.x >> 3 : blockIdx.x) % shards;
+        const uint32_t k = atomicAdd(reinterpret_cast<unsigned int *>(a.ws + (uint64_t)shard * kTicketStrideWords), 1u);
+        sh.role = (shard == 0u && k == 0u) ? 0u : 1u;
+        sh.shard = shard;
+        sh.range_lo[0] = ticket_range(k, shard, shards) * kRange;
+        sh.range_seq = 0;
+    }
     __syncthreads();
     if (sh.role == 0u) {
         resolver(a, sh);
