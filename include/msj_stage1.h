@@ -232,6 +232,16 @@ int32_t msj_token_spans_device(msj_ctx *ctx, const uint8_t *d_buf, uint64_t len,
                                uint32_t *d_end, uint8_t *d_flags, void *stream);
 
 /*
+ * msj_stage2_prep_device -- msj_tokens_device and msj_token_spans_device in one go (rows f1 + f2 + f4), with
+ * identical results: the span kernel holds every token's first byte already, so it writes the type bytes and
+ * the depth aggregates too and the buffer is read once instead of twice.  Same arguments, alignment and limits
+ * as the two calls (d_match optional).  Asynchronous on `stream`.
+ */
+int32_t msj_stage2_prep_device(msj_ctx *ctx, const uint8_t *d_buf, uint64_t len, const uint32_t *d_idx, uint64_t n,
+                               uint8_t *d_type, int32_t *d_depth, uint32_t *d_match, uint32_t *d_end, uint8_t *d_flags,
+                               msj_tokens_result *d_result, void *stream);
+
+/*
  * ---- multi-document mode (DERIVED) -----------------------------
  * The reference left upstream simdjson's streaming modes out
  * (generic/stage1/json_structural_indexer.mojo:153,169; generic/stage2/tape_builder.mojo:25 "TODO: add

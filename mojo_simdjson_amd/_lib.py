@@ -125,6 +125,8 @@ def load():
     lib.msj_token_spans_device.restype = ctypes.c_int32
     lib.msj_token_spans_device.argtypes = [ctypes.c_void_p, u8p, ctypes.c_uint64, u32p, ctypes.c_uint64,
                                            ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
+    lib.msj_stage2_prep_device.restype = ctypes.c_int32
+    lib.msj_stage2_prep_device.argtypes = [ctypes.c_void_p, u8p, ctypes.c_uint64, u32p, ctypes.c_uint64] + [ctypes.c_void_p] * 7
     lib.msj_documents_device.restype = ctypes.c_int32
     lib.msj_documents_device.argtypes = [ctypes.c_void_p, u8p, ctypes.c_uint64, ctypes.c_int32, u32p, ctypes.c_uint64,
                                          ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,

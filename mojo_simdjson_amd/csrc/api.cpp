@@ -268,6 +268,37 @@ int32_t msj_token_spans_device(msj_ctx *ctx, const uint8_t *d_buf, uint64_t len,
     return msj_launch_token_spans(d_buf, len, d_idx, n, d_end, d_flags, stream) == 0 ? MSJ_SUCCESS : MSJ_ERR_HIP;
 }
 
+extern "C" uint64_t msj_stage2_prep_workspace_bytes(uint64_t n, int with_match);
+extern "C" int msj_launch_stage2_prep(const uint8_t *d_buf, uint64_t len, const uint32_t *d_idx, uint64_t n, uint8_t *d_type,
+                                      int32_t *d_depth, uint32_t *d_match, uint32_t *d_end, uint8_t *d_flags,
+                                      msj_tokens_result *d_result, int32_t *d_ws, void *stream);
+
+int32_t msj_stage2_prep_device(msj_ctx *ctx, const uint8_t *d_buf, uint64_t len, const uint32_t *d_idx, uint64_t n,
+                               uint8_t *d_type, int32_t *d_depth, uint32_t *d_match, uint32_t *d_end, uint8_t *d_flags,
+                               msj_tokens_result *d_result, void *stream) {
+    if (!ctx || !d_result) return MSJ_ERR_BAD_ARGUMENT;
+    if (n > 0 && (!d_buf || !d_idx || !d_type || !d_depth || !d_end || !d_flags)) return MSJ_ERR_BAD_ARGUMENT;
+    if (len > MSJ_MAX_SEGMENT_BYTES || n >= (1ull << 31)) return MSJ_CAPACITY;
+    if ((reinterpret_cast<uintptr_t>(d_idx) & 15u) || (reinterpret_cast<uintptr_t>(d_depth) & 15u) ||
+        (reinterpret_cast<uintptr_t>(d_type) & 7u))
+        return MSJ_ERR_BAD_ARGUMENT;
+    if (!hip_ok(hipSetDevice(ctx->device))) return MSJ_ERR_HIP;
+    const uint64_t need = msj_stage2_prep_workspace_bytes(n, d_match != nullptr);
+    if (need > ctx->tok_ws_bytes) {
+        if (ctx->tok_ws) {
+            (void)hipDeviceSynchronize();
+            (void)hipFree(ctx->tok_ws);
+        }
+        ctx->tok_ws = nullptr;
+        ctx->tok_ws_bytes = 0;
+        if (!hip_ok(hipMalloc(reinterpret_cast<void **>(&ctx->tok_ws), need + need / 4))) return MSJ_MEMALLOC;
+        ctx->tok_ws_bytes = need + need / 4;
+    }
+    return msj_launch_stage2_prep(d_buf, len, d_idx, n, d_type, d_depth, d_match, d_end, d_flags, d_result, ctx->tok_ws, stream) == 0
+               ? MSJ_SUCCESS
+               : MSJ_ERR_HIP;
+}
+
 extern "C" uint64_t msj_documents_workspace_bytes(uint64_t n);
 extern "C" int msj_launch_documents(const uint8_t *d_buf, uint64_t len, int is_final, const uint32_t *d_idx, uint64_t n,
                                     const uint8_t *d_type, const int32_t *d_depth, const msj_carry *d_carry, uint32_t *d_doc_first, uint64_t capacity,

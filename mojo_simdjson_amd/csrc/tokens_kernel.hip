@@ -401,20 +401,31 @@ extern "C" uint64_t msj_tokens_workspace_bytes(uint64_t n, int with_match) {
     return (head_words(n) + (with_match ? tree_words(n) + 64 + n : 0)) * sizeof(int32_t);
 }
 
+// scan of the block aggregates (already in d_ws), depth of every token, bracket partners
+static int launch_depth_passes(const uint32_t *d_idx, uint64_t n, uint8_t *d_type, int32_t *d_depth, uint32_t *d_match,
+                               msj_tokens_result *d_result, int32_t *d_ws, hipStream_t s);
+
 extern "C" int msj_launch_tokens(const uint8_t *d_buf, const uint32_t *d_idx, uint64_t n, uint8_t *d_type, int32_t *d_depth,
                                  uint32_t *d_match, msj_tokens_result *d_result, int32_t *d_ws, void *stream) {
     using namespace msj_tokens;
     hipStream_t s = static_cast<hipStream_t>(stream);
     const uint64_t nb64 = (n + kBlock - 1) / kBlock;
     if (nb64 > 0x7FFFFFFFull) return (int)hipErrorInvalidValue;
-    const uint32_t nb = (uint32_t)nb64;
+    if (nb64) hipLaunchKernelGGL(gather_reduce, dim3((uint32_t)nb64), dim3(kThreads), 0, s, d_buf, d_idx, n, d_type, d_ws);
+    return launch_depth_passes(d_idx, n, d_type, d_depth, d_match, d_result, d_ws, s);
+}
+
+static int launch_depth_passes(const uint32_t *d_idx, uint64_t n, uint8_t *d_type, int32_t *d_depth, uint32_t *d_match,
+                               msj_tokens_result *d_result, int32_t *d_ws, hipStream_t s) {
+    using namespace msj_tokens;
+    (void)d_idx;
+    const uint32_t nb = (uint32_t)((n + kBlock - 1) / kBlock);
     const uint64_t nbs = nb ? nb : 1;
     int32_t *agg = d_ws, *start = d_ws + 4 * nbs;
     uint32_t *open_start = reinterpret_cast<uint32_t *>(d_ws + 5 * nbs);
     int32_t *tree = d_ws + head_words(n);  // 32-byte aligned inside the workspace
     const bool want_match = d_match != nullptr && n > 0;
     uint32_t *opens = want_match ? reinterpret_cast<uint32_t *>(tree + tree_words(n) + 64) : nullptr;
-    if (nb) hipLaunchKernelGGL(gather_reduce, dim3(nb), dim3(kThreads), 0, s, d_buf, d_idx, n, d_type, agg);
     hipLaunchKernelGGL(scan_blocks, dim3(1), dim3(1024), 0, s, agg, nb, start, open_start, d_result, n);
     // levels of the min tree: 1..3 come out of apply_depth, the rest from build_level
     MinTree t;
@@ -693,8 +704,12 @@ __device__ __forceinline__ void staged_token(const uint8_t *stage, const uint32_
     f_out = f;
 }
 
+// kFused: the kernel also writes the type byte of every token and the (sum, min, max, opening brackets)
+// aggregate of its kSpanTokens tokens -- what gather_reduce computes from a second pass over the buffer.
+template <bool kFused>
 __global__ __launch_bounds__(kSpanThreads) void token_spans(const uint8_t *__restrict__ buf, uint64_t len, const uint32_t *__restrict__ idx,
-                                                           uint64_t n, uint32_t *__restrict__ end, uint8_t *__restrict__ flags, uint32_t lds_limit) {
+                                                           uint64_t n, uint32_t *__restrict__ end, uint8_t *__restrict__ flags, uint32_t lds_limit,
+                                                           uint8_t *__restrict__ type, int4 *__restrict__ sub_agg) {
     __shared__ __attribute__((aligned(16))) uint8_t stage[kSpanLds];
     __shared__ uint32_t m_num[kSpanMaskWords], m_flt[kSpanMaskWords], m_bs[kSpanMaskWords], m_ink[kSpanMaskWords];
     const uint64_t first = (uint64_t)blockIdx.x * kSpanTokens;
@@ -713,17 +728,17 @@ __global__ __launch_bounds__(kSpanThreads) void token_spans(const uint8_t *__res
         start[k] = tok[k] < n ? (uint64_t)idx[tok[k]] : 0;
         next[k] = (tok[k] + 1 < n) ? (uint64_t)idx[tok[k] + 1] : len;
     }
-    const bool staged = hi_al - lo <= lds_limit;  // lds_limit <= kSpanLds
+    const bool staged = hi_al - lo <= lds_limit;  // lds_limit <= kSpanLds; uniform
+    uint32_t e[kSpanPer], f[kSpanPer], c[kSpanPer];
     if (!staged) {
+#pragma unroll
         for (int k = 0; k < kSpanPer; k++) {
-            if (tok[k] >= n) break;
-            uint32_t e, f;
-            span_of(FromGlobal{buf, len}, start[k], next[k], len, e, f);
-            end[tok[k]] = e;
-            flags[tok[k]] = (uint8_t)f;
+            if (tok[k] < n) {
+                span_of(FromGlobal{buf, len}, start[k], next[k], len, e[k], f[k]);
+                if (kFused) c[k] = buf[start[k]];
+            }
         }
-        return;
-    }
+    } else {
     const uint32_t span = (uint32_t)(hi_al - lo);
     for (uint32_t o = 16u * threadIdx.x; o < span; o += 16u * kSpanThreads) {
         const uint64_t g = lo + o;
@@ -760,16 +775,79 @@ __global__ __launch_bounds__(kSpanThreads) void token_spans(const uint8_t *__res
         reinterpret_cast<uint16_t *>(m_ink)[o >> 4] = (uint16_t)ink;
     }
     __syncthreads();
-    uint32_t e[kSpanPer], f[kSpanPer];
 #pragma unroll
     for (int k = 0; k < kSpanPer; k++)
-        if (tok[k] < n) staged_token(stage, m_num, m_flt, m_bs, m_ink, lo, span, len, start[k], next[k], e[k], f[k]);
+        if (tok[k] < n) {
+            staged_token(stage, m_num, m_flt, m_bs, m_ink, lo, span, len, start[k], next[k], e[k], f[k]);
+            if (kFused) c[k] = stage[start[k] - lo];
+        }
+    }
 #pragma unroll
     for (int k = 0; k < kSpanPer; k++)
         if (tok[k] < n) {
             end[tok[k]] = e[k];
             flags[tok[k]] = (uint8_t)f[k];
+            if (kFused) type[tok[k]] = (uint8_t)c[k];
         }
+    if (kFused) {
+        // ordered reduction of the running-depth monoid over the workgroup's tokens: thread t holds tokens t
+        // and t + kSpanThreads, so the order is (k = 0: waves 0..3), (k = 1: waves 0..3)
+        __shared__ Agg wave_agg[kSpanPer][kSpanThreads / 64];
+        __shared__ int wave_opens[kSpanPer][kSpanThreads / 64];
+        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+        for (int k = 0; k < kSpanPer; k++) {
+            const bool have = tok[k] < n;
+            const int dk = have ? delta_of(c[k]) : 0;
+            // deltas are -1 / 0 / +1: the running sum after each lane's token is a difference of two
+            // masked popcounts of ballots; min and max by butterflies
+            const uint64_t ups = __ballot(dk > 0), downs = __ballot(dk < 0);
+            const uint64_t upto = (2ull << lane) - 1ull;  // lanes 0..lane (lane 63: all)
+            const int run = (int)__popcll(ups & upto) - (int)__popcll(downs & upto);
+            int mn = have ? run : kNone, mx = have ? run : -kNone;
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) {
+                mn = min(mn, __shfl_xor(mn, o));
+                mx = max(mx, __shfl_xor(mx, o));
+            }
+            if (lane == 0) {
+                wave_agg[k][wave] = Agg{(int32_t)__popcll(ups) - (int32_t)__popcll(downs), mn, mx};
+                wave_opens[k][wave] = (int)__popcll(ups);
+            }
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            Agg t = {0, kNone, -kNone};
+            int no = 0;
+#pragma unroll
+            for (int k = 0; k < kSpanPer; k++)
+#pragma unroll
+                for (int w = 0; w < (int)kSpanThreads / 64; w++) {
+                    t = combine(t, wave_agg[k][w]);
+                    no += wave_opens[k][w];
+                }
+            sub_agg[blockIdx.x] = make_int4(t.sum, t.mn, t.mx, no);
+        }
+    }
+}
+
+// block aggregates of the token pre-pass (kBlock tokens) from those of the fused kernel (kSpanTokens tokens)
+static_assert(kBlock % kSpanTokens == 0, "a block of the depth pass is a whole number of span workgroups");
+__global__ __launch_bounds__(256) void merge_sub_aggregates(const int4 *__restrict__ sub, uint32_t nsub, int32_t *__restrict__ block_agg,
+                                                            uint32_t nblocks) {
+    constexpr uint32_t kSub = kBlock / kSpanTokens;
+    const uint32_t b = blockIdx.x * 256u + threadIdx.x;
+    if (b >= nblocks) return;
+    Agg t = {0, kNone, -kNone};
+    int no = 0;
+    for (uint32_t k = 0; k < kSub; k++) {
+        const uint32_t i = b * kSub + k;
+        if (i >= nsub) break;
+        const int4 q = sub[i];
+        t = combine(t, Agg{q.x, q.y, q.z});
+        no += q.w;
+    }
+    *reinterpret_cast<int4 *>(block_agg + 4 * (uint64_t)b) = make_int4(t.sum, t.mn, t.mx, no);
 }
 }  // namespace msj_tokens
 
@@ -780,7 +858,38 @@ extern "C" int msj_launch_token_spans(const uint8_t *d_buf, uint64_t len, const 
     const char *env = getenv("MSJ_SPANS_LDS_LIMIT");
     const unsigned long lim = env ? strtoul(env, nullptr, 10) : msj_tokens::kSpanLds;
     const uint32_t lds_limit = (uint32_t)(lim < msj_tokens::kSpanLds ? lim : msj_tokens::kSpanLds);
-    hipLaunchKernelGGL(msj_tokens::token_spans, dim3((uint32_t)((n + msj_tokens::kSpanTokens - 1) / msj_tokens::kSpanTokens)), dim3(msj_tokens::kSpanThreads), 0,
-                       static_cast<hipStream_t>(stream), d_buf, len, d_idx, n, d_end, d_flags, lds_limit);
+    hipLaunchKernelGGL(msj_tokens::token_spans<false>, dim3((uint32_t)((n + msj_tokens::kSpanTokens - 1) / msj_tokens::kSpanTokens)),
+                       dim3(msj_tokens::kSpanThreads), 0, static_cast<hipStream_t>(stream), d_buf, len, d_idx, n, d_end, d_flags, lds_limit,
+                       static_cast<uint8_t *>(nullptr), static_cast<int4 *>(nullptr));
     return (int)hipGetLastError();
+}
+
+// ---- everything stage 2 reads first, in one go (rows f1 + f2 + f4): the span kernel has every token's
+// first byte in LDS anyway, so it writes the type bytes and the depth aggregates as well and the token
+// pre-pass starts at its scan -- one pass over the buffer instead of two.
+extern "C" uint64_t msj_stage2_prep_workspace_bytes(uint64_t n, int with_match) {
+    const uint64_t nsub = (n + msj_tokens::kSpanTokens - 1) / msj_tokens::kSpanTokens;
+    return msj_tokens_workspace_bytes(n, with_match) + 32 + (nsub ? nsub : 1) * sizeof(int4);
+}
+
+extern "C" int msj_launch_stage2_prep(const uint8_t *d_buf, uint64_t len, const uint32_t *d_idx, uint64_t n, uint8_t *d_type,
+                                      int32_t *d_depth, uint32_t *d_match, uint32_t *d_end, uint8_t *d_flags,
+                                      msj_tokens_result *d_result, int32_t *d_ws, void *stream) {
+    using namespace msj_tokens;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const uint64_t nb64 = (n + kBlock - 1) / kBlock;
+    if (nb64 > 0x7FFFFFFFull) return (int)hipErrorInvalidValue;
+    const uint32_t nb = (uint32_t)nb64;
+    const uint32_t nsub = (uint32_t)((n + kSpanTokens - 1) / kSpanTokens);
+    // the fused kernel's aggregates live behind the token pre-pass's own workspace (16-byte aligned)
+    const uint64_t tok_bytes = (msj_tokens_workspace_bytes(n, d_match != nullptr) + 15u) & ~15ull;
+    int4 *sub = reinterpret_cast<int4 *>(reinterpret_cast<uint8_t *>(d_ws) + tok_bytes);
+    if (n) {
+        const char *env = getenv("MSJ_SPANS_LDS_LIMIT");
+        const unsigned long lim = env ? strtoul(env, nullptr, 10) : kSpanLds;
+        const uint32_t lds_limit = (uint32_t)(lim < kSpanLds ? lim : kSpanLds);
+        hipLaunchKernelGGL(token_spans<true>, dim3(nsub), dim3(kSpanThreads), 0, s, d_buf, len, d_idx, n, d_end, d_flags, lds_limit, d_type, sub);
+        hipLaunchKernelGGL(merge_sub_aggregates, dim3((nb + 255u) / 256u), dim3(256), 0, s, sub, nsub, d_ws, nb);
+    }
+    return launch_depth_passes(d_idx, n, d_type, d_depth, d_match, d_result, d_ws, s);
 }

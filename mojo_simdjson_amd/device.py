@@ -122,6 +122,25 @@ class Stage1Device:
             raise RuntimeError(f"msj_token_spans_device failed: {rc}")
         return d_end[:n], d_flags[:n]
 
+    def stage2_prep(self, d_buf, length, d_idx, n, match=False):
+        """``tokens`` and ``token_spans`` in one go (``msj_stage2_prep_device``), identical results:
+        returns (d_type, d_depth, msj_tokens_result, d_match or None, d_end, d_flags)."""
+        n = int(n)
+        dv = self.device
+        d_type = torch.empty(max(n, 1), dtype=torch.uint8, device=dv)
+        d_depth = torch.empty(max(n, 1), dtype=torch.int32, device=dv)
+        d_match = torch.empty(max(n, 1), dtype=torch.int32, device=dv) if match else None
+        d_end = torch.empty(max(n, 1), dtype=torch.int32, device=dv)
+        d_flags = torch.empty(max(n, 1), dtype=torch.uint8, device=dv)
+        d_res = torch.zeros(24, dtype=torch.uint8, device=dv)
+        rc = self.lib.msj_stage2_prep_device(self.ctx, _ptr(d_buf), int(length), _ptr(d_idx), n, _ptr(d_type), _ptr(d_depth),
+                                             _ptr(d_match) if match else None, _ptr(d_end), _ptr(d_flags), _ptr(d_res),
+                                             self._stream())
+        if rc != 0:
+            raise RuntimeError(f"msj_stage2_prep_device failed: {rc}")
+        res = _lib.MsjTokensResult.from_buffer_copy(d_res.cpu().numpy().tobytes())
+        return d_type[:n], d_depth[:n], res, (d_match[:n] if match else None), d_end[:n], d_flags[:n]
+
     def documents(self, d_buf, length, d_idx, n, d_type, d_depth, is_final=False, d_carry=None, d_doc_first=None,
                   d_result=None, sync=True):
         """Document split of one window of a stream of concatenated documents (``msj_documents_device``):

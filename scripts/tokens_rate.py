@@ -54,4 +54,15 @@ for name in ("minified", "utf8", "pretty4"):
     torch.cuda.synchronize()
     ms3 = e0.elapsed_time(e1) / 10
     print(f"           token spans (strings, numbers): {ms3:.3f} ms ({n / ms3 / 1e6:.1f} G structurals/s, {nbytes / ms3 / 1e6:.0f} GB/s of JSON)")
+    del d_type, d_depth, d_match
+    dev.stage2_prep(d_buf, nbytes, d_idx, n)
+    torch.cuda.synchronize()
+    e0.record()
+    for _ in range(10):
+        dev.stage2_prep(d_buf, nbytes, d_idx, n)
+    e1.record()
+    torch.cuda.synchronize()
+    ms4 = e0.elapsed_time(e1) / 10
+    print(f"           type + depth + spans in one go (msj_stage2_prep_device): {ms4:.3f} ms ({n / ms4 / 1e6:.1f} G structurals/s, "
+          f"{nbytes / ms4 / 1e6:.0f} GB/s of JSON) vs {ms + ms3:.3f} ms for the two calls")
 dev.close()

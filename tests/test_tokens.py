@@ -156,6 +156,49 @@ def test_token_spans(dev, lds_limit, monkeypatch):
         _check_spans(dev, a[rng.integers(0, len(a), n)].tobytes(), f"soup {k}")
 
 
+def _check_prep(dev, data, where):
+    import torch
+
+    d_buf = torch.from_numpy(np.frombuffer(data, dtype=np.uint8).copy()).to(dev.device)
+    d_idx = torch.empty(len(data) + 3 + 4, dtype=torch.int32, device=dev.device)
+    d_res = dev.new_carry()
+    dev.index(d_buf, d_idx, d_res)
+    n = int(dev.fetch(d_res).count)
+    idx = d_idx[:n].cpu().numpy().view(np.uint32)
+    t, d, res, m, e, f = dev.stage2_prep(d_buf, len(data), d_idx, n, match=True)
+    wt, wd, (final, mn, mx) = helpers.oracle_tokens(data, idx)
+    we, wf = helpers.oracle_token_spans(data, idx)
+    assert np.array_equal(t.cpu().numpy(), wt), where
+    assert np.array_equal(d.cpu().numpy(), wd), where
+    assert (res.n, res.final_depth, res.min_depth, res.max_depth) == (n, final, mn, mx), where
+    assert np.array_equal(m.cpu().numpy().view(np.uint32), helpers.oracle_match(wt)), where
+    assert np.array_equal(f.cpu().numpy(), wf), where
+    assert np.array_equal(e.cpu().numpy().view(np.uint32), we), where
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("lds_limit", ["", "0", "4096"])
+def test_stage2_prep_equals_the_separate_calls(dev, lds_limit, monkeypatch):
+    """msj_stage2_prep_device = token pre-pass + token spans from one pass over the buffer."""
+    from mojo_simdjson_amd import synth
+
+    if lds_limit:
+        monkeypatch.setenv("MSJ_SPANS_LDS_LIMIT", lds_limit)
+    for f in helpers.golden_valid_files():
+        js, _ = helpers.read_fixture(f)
+        _check_prep(dev, js, f)
+    for name in ("minified", "utf8", "pretty4"):
+        _check_prep(dev, synth.workload(name, 8 << 20).tobytes(), name)
+    rng = np.random.default_rng(12)
+    alphabet = np.frombuffer(b'{}[]{}[],: "a1\\\n', dtype=np.uint8)
+    for n in (1, 2, 255, 256, 257, 511, 512, 513, 2047, 2048, 2049, 4096 * 3 + 5, 100000, 1 << 20):
+        _check_prep(dev, alphabet[rng.integers(0, len(alphabet), n)].tobytes(), f"soup {n}")
+    _check_prep(dev, b"[" * 300000 + b"]" * 299999, "deep")
+    _check_prep(dev, b"]" * 5000 + b"[" * 7, "underflow")
+    _check_prep(dev, b'[' + b'"a\\\\b",12,' * 3000 + b'"' + b"x" * 40000 + b'",' + b'"cd",3.5,' * 3000 + b"0]", "mixed paths")
+    _check_prep(dev, b" ", "no structurals")
+
+
 @pytest.mark.gpu
 def test_tokens_workloads(dev):
     from mojo_simdjson_amd import synth
