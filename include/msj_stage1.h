@@ -278,6 +278,15 @@ int32_t msj_documents_device(msj_ctx *ctx, const uint8_t *d_buf, uint64_t len, i
                              uint64_t n, const uint8_t *d_type, const int32_t *d_depth, const msj_carry *d_carry,
                              uint32_t *d_doc_first, uint64_t capacity, msj_documents_result *d_result, void *stream);
 
+/*
+ * Device memory for hosts that have no HIP binding of their own (a Mojo DLHandle, plain C, the C++ mirrors
+ * under include/): allocation on the context's device and blocking copies.  Plumbing, not part of the path.
+ */
+int32_t msj_device_alloc(msj_ctx *ctx, uint64_t bytes, void **d_out);
+int32_t msj_device_free(msj_ctx *ctx, void *d_ptr);
+int32_t msj_copy_to_device(msj_ctx *ctx, void *d_dst, const void *src, uint64_t bytes, void *stream);
+int32_t msj_copy_to_host(msj_ctx *ctx, void *dst, const void *d_src, uint64_t bytes, void *stream);
+
 /* Tile geometry (for roofline bookkeeping and tests). */
 uint32_t msj_tile_bytes(void);
 

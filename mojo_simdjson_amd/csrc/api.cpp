@@ -329,6 +329,37 @@ int32_t msj_documents_device(msj_ctx *ctx, const uint8_t *d_buf, uint64_t len, i
                : MSJ_ERR_HIP;
 }
 
+int32_t msj_device_alloc(msj_ctx *ctx, uint64_t bytes, void **d_out) {
+    if (!ctx || !d_out) return MSJ_ERR_BAD_ARGUMENT;
+    *d_out = nullptr;
+    if (!hip_ok(hipSetDevice(ctx->device))) return MSJ_ERR_HIP;
+    return hip_ok(hipMalloc(d_out, bytes ? bytes : 1)) ? MSJ_SUCCESS : MSJ_MEMALLOC;
+}
+
+int32_t msj_device_free(msj_ctx *ctx, void *d_ptr) {
+    if (!ctx) return MSJ_ERR_BAD_ARGUMENT;
+    if (!d_ptr) return MSJ_SUCCESS;
+    if (!hip_ok(hipSetDevice(ctx->device))) return MSJ_ERR_HIP;
+    return hip_ok(hipFree(d_ptr)) ? MSJ_SUCCESS : MSJ_ERR_HIP;
+}
+
+static int32_t blocking_copy(msj_ctx *ctx, void *dst, const void *src, uint64_t bytes, void *stream, hipMemcpyKind kind) {
+    if (!ctx || (bytes && (!dst || !src))) return MSJ_ERR_BAD_ARGUMENT;
+    if (bytes == 0) return MSJ_SUCCESS;
+    if (!hip_ok(hipSetDevice(ctx->device))) return MSJ_ERR_HIP;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (!hip_ok(hipMemcpyAsync(dst, src, bytes, kind, s))) return MSJ_ERR_HIP;
+    return hip_ok(hipStreamSynchronize(s)) ? MSJ_SUCCESS : MSJ_ERR_HIP;
+}
+
+int32_t msj_copy_to_device(msj_ctx *ctx, void *d_dst, const void *src, uint64_t bytes, void *stream) {
+    return blocking_copy(ctx, d_dst, src, bytes, stream, hipMemcpyHostToDevice);
+}
+
+int32_t msj_copy_to_host(msj_ctx *ctx, void *dst, const void *d_src, uint64_t bytes, void *stream) {
+    return blocking_copy(ctx, dst, d_src, bytes, stream, hipMemcpyDeviceToHost);
+}
+
 int32_t msj_carry_fetch(msj_ctx *ctx, const msj_carry *d_carry, msj_carry *host_out, void *stream) {
     if (!ctx || !d_carry || !host_out) return MSJ_ERR_BAD_ARGUMENT;
     if (!hip_ok(hipSetDevice(ctx->device))) return MSJ_ERR_HIP;

@@ -83,3 +83,6 @@ def test_cpp_mirror_compiles():
     subprocess.check_call(["g++", "-std=c++17", "-O1", "-Wall", "-I" + os.path.join(root, "include"),
                            os.path.join(root, "tests", "cpp", "test_stage_1.cpp"), "-o", os.path.join(out, "test_stage_1"),
                            "-L" + libdir, "-lmsj_stage1", "-Wl,-rpath," + libdir])
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-Wall", "-I" + os.path.join(root, "include"),
+                           os.path.join(root, "tests", "cpp", "test_document_stream.cpp"), "-o",
+                           os.path.join(out, "test_document_stream"), "-L" + libdir, "-lmsj_stage1", "-Wl,-rpath," + libdir])

@@ -263,3 +263,22 @@ def test_document_stream_one_gib(dev):
         assert bool((w.d_depth[w.d_doc_first.long()] == 0).all())
         docs += w.n_documents
     assert docs == 12000 * nrep
+
+
+@pytest.mark.gpu
+def test_cpp_document_stream():
+    """include/document_stream.hpp (the C++ mirror above the C ABI) through tests/cpp/test_document_stream.cpp."""
+    import os
+    import subprocess
+
+    out = os.path.join(helpers.ROOT, "tests", "_build")
+    os.makedirs(out, exist_ok=True)
+    exe = os.path.join(out, "test_document_stream")
+    libdir = os.path.join(helpers.ROOT, "mojo_simdjson_amd")
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-Wall", "-I" + os.path.join(helpers.ROOT, "include"),
+                           os.path.join(helpers.ROOT, "tests", "cpp", "test_document_stream.cpp"), "-o", exe,
+                           "-L" + libdir, "-lmsj_stage1", "-Wl,-rpath," + libdir])
+    env = dict(os.environ)
+    env["LD_LIBRARY_PATH"] = "/opt/rocm/lib:" + env.get("LD_LIBRARY_PATH", "")
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode == 0 and "test_document_stream ok" in r.stdout, r.stdout[-3000:] + r.stderr[-2000:]
