@@ -121,6 +121,72 @@ __global__ __launch_bounds__(kThreads) void gather_reduce(const uint8_t *__restr
     }
 }
 
+// (2a) many workgroups: exclusive scan of the block aggregates INSIDE each run of kSuper blocks (relative
+//      start depth and start slot per block) and the aggregate of the run.  One workgroup scanning all
+//      the blocks alone took 0.1 - 0.26 ms for 10^5 blocks (every pass pays the full memory latency with
+//      nothing else on the chip); this way the single workgroup of (2) only sees the runs.
+constexpr uint32_t kSuper = 1024;  // blocks per run: 256 threads x 4
+__global__ __launch_bounds__(256) void scan_super(const int32_t *__restrict__ block_agg, uint32_t nblocks, int32_t *__restrict__ rel_start,
+                                                  uint32_t *__restrict__ rel_open, int32_t *__restrict__ super_agg) {
+    __shared__ Agg wave_agg[4];
+    __shared__ uint32_t wave_opens[4];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint32_t first = blockIdx.x * kSuper + threadIdx.x * 4u;
+    Agg own[4];
+    uint32_t own_opens[4];
+    Agg a = {0, kNone, -kNone};
+    uint32_t no = 0;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        own[k] = Agg{0, kNone, -kNone};
+        own_opens[k] = 0;
+        if (first + k < nblocks) {
+            const int4 q = *reinterpret_cast<const int4 *>(block_agg + 4 * (uint64_t)(first + k));
+            own[k] = Agg{q.x, q.y, q.z};
+            own_opens[k] = (uint32_t)q.w;
+        }
+        a = combine(a, own[k]);
+        no += own_opens[k];
+    }
+    const Agg mine = a;
+    const uint32_t mine_opens = no;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const Agg p = shfl_up(a, o);
+        const uint32_t po = __shfl_up(no, o);
+        if (lane >= o) {
+            a = combine(p, a);
+            no += po;
+        }
+    }
+    if (lane == 63) {
+        wave_agg[wave] = a;
+        wave_opens[wave] = no;
+    }
+    __syncthreads();
+    Agg before = {0, kNone, -kNone};
+    uint32_t before_opens = 0;
+    for (int w = 0; w < wave; w++) {
+        before = combine(before, wave_agg[w]);
+        before_opens += wave_opens[w];
+    }
+    const Agg incl = combine(before, a);
+    const uint32_t incl_opens = before_opens + no;
+    int32_t run = incl.sum - mine.sum;
+    uint32_t ro = incl_opens - mine_opens;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        if (first + k < nblocks) {
+            rel_start[first + k] = run;
+            rel_open[first + k] = ro;
+        }
+        run += own[k].sum;
+        ro += own_opens[k];
+    }
+    if (threadIdx.x == 255)
+        *reinterpret_cast<int4 *>(super_agg + 4 * (uint64_t)blockIdx.x) = make_int4(incl.sum, incl.mn, incl.mx, (int)incl_opens);
+}
+
 // (2) one workgroup: exclusive scan of the block sums, global min / max / final depth.  Each
 //     thread folds kScanPer consecutive block aggregates serially (so a pass covers 8 192 blocks).
 constexpr int kScanPer = 8;
@@ -208,7 +274,8 @@ __global__ __launch_bounds__(1024) void scan_blocks(const int32_t *__restrict__ 
 
 // (3) depth of every token
 __global__ __launch_bounds__(kThreads) void apply_depth(const uint8_t *__restrict__ type, uint64_t n,
-                                                        const int32_t *__restrict__ block_start, int32_t *__restrict__ depth,
+                                                        const int32_t *__restrict__ block_start, const int32_t *__restrict__ super_start,
+                                                        const uint32_t *__restrict__ super_open, int32_t *__restrict__ depth,
                                                         int32_t *__restrict__ min8, int32_t *__restrict__ min64,
                                                         int32_t *__restrict__ min512, const uint32_t *__restrict__ open_start,
                                                         uint32_t *__restrict__ opens) {
@@ -250,10 +317,10 @@ __global__ __launch_bounds__(kThreads) void apply_depth(const uint8_t *__restric
         wave_no[wave] = incl_no;
     }
     __syncthreads();
-    int before = block_start[blockIdx.x] + incl - run;
+    int before = super_start[blockIdx.x / kSuper] + block_start[blockIdx.x] + incl - run;
     for (int w = 0; w < wave; w++) before += wave_sum[w];
     if (opens) {  // the token indices of all opening brackets, in order (work list of match_brackets)
-        uint32_t slot = open_start[blockIdx.x] + (uint32_t)(incl_no - no);
+        uint32_t slot = super_open[blockIdx.x / kSuper] + open_start[blockIdx.x] + (uint32_t)(incl_no - no);
         for (int w = 0; w < wave; w++) slot += (uint32_t)wave_no[w];
 #pragma unroll
         for (int k = 0; k < kPer; k++)
@@ -393,9 +460,16 @@ static uint64_t tree_words(uint64_t n) {  // every level padded to a multiple of
     }
     return w;
 }
-static uint64_t head_words(uint64_t n) {
+static uint64_t super_count(uint64_t n) {
+    const uint64_t nb = (n + msj_tokens::kBlock - 1) / msj_tokens::kBlock;
+    return nb ? (nb + msj_tokens::kSuper - 1) / msj_tokens::kSuper : 1;
+}
+static uint64_t block_words(uint64_t n) {  // 4 (aggregate) + relative start depth + relative start slot per block
     const uint64_t nb = (n + msj_tokens::kBlock - 1) / msj_tokens::kBlock;
     return (6 * (nb ? nb : 1) + 7u) & ~7ull;
+}
+static uint64_t head_words(uint64_t n) {  // ... + the same six words per run of kSuper blocks
+    return block_words(n) + ((6 * super_count(n) + 7u) & ~7ull);
 }
 extern "C" uint64_t msj_tokens_workspace_bytes(uint64_t n, int with_match) {
     return (head_words(n) + (with_match ? tree_words(n) + 64 + n : 0)) * sizeof(int32_t);
@@ -426,7 +500,11 @@ static int launch_depth_passes(const uint32_t *d_idx, uint64_t n, uint8_t *d_typ
     int32_t *tree = d_ws + head_words(n);  // 32-byte aligned inside the workspace
     const bool want_match = d_match != nullptr && n > 0;
     uint32_t *opens = want_match ? reinterpret_cast<uint32_t *>(tree + tree_words(n) + 64) : nullptr;
-    hipLaunchKernelGGL(scan_blocks, dim3(1), dim3(1024), 0, s, agg, nb, start, open_start, d_result, n);
+    const uint32_t nsuper = (uint32_t)super_count(n);
+    int32_t *super_agg = d_ws + block_words(n), *super_start = super_agg + 4 * (uint64_t)nsuper;
+    uint32_t *super_open = reinterpret_cast<uint32_t *>(super_start + nsuper);
+    if (nb) hipLaunchKernelGGL(scan_super, dim3(nsuper), dim3(256), 0, s, agg, nb, start, open_start, super_agg);
+    hipLaunchKernelGGL(scan_blocks, dim3(1), dim3(1024), 0, s, super_agg, nb ? nsuper : 0u, super_start, super_open, d_result, n);
     // levels of the min tree: 1..3 come out of apply_depth, the rest from build_level
     MinTree t;
     t.lv[0] = d_depth;
@@ -450,7 +528,7 @@ static int launch_depth_passes(const uint32_t *d_idx, uint64_t n, uint8_t *d_typ
     int32_t *l3 = want_match ? (t.nlev > 3 ? lvl[3] : tree + tree_words(n) + 40) : nullptr;
     if (want_match)  // padding entries of the tree levels must never qualify: 0x7F7F7F7F
         (void)hipMemsetAsync(tree, 0x7F, (tree_words(n) + 64) * sizeof(int32_t), s);
-    if (nb) hipLaunchKernelGGL(apply_depth, dim3(nb), dim3(kThreads), 0, s, d_type, n, start, d_depth, l1, l2, l3, open_start, opens);
+    if (nb) hipLaunchKernelGGL(apply_depth, dim3(nb), dim3(kThreads), 0, s, d_type, n, start, super_start, super_open, d_depth, l1, l2, l3, open_start, opens);
     if (want_match) {
         for (int k = 4; k < t.nlev; k++)
             hipLaunchKernelGGL(build_level, dim3((t.cnt[k] + 255u) / 256u), dim3(256), 0, s, t.lv[k - 1], t.cnt[k - 1], lvl[k], t.cnt[k]);
