@@ -89,11 +89,15 @@ class DocumentStream {
         const uint64_t n = carry.count;
         rc = msj_tokens_device(ctx_, d_buf_ + base, wlen, idx_, n, type_, depth_, nullptr, d_tok, nullptr);
         if (rc == 0) rc = msj_documents_device(ctx_, d_buf_ + base, wlen, last ? 1 : 0, idx_, n, type_, depth_, d_cout, first_, capacity_, d_doc, nullptr);
-        msj_tokens_result tok{};
-        msj_documents_result doc{};
-        if (rc == 0) rc = msj_copy_to_host(ctx_, &tok, d_tok, sizeof tok, nullptr);
-        if (rc == 0) rc = msj_copy_to_host(ctx_, &doc, d_doc, sizeof doc, nullptr);
+        struct {  // one read for both result structs: small_[128 .. 224)
+            msj_tokens_result tok;
+            uint8_t pad[64 - sizeof(msj_tokens_result)];
+            msj_documents_result doc;
+        } both{};
+        if (rc == 0) rc = msj_copy_to_host(ctx_, &both, d_tok, sizeof both, nullptr);
         if (rc != 0) return fail(rc > 0 ? rc : errors::UNEXPECTED_ERROR, "token pre-pass failed");
+        const msj_tokens_result &tok = both.tok;
+        const msj_documents_result &doc = both.doc;
         const bool cut = doc.n_complete < doc.n_documents;
         if (carry.unescaped_error) return fail(errors::UNESCAPED_CHARS, "control character inside a string");
         if (tok.min_depth < 0) return fail(errors::TAPE_ERROR, "closing bracket without an opening one");

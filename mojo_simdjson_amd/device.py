@@ -87,11 +87,11 @@ class Stage1Device:
             raise RuntimeError(f"msj_stage1_shard_device failed: {rc}")
         return rc, nseg.value
 
-    def tokens(self, d_buf, length, d_idx, n, d_type=None, d_depth=None, d_match=None, match=False):
+    def tokens(self, d_buf, length, d_idx, n, d_type=None, d_depth=None, d_match=None, match=False, d_result=None, sync=True):
         """Token stream for stage 2 (``msj_tokens_device``): type byte and nesting depth of every
         structural, optionally (match=True or d_match given) the partner index of every bracket.
         Returns (d_type uint8[n], d_depth int32[n], msj_tokens_result[, d_match int32[n]]); blocking
-        only for the 24-byte result."""
+        only for the 24-byte result (sync=False: not at all, the result stays in d_result on the device)."""
         n = int(n)
         if d_type is None:
             d_type = torch.empty(max(n, 1), dtype=torch.uint8, device=self.device)
@@ -99,13 +99,14 @@ class Stage1Device:
             d_depth = torch.empty(max(n, 1), dtype=torch.int32, device=self.device)
         if match and d_match is None:
             d_match = torch.empty(max(n, 1), dtype=torch.int32, device=self.device)
-        d_res = torch.zeros(24, dtype=torch.uint8, device=self.device)
+        d_res = d_result if d_result is not None else torch.zeros(24, dtype=torch.uint8, device=self.device)
         rc = self.lib.msj_tokens_device(self.ctx, _ptr(d_buf), int(length), _ptr(d_idx), n, _ptr(d_type),
                                         _ptr(d_depth), _ptr(d_match) if d_match is not None else None,
                                         _ptr(d_res), self._stream())
         if rc != 0:
             raise RuntimeError(f"msj_tokens_device failed: {rc}")
-        res = _lib.MsjTokensResult.from_buffer_copy(d_res.cpu().numpy().tobytes())
+        # sync=False: nothing is waited for; the third element is the device tensor holding the msj_tokens_result
+        res = _lib.MsjTokensResult.from_buffer_copy(d_res.cpu().numpy().tobytes()) if sync else d_res
         if d_match is not None:
             return d_type[:n], d_depth[:n], res, d_match[:n]
         return d_type[:n], d_depth[:n], res

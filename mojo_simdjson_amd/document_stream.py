@@ -18,7 +18,7 @@ from dataclasses import dataclass
 
 import torch
 
-from . import errors
+from . import _lib, errors
 
 MAX_WINDOW = 1 << 31
 
@@ -83,6 +83,7 @@ class DocumentStream:
         self._first = torch.empty(self.capacity, dtype=torch.int32, device=dvc)
         self._zero = dev.new_carry()
         self._carry = dev.new_carry()
+        self._results = torch.zeros(64, dtype=torch.uint8, device=dvc)  # msj_tokens_result | msj_documents_result
         self.windows = 0
 
     def __iter__(self):
@@ -101,9 +102,14 @@ class DocumentStream:
             if carry.internal_error:
                 raise DocumentStreamError(errors.CAPACITY, f"window at {base}: more than {self.capacity} structurals")
             n = int(carry.count)
-            d_type, d_depth, tok = dev.tokens(d_win, wlen, self._idx, n, d_type=self._type, d_depth=self._depth)
-            d_first, res = dev.documents(d_win, wlen, self._idx, n, d_type, d_depth, is_final=last, d_carry=self._carry,
-                                         d_doc_first=self._first)
+            # the two small result structs of the token pre-pass and the split come back in one read
+            d_type, d_depth, _ = dev.tokens(d_win, wlen, self._idx, n, d_type=self._type, d_depth=self._depth,
+                                            d_result=self._results[:24], sync=False)
+            d_first, _ = dev.documents(d_win, wlen, self._idx, n, d_type, d_depth, is_final=last, d_carry=self._carry,
+                                       d_doc_first=self._first, d_result=self._results[32:64], sync=False)
+            blob = self._results.cpu().numpy().tobytes()
+            tok = _lib.MsjTokensResult.from_buffer_copy(blob[:24])
+            res = _lib.MsjDocumentsResult.from_buffer_copy(blob[32:64])
             cut = res.n_complete < res.n_documents
             if carry.unescaped_error:
                 raise DocumentStreamError(errors.UNESCAPED_CHARS, f"window at {base}: control character inside a string")
