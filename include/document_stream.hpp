@@ -88,7 +88,7 @@ class DocumentStream {
         if (carry.internal_error) return fail(errors::CAPACITY, "more structurals in a window than index_capacity");
         const uint64_t n = carry.count;
         rc = msj_tokens_device(ctx_, d_buf_ + base, wlen, idx_, n, type_, depth_, nullptr, d_tok, nullptr);
-        if (rc == 0) rc = msj_documents_device(ctx_, d_buf_ + base, wlen, last ? 1 : 0, idx_, n, type_, depth_, d_cout, first_, capacity_, d_doc, nullptr);
+        if (rc == 0) rc = msj_documents_device(ctx_, d_buf_ + base, wlen, (last ? MSJ_DOCS_FINAL : 0) | MSJ_DOCS_AFTER_TOKENS, idx_, n, type_, depth_, d_cout, first_, capacity_, d_doc, nullptr);
         struct {  // one read for both result structs: small_[128 .. 224)
             msj_tokens_result tok;
             uint8_t pad[64 - sizeof(msj_tokens_result)];

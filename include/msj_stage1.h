@@ -261,12 +261,17 @@ int32_t msj_stage2_prep_device(msj_ctx *ctx, const uint8_t *d_buf, uint64_t len,
  *                               returns for the window)
  *              resume_offset    byte offset (relative to the window) of that token = where the next
  *                               window has to start; len when nothing is cut
- * d_buf / len: the window; is_final: it is the end of the stream.  d_type / d_depth as written by
+ * d_buf / len: the window; is_final: MSJ_DOCS_* bits -- MSJ_DOCS_FINAL: the window is the end of the stream;
+ * MSJ_DOCS_AFTER_TOKENS: d_type / d_depth are exactly what the LAST msj_tokens_device / msj_stage2_prep_device call
+ * on this context wrote (same n, same stream order) and have not been changed since: the per-block counts that call
+ * left in the context's workspace are used instead of a pass over the two arrays.  d_type / d_depth as written by
  * msj_tokens_device for the same d_idx; d_carry (optional, may be NULL):
  * the carry_out of the window's msj_stage1_shard_device call, read on the device.  A window of a
  * stream is indexed with msj_stage1_shard_device(..., is_final = 0): nothing is an error yet at its end.
  * Asynchronous on `stream`.
  */
+#define MSJ_DOCS_FINAL 1
+#define MSJ_DOCS_AFTER_TOKENS 2
 typedef struct msj_documents_result {
     uint64_t n_documents;
     uint64_t n_complete;

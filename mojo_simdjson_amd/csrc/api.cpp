@@ -35,6 +35,7 @@ struct msj_ctx {
     uint32_t grid = 0;            // persistent workgroups per launch (CUs x resident blocks per CU)
     int32_t *tok_ws = nullptr;    // block aggregates of the token pre-pass
     uint64_t tok_ws_bytes = 0;
+    uint64_t tok_doc_n = ~0ull;   // the token count whose document aggregates tok_ws holds (~0: none)
     void *doc_ws = nullptr;       // block counts of the document split
     uint64_t doc_ws_bytes = 0;
 };
@@ -252,8 +253,10 @@ int32_t msj_tokens_device(msj_ctx *ctx, const uint8_t *d_buf, uint64_t len, cons
         if (!hip_ok(hipMalloc(reinterpret_cast<void **>(&ctx->tok_ws), need + need / 4))) return MSJ_MEMALLOC;
         ctx->tok_ws_bytes = need + need / 4;
     }
-    return msj_launch_tokens(d_buf, d_idx, n, d_type, d_depth, d_match, d_result, ctx->tok_ws, stream) == 0 ? MSJ_SUCCESS
-                                                                                                 : MSJ_ERR_HIP;
+    ctx->tok_doc_n = ~0ull;
+    if (msj_launch_tokens(d_buf, d_idx, n, d_type, d_depth, d_match, d_result, ctx->tok_ws, stream) != 0) return MSJ_ERR_HIP;
+    ctx->tok_doc_n = n;
+    return MSJ_SUCCESS;
 }
 
 extern "C" int msj_launch_token_spans(const uint8_t *d_buf, uint64_t len, const uint32_t *d_idx, uint64_t n, uint32_t *d_end,
@@ -294,15 +297,18 @@ int32_t msj_stage2_prep_device(msj_ctx *ctx, const uint8_t *d_buf, uint64_t len,
         if (!hip_ok(hipMalloc(reinterpret_cast<void **>(&ctx->tok_ws), need + need / 4))) return MSJ_MEMALLOC;
         ctx->tok_ws_bytes = need + need / 4;
     }
-    return msj_launch_stage2_prep(d_buf, len, d_idx, n, d_type, d_depth, d_match, d_end, d_flags, d_result, ctx->tok_ws, stream) == 0
-               ? MSJ_SUCCESS
-               : MSJ_ERR_HIP;
+    ctx->tok_doc_n = ~0ull;
+    if (msj_launch_stage2_prep(d_buf, len, d_idx, n, d_type, d_depth, d_match, d_end, d_flags, d_result, ctx->tok_ws, stream) != 0)
+        return MSJ_ERR_HIP;
+    ctx->tok_doc_n = n;
+    return MSJ_SUCCESS;
 }
 
 extern "C" uint64_t msj_documents_workspace_bytes(uint64_t n);
 extern "C" int msj_launch_documents(const uint8_t *d_buf, uint64_t len, int is_final, const uint32_t *d_idx, uint64_t n,
                                     const uint8_t *d_type, const int32_t *d_depth, const msj_carry *d_carry, uint32_t *d_doc_first, uint64_t capacity,
-                                    msj_documents_result *d_result, void *d_ws, void *stream);
+                                    msj_documents_result *d_result, void *d_ws, const void *d_block_agg, void *stream);
+extern "C" void *msj_tokens_doc_aggregates(int32_t *d_ws, uint64_t n);
 
 int32_t msj_documents_device(msj_ctx *ctx, const uint8_t *d_buf, uint64_t len, int32_t is_final, const uint32_t *d_idx,
                              uint64_t n, const uint8_t *d_type, const int32_t *d_depth, const msj_carry *d_carry,
@@ -324,7 +330,12 @@ int32_t msj_documents_device(msj_ctx *ctx, const uint8_t *d_buf, uint64_t len, i
         if (!hip_ok(hipMalloc(&ctx->doc_ws, need + need / 4))) return MSJ_MEMALLOC;
         ctx->doc_ws_bytes = need + need / 4;
     }
-    return msj_launch_documents(d_buf, len, is_final, d_idx, n, d_type, d_depth, d_carry, d_doc_first, capacity, d_result, ctx->doc_ws, stream) == 0
+    // MSJ_DOCS_AFTER_TOKENS: the block aggregates the token pre-pass left in its workspace are for these arrays
+    const void *pre = ((is_final & MSJ_DOCS_AFTER_TOKENS) && ctx->tok_ws && ctx->tok_doc_n == n && n > 0)
+                          ? msj_tokens_doc_aggregates(ctx->tok_ws, n)
+                          : nullptr;
+    return msj_launch_documents(d_buf, len, is_final & MSJ_DOCS_FINAL, d_idx, n, d_type, d_depth, d_carry, d_doc_first, capacity, d_result, ctx->doc_ws,
+                                pre, stream) == 0
                ? MSJ_SUCCESS
                : MSJ_ERR_HIP;
 }

@@ -33,6 +33,7 @@ namespace msj_docs {
 constexpr int kThreads = 256;
 constexpr int kPer = 8;                       // tokens per thread
 constexpr uint32_t kBlock = kThreads * kPer;  // tokens per workgroup
+static_assert(kBlock == 2048, "apply_depth (tokens_kernel.hip) writes the same aggregates with its own block size");
 
 __device__ __forceinline__ bool is_open(uint32_t c) { return c == '{' || c == '['; }
 __device__ __forceinline__ bool is_close(uint32_t c) { return c == '}' || c == ']'; }
@@ -273,18 +274,19 @@ extern "C" uint64_t msj_documents_workspace_bytes(uint64_t n) {
 
 extern "C" int msj_launch_documents(const uint8_t *d_buf, uint64_t len, int is_final, const uint32_t *d_idx, uint64_t n,
                                     const uint8_t *d_type, const int32_t *d_depth, const msj_carry *d_carry, uint32_t *d_doc_first, uint64_t capacity,
-                                    msj_documents_result *d_result, void *d_ws, void *stream) {
+                                    msj_documents_result *d_result, void *d_ws, const void *d_block_agg, void *stream) {
     using namespace msj_docs;
     hipStream_t s = static_cast<hipStream_t>(stream);
     const uint64_t nb64 = (n + kBlock - 1) / kBlock;
     if (nb64 > 0x7FFFFFFFull) return (int)hipErrorInvalidValue;
     const uint32_t nb = (uint32_t)nb64;
     const uint32_t ns = (nb + kSuper - 1u) / kSuper;
-    uint4 *agg = static_cast<uint4 *>(d_ws);                 // per block
-    uint4 *super_agg = agg + (nb ? nb : 1);                  // per run of kSuper blocks
+    // per block; d_block_agg: already written by the token pre-pass for exactly these arrays
+    const uint4 *agg = d_block_agg ? static_cast<const uint4 *>(d_block_agg) : static_cast<const uint4 *>(d_ws);
+    uint4 *super_agg = static_cast<uint4 *>(d_ws) + (nb ? nb : 1);  // per run of kSuper blocks
     uint32_t *off = reinterpret_cast<uint32_t *>(super_agg + (ns ? ns : 1));
     uint32_t *super_off = off + (nb ? nb : 1);
-    if (nb) hipLaunchKernelGGL(doc_count, dim3(nb), dim3(kThreads), 0, s, d_type, d_depth, n, agg);
+    if (nb && !d_block_agg) hipLaunchKernelGGL(doc_count, dim3(nb), dim3(kThreads), 0, s, d_type, d_depth, n, static_cast<uint4 *>(d_ws));
     if (nb) hipLaunchKernelGGL(doc_scan_super, dim3(ns), dim3(256), 0, s, agg, nb, off, super_agg);
     hipLaunchKernelGGL(doc_scan, dim3(1), dim3(1024), 0, s, super_agg, ns, super_off, d_type, d_idx, n, d_buf, len, is_final, d_carry, d_result);
     if (nb) hipLaunchKernelGGL(doc_write, dim3(nb), dim3(kThreads), 0, s, d_type, d_depth, n, off, super_off, d_doc_first, capacity);

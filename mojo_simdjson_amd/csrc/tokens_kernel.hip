@@ -278,9 +278,10 @@ __global__ __launch_bounds__(kThreads) void apply_depth(const uint8_t *__restric
                                                         const uint32_t *__restrict__ super_open, int32_t *__restrict__ depth,
                                                         int32_t *__restrict__ min8, int32_t *__restrict__ min64,
                                                         int32_t *__restrict__ min512, const uint32_t *__restrict__ open_start,
-                                                        uint32_t *__restrict__ opens) {
+                                                        uint32_t *__restrict__ opens, uint4 *__restrict__ doc_agg) {
     __shared__ int wave_sum[kThreads / 64];
     __shared__ int wave_no[kThreads / 64];
+    __shared__ uint32_t doc_cnt[kThreads / 64], doc_start[kThreads / 64], doc_close[kThreads / 64];
     const uint64_t base = (uint64_t)blockIdx.x * kBlock + (uint64_t)threadIdx.x * kPer;
     uint32_t c[kPer];
     if (base + kPer <= n) {
@@ -339,6 +340,43 @@ __global__ __launch_bounds__(kThreads) void apply_depth(const uint8_t *__restric
 #pragma unroll
         for (int k = 0; k < kPer; k++)
             if (base + k < n) depth[base + k] = out[k];
+    }
+    {   // what the document split (documents_kernel.hip, doc_count) would recompute from type[] and depth[]:
+        // per block the number of tokens that start a document (depth 0, not a closing bracket), the last of
+        // them + 1 and the last closing bracket at depth 0 + 1
+        uint32_t cnt = 0, ls = 0, lc = 0;
+#pragma unroll
+        for (int k = 0; k < kPer; k++) {
+            if (base + k < n && out[k] == 0) {
+                if (d[k] < 0) {
+                    lc = (uint32_t)(base + k) + 1u;
+                } else {
+                    cnt++;
+                    ls = (uint32_t)(base + k) + 1u;
+                }
+            }
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            cnt += (uint32_t)__shfl_xor((int)cnt, o);
+            ls = max(ls, (uint32_t)__shfl_xor((int)ls, o));
+            lc = max(lc, (uint32_t)__shfl_xor((int)lc, o));
+        }
+        if (lane == 0) {
+            doc_cnt[wave] = cnt;
+            doc_start[wave] = ls;
+            doc_close[wave] = lc;
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            uint32_t tc = 0, ts = 0, te = 0;
+            for (int w = 0; w < kThreads / 64; w++) {
+                tc += doc_cnt[w];
+                ts = max(ts, doc_start[w]);
+                te = max(te, doc_close[w]);
+            }
+            doc_agg[blockIdx.x] = make_uint4(tc, ts, te, 0);
+        }
     }
     if (min8) {  // the three lowest levels of the 8-ary min tree used for bracket matching
         int m = kNone;
@@ -464,9 +502,16 @@ static uint64_t super_count(uint64_t n) {
     const uint64_t nb = (n + msj_tokens::kBlock - 1) / msj_tokens::kBlock;
     return nb ? (nb + msj_tokens::kSuper - 1) / msj_tokens::kSuper : 1;
 }
-static uint64_t block_words(uint64_t n) {  // 4 (aggregate) + relative start depth + relative start slot per block
+// per block: 4 words (depth aggregate) + 4 (document aggregate, for msj_documents_device) + relative start
+// depth + relative start slot
+static uint64_t block_words(uint64_t n) {
     const uint64_t nb = (n + msj_tokens::kBlock - 1) / msj_tokens::kBlock;
-    return (6 * (nb ? nb : 1) + 7u) & ~7ull;
+    return (10 * (nb ? nb : 1) + 7u) & ~7ull;
+}
+static_assert(msj_tokens::kBlock == 2048, "documents_kernel.hip reads these aggregates with its own block size");
+extern "C" void *msj_tokens_doc_aggregates(int32_t *d_ws, uint64_t n) {
+    const uint64_t nb = (n + msj_tokens::kBlock - 1) / msj_tokens::kBlock;
+    return d_ws + 4 * (nb ? nb : 1);
 }
 static uint64_t head_words(uint64_t n) {  // ... + the same six words per run of kSuper blocks
     return block_words(n) + ((6 * super_count(n) + 7u) & ~7ull);
@@ -495,8 +540,9 @@ static int launch_depth_passes(const uint32_t *d_idx, uint64_t n, uint8_t *d_typ
     (void)d_idx;
     const uint32_t nb = (uint32_t)((n + kBlock - 1) / kBlock);
     const uint64_t nbs = nb ? nb : 1;
-    int32_t *agg = d_ws, *start = d_ws + 4 * nbs;
-    uint32_t *open_start = reinterpret_cast<uint32_t *>(d_ws + 5 * nbs);
+    int32_t *agg = d_ws, *start = d_ws + 8 * nbs;
+    uint32_t *open_start = reinterpret_cast<uint32_t *>(d_ws + 9 * nbs);
+    uint4 *doc_agg = reinterpret_cast<uint4 *>(d_ws + 4 * nbs);
     int32_t *tree = d_ws + head_words(n);  // 32-byte aligned inside the workspace
     const bool want_match = d_match != nullptr && n > 0;
     uint32_t *opens = want_match ? reinterpret_cast<uint32_t *>(tree + tree_words(n) + 64) : nullptr;
@@ -528,7 +574,7 @@ static int launch_depth_passes(const uint32_t *d_idx, uint64_t n, uint8_t *d_typ
     int32_t *l3 = want_match ? (t.nlev > 3 ? lvl[3] : tree + tree_words(n) + 40) : nullptr;
     if (want_match)  // padding entries of the tree levels must never qualify: 0x7F7F7F7F
         (void)hipMemsetAsync(tree, 0x7F, (tree_words(n) + 64) * sizeof(int32_t), s);
-    if (nb) hipLaunchKernelGGL(apply_depth, dim3(nb), dim3(kThreads), 0, s, d_type, n, start, super_start, super_open, d_depth, l1, l2, l3, open_start, opens);
+    if (nb) hipLaunchKernelGGL(apply_depth, dim3(nb), dim3(kThreads), 0, s, d_type, n, start, super_start, super_open, d_depth, l1, l2, l3, open_start, opens, doc_agg);
     if (want_match) {
         for (int k = 4; k < t.nlev; k++)
             hipLaunchKernelGGL(build_level, dim3((t.cnt[k] + 255u) / 256u), dim3(256), 0, s, t.lv[k - 1], t.cnt[k - 1], lvl[k], t.cnt[k]);

@@ -143,11 +143,12 @@ class Stage1Device:
         return d_type[:n], d_depth[:n], res, (d_match[:n] if match else None), d_end[:n], d_flags[:n]
 
     def documents(self, d_buf, length, d_idx, n, d_type, d_depth, is_final=False, d_carry=None, d_doc_first=None,
-                  d_result=None, sync=True):
+                  d_result=None, sync=True, after_tokens=False):
         """Document split of one window of a stream of concatenated documents (``msj_documents_device``):
         the token index at which each document starts, and how far the complete documents reach.
         d_buf / length: the window; is_final: it ends the stream; d_type / d_depth: from ``tokens`` for the
-        same d_idx; d_carry: the window's stage-1 carry_out.
+        same d_idx; d_carry: the window's stage-1 carry_out; after_tokens: d_type / d_depth are what the last
+        ``tokens`` / ``stage2_prep`` call of this device wrote, untouched since (MSJ_DOCS_AFTER_TOKENS).
         Returns (d_doc_first int32[capacity], msj_documents_result) -- blocking for the 32-byte result --
         or, with sync=False, (d_doc_first, d_result) with nothing waited for."""
         n = int(n)
@@ -155,7 +156,8 @@ class Stage1Device:
             d_doc_first = torch.empty(max(n, 1), dtype=torch.int32, device=self.device)
         if d_result is None:
             d_result = torch.zeros(32, dtype=torch.uint8, device=self.device)
-        rc = self.lib.msj_documents_device(self.ctx, _ptr(d_buf), int(length), int(is_final), _ptr(d_idx), n, _ptr(d_type),
+        rc = self.lib.msj_documents_device(self.ctx, _ptr(d_buf), int(length), int(bool(is_final)) | (2 if after_tokens else 0), _ptr(d_idx), n,
+                                           _ptr(d_type),
                                            _ptr(d_depth), _ptr(d_carry) if d_carry is not None else None, _ptr(d_doc_first),
                                            d_doc_first.numel(), _ptr(d_result), self._stream())
         if rc != 0:

@@ -62,7 +62,7 @@ class DocumentStream:
     two bytes beyond).  The arrays a Window carries are reused by the next one.
     """
 
-    def __init__(self, dev, d_buf, length=None, window=1 << 28, flags=0, index_capacity=None):
+    def __init__(self, dev, d_buf, length=None, window=1 << 28, flags=0, index_capacity=None, reuse_counts=True):
         self.dev = dev
         self.d_buf = d_buf
         self.length = int(d_buf.numel() if length is None else length)
@@ -72,6 +72,7 @@ class DocumentStream:
         if d_buf.data_ptr() % 16:
             raise ValueError("the stream must be 16-byte aligned")
         self.flags = int(flags) & 3
+        self.reuse_counts = bool(reuse_counts)  # MSJ_DOCS_AFTER_TOKENS: the split starts from the pre-pass's block counts
         w = min(self.window + 16, max(self.length, 16))
         if index_capacity is None:
             index_capacity = w + 3 if w <= (64 << 20) else w // 2 + 1024
@@ -106,7 +107,7 @@ class DocumentStream:
             d_type, d_depth, _ = dev.tokens(d_win, wlen, self._idx, n, d_type=self._type, d_depth=self._depth,
                                             d_result=self._results[:24], sync=False)
             d_first, _ = dev.documents(d_win, wlen, self._idx, n, d_type, d_depth, is_final=last, d_carry=self._carry,
-                                       d_doc_first=self._first, d_result=self._results[32:64], sync=False)
+                                       d_doc_first=self._first, d_result=self._results[32:64], sync=False, after_tokens=self.reuse_counts)
             blob = self._results.cpu().numpy().tobytes()
             tok = _lib.MsjTokensResult.from_buffer_copy(blob[:24])
             res = _lib.MsjDocumentsResult.from_buffer_copy(blob[32:64])

@@ -43,15 +43,21 @@ print(f"document split: {nbytes} B, {n} structurals, {res.n_documents} documents
       f"{n / ms / 1e6:.1f} G structurals/s, {alg / ms / 1e6:.0f} GB/s of its own traffic, {nbytes / ms / 1e6:.0f} GB/s of JSON")
 del d_idx, t, d, d_first
 for window in (64 << 20, 256 << 20, 1 << 30):
-    for rep in range(2):
+    best = {}
+    for rep in range(6):
+        reuse = rep % 2 == 0
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         docs = 0
-        stream = DocumentStream(dev, d_buf, nbytes, window=window, index_capacity=int((window + 16) * 0.4))
+        stream = DocumentStream(dev, d_buf, nbytes, window=window, index_capacity=int((window + 16) * 0.4), reuse_counts=reuse)
         for w in stream:
             docs += w.n_documents
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
+        if rep >= 2:
+            best[reuse] = min(best.get(reuse, 1e9), dt)
+    dt = best[True]
     print(f"DocumentStream window {window >> 20:5d} MiB: {stream.windows} windows, {docs} documents, {dt * 1e3:.2f} ms, "
-          f"{nbytes / dt / 1e9:.0f} GB/s of JSON, {docs / dt / 1e6:.0f} M documents/s")
+          f"{nbytes / dt / 1e9:.0f} GB/s of JSON, {docs / dt / 1e6:.0f} M documents/s "
+          f"({best[False] * 1e3:.2f} ms when the split counts the document starts itself)")
 dev.close()

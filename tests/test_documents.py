@@ -114,7 +114,7 @@ def dev():
     d.close()
 
 
-def _gpu_window(dev, data, skip=0, capacity=None, is_final=False):
+def _gpu_window(dev, data, skip=0, capacity=None, is_final=False, after_tokens=False):
     """Stage 1 (non-final shard, zero carries) + token pre-pass + document split of one window."""
     import torch
 
@@ -128,7 +128,7 @@ def _gpu_window(dev, data, skip=0, capacity=None, is_final=False):
     first = None
     if capacity is not None:
         first = torch.full((max(capacity, 1),), -1, dtype=torch.int32, device=dev.device)[:capacity]
-    d_first, res = dev.documents(d_buf, len(data), d_idx, n, t, d, is_final=is_final, d_carry=cout, d_doc_first=first)
+    d_first, res = dev.documents(d_buf, len(data), d_idx, n, t, d, is_final=is_final, d_carry=cout, d_doc_first=first, after_tokens=after_tokens)
     got = (int(res.n_documents), int(res.n_complete), int(res.tokens_complete), int(res.resume_offset))
     k = min(got[0], d_first.numel())
     return (d_idx[:n].cpu().numpy().view(np.uint32), bool(c.in_string), t.cpu().numpy(), d.cpu().numpy(),
@@ -138,8 +138,8 @@ def _gpu_window(dev, data, skip=0, capacity=None, is_final=False):
 def _check_window(dev, oracle, data, where, capacity=None):
     widx, wopen = helpers.oracle_window(oracle.msj_oracle_stage1, data)
     wtyp, wdep, _ = helpers.oracle_tokens(data, widx)
-    for is_final in (False, True):
-        idx, open_string, typ, dep, first, got = _gpu_window(dev, data, capacity=capacity, is_final=is_final)
+    for is_final, after_tokens in ((False, False), (True, True), (False, True)):  # with / without the counts of the pre-pass
+        idx, open_string, typ, dep, first, got = _gpu_window(dev, data, capacity=capacity, is_final=is_final, after_tokens=after_tokens)
         assert np.array_equal(idx, widx) and open_string == wopen, where
         wfirst, want = helpers.oracle_documents(data, widx, wtyp, wdep, wopen, capacity=capacity, is_final=is_final)
         assert got == want, (where, is_final, got, want)
