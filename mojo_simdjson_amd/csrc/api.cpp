@@ -15,6 +15,12 @@
 #include "../../include/msj_stage1.h"
 #include "stage1_kernel.h"
 
+// small-input path of msj_stage1: input, result and len + 3 indices fit the pinned staging buffer
+constexpr uint64_t kSmallInput = 64u << 10;
+constexpr uint64_t kPinBytes = kSmallInput + 64 + (kSmallInput + 3) * sizeof(uint32_t) + 64;
+
+static_assert(sizeof(msj_carry) == 64, "the small-input staging layout assumes a 64-byte carry");
+
 struct msj_ctx {
     int device = 0;
     // Two workspace buffers (tickets + descriptors) used alternately.  A launch needs its
@@ -32,6 +38,8 @@ struct msj_ctx {
     uint32_t *d_idx = nullptr;
     uint64_t d_idx_words = 0;
     msj_carry *d_result = nullptr;
+    uint8_t *h_pin = nullptr;     // pinned host staging of the small-input path of msj_stage1 (kPinBytes)
+    uint8_t *d_small = nullptr;   // ... and its device side: [input][msj_carry][indices], same layout
     uint32_t grid = 0;            // persistent workgroups per launch (CUs x resident blocks per CU)
     int32_t *tok_ws = nullptr;    // block aggregates of the token pre-pass
     uint64_t tok_ws_bytes = 0;
@@ -202,6 +210,8 @@ void msj_ctx_destroy(msj_ctx *ctx) {
     if (ctx->d_in) (void)hipFree(ctx->d_in);
     if (ctx->d_idx) (void)hipFree(ctx->d_idx);
     if (ctx->d_result) (void)hipFree(ctx->d_result);
+    if (ctx->h_pin) (void)hipHostFree(ctx->h_pin);
+    if (ctx->d_small) (void)hipFree(ctx->d_small);
     delete ctx;
 }
 
@@ -390,6 +400,33 @@ int32_t msj_stage1_ctx(msj_ctx *ctx, const uint8_t *buf, uint64_t len, uint32_t 
     if (len > MSJ_MAX_SEGMENT_BYTES) return MSJ_CAPACITY;
     if (!hip_ok(hipSetDevice(ctx->device))) return MSJ_ERR_HIP;
 
+    // Small inputs: latency, not bandwidth.  Through pinned staging everything is enqueued at once -- input up,
+    // kernel, result and ALL len + 3 index slots down in one copy (n is not known yet; 4 bytes per input byte
+    // is cheap at this size) -- and the host waits once instead of three times (pageable copies are synchronous).
+    if (len <= kSmallInput && idx_capacity >= len + 3) {
+        if (!ctx->h_pin && !hip_ok(hipHostMalloc(reinterpret_cast<void **>(&ctx->h_pin), kPinBytes, hipHostMallocDefault))) ctx->h_pin = nullptr;
+        if (!ctx->d_small && !hip_ok(hipMalloc(reinterpret_cast<void **>(&ctx->d_small), kPinBytes))) ctx->d_small = nullptr;
+    }
+    if (len <= kSmallInput && idx_capacity >= len + 3 && ctx->h_pin && ctx->d_small) {
+        // [0, kSmallInput): input | [kSmallInput, +64): msj_carry | then len + 3 indices
+        std::memcpy(ctx->h_pin, buf, len);
+        if (!hip_ok(hipMemcpyAsync(ctx->d_small, ctx->h_pin, len, hipMemcpyHostToDevice, nullptr))) return MSJ_ERR_HIP;
+        msj_carry *d_res = reinterpret_cast<msj_carry *>(ctx->d_small + kSmallInput);
+        uint32_t *d_ix = reinterpret_cast<uint32_t *>(ctx->d_small + kSmallInput + 64);
+        int32_t rc = msj_stage1_device(ctx, ctx->d_small, len, d_ix, len + 3, d_res, nullptr, flags);
+        if (rc != MSJ_SUCCESS) return rc;
+        if (!hip_ok(hipMemcpyAsync(ctx->h_pin + kSmallInput, d_res, 64 + (len + 3) * sizeof(uint32_t), hipMemcpyDeviceToHost, nullptr)) ||
+            !hip_ok(hipStreamSynchronize(nullptr)))
+            return MSJ_ERR_HIP;
+        const msj_carry res = *reinterpret_cast<const msj_carry *>(ctx->h_pin + kSmallInput);
+        if (utf8_verdict_out) *utf8_verdict_out = res.utf8_error ? MSJ_UTF8_ERROR : MSJ_SUCCESS;
+        if (res.code == MSJ_UNCLOSED_STRING || res.code == MSJ_UNESCAPED_CHARS || res.code == MSJ_UNEXPECTED_ERROR ||
+            res.code == MSJ_CAPACITY)
+            return res.code;  // the reference returns before it sets n or the trailer (:151-158)
+        std::memcpy(idx_out, ctx->h_pin + kSmallInput + 64, (res.count + 3) * sizeof(uint32_t));
+        *n_out = res.count;
+        return res.code;
+    }
     // device staging (the reference's allocate(len), dom_parser_implementation.mojo:85-89)
     const uint64_t in_bytes = (len + 63u) & ~63ull;
     if (in_bytes > ctx->d_in_bytes) {
