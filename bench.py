@@ -157,6 +157,8 @@ def main():
     ap.add_argument("--gib-per-gpu", type=float, default=1.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-utf8", action="store_true", help="skip UTF-8 validation (not the headline config)")
+    ap.add_argument("--no-emit", action="store_true",
+                    help="diagnostic: summary pass only, no index writes (never a reported number)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -213,7 +215,14 @@ def main():
     d_idx = torch.empty(cap, dtype=torch.int32, device=device)
     d_res = dev.new_carry()
 
-    if world == 1 and shard_len <= 0xFFFFFFFF:
+    if world == 1 and args.no_emit:
+        d_zero = dev.new_carry()
+
+        def step():
+            dev.shard(d_shard, shard_len, d_idx, d_zero, d_res, is_final=True, no_emit=True, trailer_len=total_len,
+                      flags=flags)
+            return None
+    elif world == 1 and shard_len <= 0xFFFFFFFF:
         def step():
             dev.index(d_shard, d_idx, d_res, flags=flags, length=shard_len)
             return None
@@ -337,6 +346,7 @@ def main():
                 "structurals_total": total_count,
                 "density": round(total_count / total_len, 5),
                 "utf8_validation": not args.no_utf8,
+                **({"diagnostic": "no-emit summary pass: not a stage-1 result"} if args.no_emit else {}),
                 "sharding": "single GPU" if world == 1 else f"{world} byte-range shards, RCCL stitch",
             },
             "roofline": {
