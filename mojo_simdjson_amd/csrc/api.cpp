@@ -41,6 +41,7 @@ struct msj_ctx {
     uint8_t *h_pin = nullptr;     // pinned host staging of the small-input path of msj_stage1 (kPinBytes)
     uint8_t *d_small = nullptr;   // ... and its device side: [input][msj_carry][indices], same layout
     uint32_t grid = 0;            // persistent workgroups per launch (CUs x resident blocks per CU)
+    uint32_t wait_ticks = msj::kWaitTicksDefault;  // bound of the kernel's waits (10 ns ticks)
     int32_t *tok_ws = nullptr;    // block aggregates of the token pre-pass
     uint64_t tok_ws_bytes = 0;
     uint64_t tok_doc_n = ~0ull;   // the token count whose document aggregates tok_ws holds (~0: none)
@@ -130,6 +131,7 @@ int32_t enqueue_shard(msj_ctx *ctx, const uint8_t *d_buf, uint64_t len, uint32_t
         if (no_emit) a.flags |= msj::kFlagNoEmit;
         if (s == 0) a.flags |= flags & (15u << msj::kFlagSkipShift);
         a.stamps = g_stamps;
+        a.wait_ticks = ctx->wait_ticks;
         // ticket + descriptors must read as "not ready" at launch: this launch's buffer is clean
         // already in the steady state; the other one is cleaned by this launch if its dirt has
         // this launch's layout, by a memset otherwise

@@ -246,6 +246,33 @@ MSJ_HD uint32_t top_run(uint64_t m) {
 #endif
 }
 
+// JsonEscapeScanner.next (json_escape_scanner.mojo:18-45) for next_is_escaped = 0, in the pieces the
+// kernel uses (a block that starts escaped is rare: the kernel takes escaped_mask() for those tiles).
+//   escape_tt0      tt = t ^ ODD, t = (((bs << 1) | ODD) - bs) ^ ODD  (:39-45); the shift by one is an
+//                   add and a funnel shift (a 64-bit shift issues at a quarter of the rate)
+//   escape_out0     next_is_escaped of the next block = bit 63 of escape = t & bs  (:30-31)
+//   unescaped_quotes0  eq['"'] & ~escaped (json_string_scanner.mojo:58): on a quote byte backslash is 0,
+//                   so escaped = t ^ backslash = t there
+MSJ_HD uint64_t escape_tt0(uint64_t backslash) {
+    const uint64_t ODD = 0xAAAAAAAAAAAAAAAAull;
+    const uint32_t lo = (uint32_t)backslash, hi = (uint32_t)(backslash >> 32);
+    uint32_t sl;
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm("v_add_u32_e32 %0, %1, %1" : "=v"(sl) : "v"(lo));  // lo << 1 at full rate
+    const uint32_t sh = __builtin_amdgcn_alignbit(hi, lo, 31);
+#else
+    sl = lo << 1;
+    const uint32_t sh = (hi << 1) | (lo >> 31);
+#endif
+    return (u64(sl, sh) | ODD) - backslash;
+}
+MSJ_HD uint32_t escape_out0(uint64_t tt, uint64_t backslash) {
+    return lut3<MSJ_TT((TA ^ TB) & TC)>((uint32_t)(tt >> 32), 0xAAAAAAAAu, (uint32_t)(backslash >> 32)) >> 31;
+}
+MSJ_HD uint64_t unescaped_quotes0(uint64_t quote_chr, uint64_t tt) {
+    return lut3<MSJ_TT(TA & ~(TB ^ TC))>(quote_chr, tt, 0xAAAAAAAAAAAAAAAAull);
+}
+
 // ---------------------------------------------------------------------------
 // UTF-8 (strict, Unicode Table 3-7) on bit-planes.  The reference's checker is
 // an empty stub (json_structural_indexer.mojo:16-30); this implements what
@@ -377,14 +404,23 @@ MSJ_HD BlockOut block_step(const uint32_t x[16], uint64_t valid, BlockCarry &cy)
 #pragma unroll
     for (int k = 0; k < 8; k++) p[k] &= valid;
     const Classes c = classify(p, valid);
+    // the kernel's two escape paths: carry-in 0 (pieces above), carry-in 1 (escaped_mask)
     uint32_t e_out;
-    const uint64_t escaped = escaped_mask(c.backslash, cy.next_is_escaped, &e_out);
-    const uint64_t quote = c.quote_chr & ~escaped;
+    uint64_t quote;
+    if (cy.next_is_escaped == 0) {
+        const uint64_t tt = escape_tt0(c.backslash);
+        e_out = escape_out0(tt, c.backslash);
+        quote = unescaped_quotes0(c.quote_chr, tt);
+    } else {
+        const uint64_t escaped = escaped_mask(c.backslash, cy.next_is_escaped, &e_out);
+        quote = c.quote_chr & ~escaped;
+    }
     const uint64_t in_string = prefix_xor(quote) ^ (uint64_t)(-(int64_t)cy.in_string);
-    const uint64_t scalar = ~(c.op | c.ws);
-    const uint64_t nonquote_scalar = scalar & ~quote;
+    // scalar = ~(op | ws); nonquote_scalar = scalar & ~quote  (json_scanner.mojo:64-70)
+    const uint64_t nonquote_scalar = lut3<MSJ_TT(~TA & ~TB & ~TC)>(c.op, c.ws, quote);
     const uint64_t follows = (nonquote_scalar << 1) | cy.prev_scalar;
-    const uint64_t potential = c.op | (scalar & ~follows);
+    // potential_structural_start = op | (scalar & ~follows) = op | (~ws & ~follows)  (:40-49)
+    const uint64_t potential = lut3<MSJ_TT(TA | (~TB & ~TC))>(c.op, c.ws, follows);
     BlockOut o;
     o.structural = potential & ~(in_string ^ quote);
     o.unescaped = c.ctrl & in_string;

@@ -23,7 +23,7 @@ constexpr uint32_t kRange = kWaves * kBatch;       // tiles per ticket range = p
 constexpr uint32_t kPendSlots = kDefer * kBatch;   // parked tiles per wave
 constexpr int kResolveE = 4;                       // tiles folded per resolver lane
 constexpr uint32_t kResolveChunk = 64u * kResolveE; // tiles per resolver chunk (one wave, one round)
-constexpr uint32_t kSpinLimit = 1u << 18;          // bounded polling (internal_error on expiry, ~0.3 s)
+constexpr uint32_t kWaitTicksDefault = 200000000u; // bound of every inter-workgroup wait: 2 s of s_memrealtime (100 MHz)
 // largest segment one launch indexes with uint32 offsets (multiple of the tile)
 constexpr uint64_t kSegmentBytes = 0xFFFF0000ull;
 
@@ -50,6 +50,7 @@ struct KernelArgs {
     uint64_t trailer_len;     // value of the two `len` trailer words (FINAL only)
     uint32_t ntiles;
     uint32_t flags;
+    uint32_t wait_ticks;      // bound of every wait in the kernel, in s_memrealtime ticks (10 ns); expiry poisons the launch
     uint64_t *stamps;         // diagnostic builds only (-DMSJ_STAMPS): 16 words per tile, else null
 };
 

@@ -50,7 +50,7 @@ namespace msj {
 // agg[t] (written by the tile's wave), status 1:
 //   61 quote parity, 60 err(s_in=0), 59 err(s_in=1), 58 e_out, 57 ps_out,
 //   56 utf8 err, 55 utf8 sequence pending at tile end, 54 poisoned (timeout),
-//   30:15 count(s_in=1), 14:0 count(s_in=0)
+//   31:16 count(s_in=1), 15:0 count(s_in=0)
 // pre[t] (written by the resolver), status 2:
 //   61 in_string before the tile, 60 unescaped err before, 56 utf8 err before,
 //   54 poisoned, 31:0 structurals before the tile (launch-relative)
@@ -129,12 +129,14 @@ __device__ __forceinline__ uint64_t uniform64(uint64_t v) {
 
 struct Shared {
     uint32_t role;
-    uint32_t range_lo[2];    // worker workgroups: base tile of the next range (double buffered)
-    uint32_t range_seq;      // ... and the iteration it was handed over in (wave 0 -> the others)
+    uint32_t shard;          // worker workgroups: the ticket shard they draw from
+    uint32_t first_lo;       // ... and the base tile of their first range
+    // worker workgroups: wave 0 hands the next range to the other waves with ONE 8-byte LDS store:
+    // low word = base tile of the next range, high word = the iteration it is for (r + 1)
+    uint64_t handoff __attribute__((aligned(8)));
     uint64_t tagg[2][kRange]; // worker workgroups: the range's tile aggregates, in tile order
     // resolver hand-off between its waves
     uint32_t rs_seq, rs_s, rs_cnt, rs_err, rs_u8, rs_poison;
-    uint32_t shard;          // worker workgroups: the ticket shard they draw from
     // per-wave index staging for coalesced stores
     uint32_t stage[kWaves][kStageWords] __attribute__((aligned(16)));
     // computed-but-not-yet-emitted tiles (two ranges deep), per wave and slot:
@@ -144,15 +146,34 @@ struct Shared {
     uint32_t pend_meta[kWaves][kPendSlots][4] __attribute__((aligned(16)));  // tile (~0 = empty), tile_cnt, in_cnt, in_s
 };
 
+// Waits are bounded by WALL TIME (s_memrealtime: a constant 100 MHz counter), not by a number
+// of polls: a.wait_ticks (default 2 s; tests lower it to force the expiry path).  The clock is read
+// once per 256 polls, for the first time after 256 (a short wait never reads it).  Expiry poisons
+// the launch (internal_error); the host then re-runs the segment through the two-pass kernels,
+// which wait for nothing (api.cpp).
+struct WaitClock {
+    uint32_t spins = 0, t0 = 0;
+    __device__ __forceinline__ bool expired(const uint32_t wait_ticks) {
+        if ((++spins & 255u) != 0u) return false;
+        const uint32_t now = (uint32_t)__builtin_amdgcn_s_memrealtime();  // 32 bits of 10 ns ticks: 42 s
+        if (spins == 256u) {
+            t0 = now;
+            return false;
+        }
+        return now - t0 > wait_ticks;
+    }
+    __device__ __forceinline__ void restart() { spins = 0; }
+};
+
 // Bounded poll of one descriptor until its status is non-zero.
-__device__ __forceinline__ uint64_t wait_desc(const uint64_t *p, uint32_t *timeout) {
+__device__ __forceinline__ uint64_t wait_desc(const uint64_t *p, const uint32_t wait_ticks, uint32_t *timeout) {
     // one address for the whole wave: the value is uniform (scalar loop control)
     uint64_t d = uniform64(ld_desc(p));
-    uint32_t spins = 0;
-    while ((d >> 62) == 0) {
+    WaitClock clk;
+    while ((d >> 62) == 0ull) {
         __builtin_amdgcn_s_sleep(2);
         d = uniform64(ld_desc(p));
-        if (++spins > kSpinLimit) {
+        if (clk.expired(wait_ticks)) {
             *timeout = 1;
             break;
         }
@@ -167,23 +188,40 @@ struct Block {
     uint32_t wb;
 };
 
-// Branch-free (so the compiler can leave all five loads in flight): pieces past
-// the end are redirected to the last 16-B piece that starts inside the input;
-// whatever they return is masked by `valid` in compute_tile.
-__device__ __forceinline__ void load_block(const KernelArgs &a, uint32_t tile, uint32_t lane, Block &b) {
+// Branch-free (so the compiler can leave all five loads in flight) and free of vector address
+// arithmetic beyond one clamp per piece: the tile's base is scalar, the lane's piece offsets
+// are loop invariants (lane_off[k] = 64 * lane + 16 * k), and pieces past the end are redirected to the
+// last 16-B piece that starts inside the input -- whatever they return is masked by `valid` in
+// compute_tile.  For a tile inside the input the clamp is a no-op.
+__device__ __forceinline__ void load_block(const KernelArgs &a, const uint32_t tile, const uint32_t (&lane_off)[4],
+                                           const uint32_t lane, Block &b) {
     // one launch covers < 2^32 bytes (kSegmentBytes), so offsets fit 32 bits
     const uint32_t len32 = (uint32_t)a.len;
-    const uint32_t blk_off = tile * kTileBytes + lane * 64u;
-    const uint32_t last_piece = (len32 - 1u) & ~15u;  // buf is 16-B aligned
+    const uint32_t tile_off = tile * kTileBytes;                // uniform; tile < ntiles, so tile_off < len
+    const uint8_t *base = a.buf + tile_off;                     // uniform
+    const uint32_t lim = ((len32 - 1u) & ~15u) - tile_off;      // last piece that starts inside the input (buf is 16-B aligned)
 #pragma unroll
     for (int k = 0; k < 4; k++) {
-        const uint32_t off = blk_off + 16u * k;
-        b.q[k] = *reinterpret_cast<const uint4 *>(a.buf + (off < last_piece ? off : last_piece));
+        const uint32_t off = lane_off[k] < lim ? lane_off[k] : lim;
+        b.q[k] = *reinterpret_cast<const uint4 *>(base + off);
     }
+    // the 64 bytes in front of the tile; the launch's first tile has them only with kFlagHasPrefix
+    // (without: any readable bytes will do, compute_tile ignores them)
     const bool have_window = (tile > 0) || (a.flags & kFlagHasPrefix);
-    const int64_t woff = have_window ? (int64_t)(tile * kTileBytes) - 64 + (int64_t)lane
-                                     : (int64_t)(lane < len32 ? lane : len32 - 1u);
-    b.wb = a.buf[woff];
+    const uint8_t *wbase = have_window ? base - 64 : a.buf;
+    const uint32_t wlim = have_window ? 63u : len32 - 1u;
+    b.wb = wbase[lane < wlim ? lane : wlim];
+}
+
+// The kBatch tiles of this wave in the range that starts at tile `lo`.
+__device__ __forceinline__ void load_range(const KernelArgs &a, const uint32_t lo, const uint32_t wave,
+                                           const uint32_t (&lane_off)[4], const uint32_t lane, Block (&blk)[kBatch]) {
+    const uint32_t ntiles = a.ntiles;
+#pragma unroll
+    for (uint32_t j = 0; j < kBatch; j++) {
+        const uint32_t t = lo + kWaves * j + wave;
+        load_block(a, t < ntiles ? t : ntiles - 1u, lane_off, lane, blk[j]);  // past the end: harmless re-read
+    }
 }
 
 // Forces the wait for prefetched registers HERE (their loads were issued a whole
@@ -276,23 +314,75 @@ __device__ __forceinline__ void scatter_bits16(uint32_t t, uint32_t lds_byte_add
         : "vcc", "memory");
 }
 
-// What a computed tile keeps in registers until its indices are emitted.
+// What a computed tile keeps in registers until it is parked.
 struct Pending {
     uint64_t T0, T1;     // structural_start masks for tile s_in = 0 / 1
     uint32_t excl;       // packed exclusive wave scan of the per-lane counts
-    uint32_t tile_cnt;   // packed tile totals
-    uint32_t tile;
+    uint32_t tile_cnt;   // packed tile totals (uniform)
 };
 
-// ---- one tile: masks, carries, counts; publishes the tile aggregate ------------
-__device__ __forceinline__ Pending compute_tile(const KernelArgs &a, const uint32_t tile,
-                                                const uint32_t lane, const Block &blk,
-                                                uint32_t &timeout, uint64_t &agg_word) {
-    uint64_t *agg = a.ws + kDescOffset;
-    const uint32_t len = (uint32_t)a.len;  // < 2^32 per launch
-    const uint32_t blk_off = tile * kTileBytes + lane * 64u;
-    MSJ_STAMP(tile, 1);
+// Carries into a tile from the 64 bytes in front of it: wave-uniform, and apart from one compare
+// (the window's backslash mask) and three lane reads, branch-free scalar code that the scheduler can
+// run beside the bit-plane transpose.  The escape scanner (json_escape_scanner.mojo:18-45) on the
+// window's backslash mask with carry-in 0 is exact unless the run of backslashes in front of the
+// tile reaches back to the window's first byte (>= 63 bytes): `resolved` is false then and the tile
+// takes the exact carries its predecessor publishes with its aggregate.
+struct TileCarry {
+    uint32_t e_in, ps_in, u8_in;
+    bool resolved;
+};
+__device__ __forceinline__ TileCarry window_carries(const KernelArgs &a, const uint32_t tile, const uint32_t wb,
+                                                    const uint32_t carry0) {
+    TileCarry c;
+    const bool have_window = (tile > 0) || (a.flags & kFlagHasPrefix);
+    const uint32_t b1 = bcast(wb, 63), b2 = bcast(wb, 62), b3 = bcast(wb, 61);  // byte[-1], [-2], [-3]
+    c.u8_in = 0;
+    if (have_window && ((b1 | b2 | b3) & 0x80u)) {
+        // utf8 carry word of the window's last bytes (lane_math.h layout)
+        const uint32_t l1 = (b1 >= 0xC0u && b1 < 0xF8u), l1_34 = (b1 >= 0xE0u && b1 < 0xF8u);
+        const uint32_t l1_4 = (b1 >= 0xF0u && b1 < 0xF8u);
+        const uint32_t l2_34 = (b2 >= 0xE0u && b2 < 0xF8u), l2_4 = (b2 >= 0xF0u && b2 < 0xF8u);
+        const uint32_t l3_4 = (b3 >= 0xF0u && b3 < 0xF8u);
+        c.u8_in = l1 | (l2_34 << 1) | (l1_34 << 2) | (l3_4 << 3) | (l2_4 << 4) | (l1_4 << 5) |
+                  ((uint32_t)(b1 == 0xE0u) << 6) | ((uint32_t)(b1 == 0xEDu) << 7) |
+                  ((uint32_t)(b1 == 0xF0u) << 8) | ((uint32_t)(b1 == 0xF4u) << 9);
+    }
+    const uint64_t WB = __ballot(wb == 0x5Cu);
+    constexpr uint64_t ODD = 0xAAAAAAAAAAAAAAAAull;
+    const uint64_t t = (((WB << 1) | ODD) - WB) ^ ODD;      // :39-45 with next_is_escaped = 0
+    const uint32_t esc1 = (uint32_t)((t ^ WB) >> 63);       // byte[-1] is escaped
+    // op | ws as a 128-entry bit table (haswell.mojo:22-74):
+    // {09,0A,0C,0D,1A,20,2C,3A} in the low word, {5B,5D,7B,7D} in the high word
+    constexpr uint64_t kNsLo = (1ull << 0x09) | (1ull << 0x0A) | (1ull << 0x0C) | (1ull << 0x0D) |
+                               (1ull << 0x1A) | (1ull << 0x20) | (1ull << 0x2C) | (1ull << 0x3A);
+    constexpr uint64_t kNsHi = (1ull << (0x5B - 64)) | (1ull << (0x5D - 64)) |
+                               (1ull << (0x7B - 64)) | (1ull << (0x7D - 64));
+    const uint64_t tab = (b1 & 0x40u) ? kNsHi : kNsLo;
+    const uint32_t nonscalar = (uint32_t)(tab >> (b1 & 63u)) & (uint32_t)(b1 < 0x80u);
+    // byte[-1] an unescaped backslash: the tile's first byte is escaped
+    c.e_in = (uint32_t)((t & WB) >> 63);
+    // prev_scalar: byte[-1] is a scalar character (a backslash is one) and not a real quote
+    c.ps_in = ~nonscalar & 1u & ((b1 == 0x22u) ? esc1 : 1u);
+    // the run in front of the tile reaches the window's first byte: not decided by the window
+    c.resolved = (WB | (1ull << 63)) != ~0ull;
+    if (tile == 0) {
+        // exact state at the first byte of this launch
+        c.e_in = carry0 & 1u;
+        c.ps_in = (carry0 >> 1) & 1u;
+        c.resolved = true;
+    }
+    return c;
+}
 
+// ---- one tile: masks, carries, counts; returns the tile aggregate in agg_word ------------
+// Written for latency as much as for instruction count: the wave-level decisions (a block starts
+// escaped? any byte >= 0x80?) are taken from ballots issued long before the branch that needs
+// them, and there is ONE rare branch (redo the escape scanner) instead of one per special case.
+__device__ __forceinline__ Pending compute_tile(const KernelArgs &a, const uint32_t tile,
+                                                const uint32_t lane, const Block &blk, const uint32_t carry0,
+                                                uint32_t &timeout, uint64_t &agg_word) {
+    const uint32_t len = (uint32_t)a.len;  // < 2^32 per launch
+    MSJ_STAMP(tile, 1);
     uint32_t x[16];
 #pragma unroll
     for (int k = 0; k < 4; k++) {
@@ -301,123 +391,96 @@ __device__ __forceinline__ Pending compute_tile(const KernelArgs &a, const uint3
         x[4 * k + 2] = blk.q[k].z;
         x[4 * k + 3] = blk.q[k].w;
     }
-    uint64_t valid;  // bytes past the end behave as the reference's 0x20 padding (:103-107)
-    if (blk_off >= len)
-        valid = 0ull;
-    else if (len - blk_off >= 64u)
-        valid = ~0ull;
-    else
-        valid = (1ull << (len - blk_off)) - 1ull;
+    TileCarry tc = window_carries(a, tile, blk.wb, carry0);
     // a window of a document stream starts at a document, its 16-byte aligned base up to 15 bytes
     // earlier: those bytes (the end of the previous document) read as blanks
     const uint32_t skip = tile == 0 ? (a.flags >> kFlagSkipShift) & 15u : 0u;  // uniform
-
-    // ---- carries into the tile from the 64 bytes in front of it (wave-uniform; apart from
-    //      one compare + ballot for the backslash run this is scalar code on byte[-1..-3])
-    const bool have_window = (tile > 0) || (a.flags & kFlagHasPrefix);
-    uint32_t tile_e_in, tile_ps_in, tile_u8_in = 0;
-    {
-        const uint32_t wb = blk.wb;
-        const uint32_t b1 = bcast(wb, 63), b2 = bcast(wb, 62), b3 = bcast(wb, 61);  // byte[-1], [-2], [-3]
-        if (have_window && ((b1 | b2 | b3) & 0x80u)) {
-            // utf8 carry word of the window's last bytes (lane_math.h layout)
-            const uint32_t l1 = (b1 >= 0xC0u && b1 < 0xF8u), l1_34 = (b1 >= 0xE0u && b1 < 0xF8u);
-            const uint32_t l1_4 = (b1 >= 0xF0u && b1 < 0xF8u);
-            const uint32_t l2_34 = (b2 >= 0xE0u && b2 < 0xF8u), l2_4 = (b2 >= 0xF0u && b2 < 0xF8u);
-            const uint32_t l3_4 = (b3 >= 0xF0u && b3 < 0xF8u);
-            tile_u8_in = l1 | (l2_34 << 1) | (l1_34 << 2) | (l3_4 << 3) | (l2_4 << 4) | (l1_4 << 5) |
-                         ((uint32_t)(b1 == 0xE0u) << 6) | ((uint32_t)(b1 == 0xEDu) << 7) |
-                         ((uint32_t)(b1 == 0xF0u) << 8) | ((uint32_t)(b1 == 0xF4u) << 9);
-        }
-        if (tile == 0) {
-            // exact state at the first byte of this launch
-            tile_e_in = a.carry_in->next_is_escaped & 1u;
-            tile_ps_in = a.carry_in->prev_scalar & 1u;
-        } else {
-            const uint64_t WB = __ballot(wb == 0x5Cu);
-            const uint32_t r = top_run(WB);                         // backslashes ending at byte[-1]
-            // (WB<<1)|1 has bit 0 forced: a result of 64 means bits 1..63 are all set
-            const uint32_t r2 = top_run((WB << 1) | 1ull);          // run ending at byte[-2]
-            // branch-free scalar code.  op | ws as a 128-entry bit table (haswell.mojo:22-74):
-            // {09,0A,0C,0D,1A,20,2C,3A} in the low word, {5B,5D,7B,7D} in the high word
-            constexpr uint64_t kNsLo = (1ull << 0x09) | (1ull << 0x0A) | (1ull << 0x0C) | (1ull << 0x0D) |
-                                       (1ull << 0x1A) | (1ull << 0x20) | (1ull << 0x2C) | (1ull << 0x3A);
-            constexpr uint64_t kNsHi = (1ull << (0x5B - 64)) | (1ull << (0x5D - 64)) |
-                                       (1ull << (0x7B - 64)) | (1ull << (0x7D - 64));
-            const uint64_t tab = (b1 & 0x40u) ? kNsHi : kNsLo;
-            const uint32_t nonscalar = (uint32_t)(tab >> (b1 & 63u)) & (uint32_t)(b1 < 0x80u);
-            const uint32_t is_quote = (uint32_t)(b1 == 0x22u);
-            tile_e_in = r & 1u;
-            // byte[-1] a backslash: non-quote scalar.  op/ws: not a scalar.  '"': a real quote
-            // unless escaped by an odd run before it.  Anything else: scalar.
-            tile_ps_in = (uint32_t)(r >= 1u) | (~nonscalar & 1u & (is_quote ? (r2 & 1u) : 1u));
-            const bool resolved = (r != 64u) & !((r == 0u) & (is_quote != 0u) & (r2 == 64u));
-            if (!resolved) {
-                // >= 62 consecutive backslashes in front of the tile: take the exact
-                // carries the predecessor publishes with its aggregate.
-                uint32_t to = 0;
-                const uint64_t d = wait_desc(&agg[tile - 1], &to);
-                if (to) timeout = 1;
-                tile_e_in = (uint32_t)(d >> 58) & 1u;
-                tile_ps_in = (uint32_t)(d >> 57) & 1u;
-            }
-        }
-    }
+    const bool partial = tile * kTileBytes + kTileBytes > len;  // uniform: the launch's last tile, cut short
 
     MSJ_STAMP(tile, 2);
     // ---- bit-planes and character classes (lane_math.h)
     uint64_t p[8];
     bitplanes(x, p);
     Classes cls;
-    if (tile * kTileBytes + kTileBytes <= len && !skip) {  // uniform: every byte of the tile is input
+    uint64_t valid = ~0ull;
+    if (!partial && !skip) {  // uniform: every byte of the tile is input
         cls = classify(p, ~0ull);
     } else {
+        // bytes past the end behave as the reference's 0x20 padding (:103-107)
+        const uint32_t blk_off = tile * kTileBytes + lane * 64u;
+        if (blk_off >= len)
+            valid = 0ull;
+        else if (len - blk_off < 64u)
+            valid = (1ull << (len - blk_off)) - 1ull;
         if (lane == 0) valid &= ~0ull << skip;
 #pragma unroll
         for (int k = 0; k < 8; k++) p[k] &= valid;
         cls = classify(p, valid);
     }
+    // any byte >= 0x80 in the tile (decides the UTF-8 pass much later)
+    const uint64_t nonascii = __ballot(((uint32_t)p[7] | (uint32_t)(p[7] >> 32)) != 0u);
 
-    // ---- escape carry, lane level: g = carry-out if carry-in were 0, pr = all 64
-    //      bytes are backslashes (carry propagates).  Wave level: carry-lookahead add.
-    const uint32_t tr = top_run(cls.backslash);
-    const uint64_t G = __ballot((tr & 1u) != 0u);  // tr == 64 -> 0
-    const uint64_t Pm = __ballot(tr == 64u);
+    // ---- escapes (json_escape_scanner.mojo:18-45).  Per lane for carry-in 0: tt, and the carry the
+    //      block would hand on (g).  Wave level: ballot g and "all 64 bytes are backslashes" (the
+    //      carry propagates); the carries of the 64-bit addition (G|P) + G + carry_in are exactly
+    //      the per-lane carries (carry-lookahead).  A block that starts escaped is rare (the byte
+    //      before it ends an odd run of backslashes): quotes and strings are computed for carry-in 0
+    //      first, and only a tile that has such a block redoes them with the lanes' carries.
+    const uint64_t tt = escape_tt0(cls.backslash);
+    const uint64_t G = __ballot(escape_out0(tt, cls.backslash) != 0u);
+    const uint64_t Pm = __ballot(((uint32_t)cls.backslash & (uint32_t)(cls.backslash >> 32)) == 0xFFFFFFFFu);
+    uint64_t quote = unescaped_quotes0(cls.quote_chr, tt);  // eq['"'] & ~escaped  (json_string_scanner.mojo:58)
+    // ---- strings (json_string_scanner.mojo:55-69)
+    uint64_t S0 = prefix_xor(quote);  // in_string if the lane started outside a string
     const uint64_t add_a = G | Pm, add_b = G;
-    const uint64_t add_s = add_a + add_b + tile_e_in;
-    uint32_t tile_e_out = (uint32_t)(((add_a & add_b) | ((add_a | add_b) & ~add_s)) >> 63);
-    const uint64_t carries = add_s ^ add_a ^ add_b;
-    const uint32_t lane_e_in = (uint32_t)(carries >> lane) & 1u;
+    uint64_t add_s = add_a + add_b + tc.e_in;
+    uint64_t carries = add_s ^ add_a ^ add_b;
+    uint64_t escaped = 0;  // only needed (and only right) on the rare path
     MSJ_STAMP(tile, 3);
-
-    // ---- strings (json_string_scanner.mojo:55-69) with the lane's exact escape carry
-    uint32_t lane_e_out;
-    const uint64_t escaped = escaped_mask(cls.backslash, lane_e_in, &lane_e_out);
-    const uint64_t quote = cls.quote_chr & ~escaped;
-    const uint64_t S0 = prefix_xor(quote);  // in_string if the lane started outside a string
-    const uint64_t PM = __ballot((S0 >> 63) != 0);
-    const uint32_t lane_par = lanes_below(PM) & 1u;  // parity of the lanes before me in the tile
+    if (carries != 0ull || partial || !tc.resolved) {  // uniform, rare
+        if (!tc.resolved) {
+            // >= 63 consecutive backslashes in front of the tile: exact carries from the predecessor
+            uint32_t to = 0;
+            const uint64_t d = wait_desc(&a.ws[kDescOffset + tile - 1], a.wait_ticks, &to);
+            if (to) timeout = 1;
+            tc.e_in = (uint32_t)(d >> 58) & 1u;
+            tc.ps_in = (uint32_t)(d >> 57) & 1u;
+            add_s = add_a + add_b + tc.e_in;
+            carries = add_s ^ add_a ^ add_b;
+        }
+        uint32_t lane_e_out;
+        escaped = escaped_mask(cls.backslash, (uint32_t)(carries >> lane) & 1u, &lane_e_out);
+        quote = cls.quote_chr & ~escaped;
+        S0 = prefix_xor(quote);
+    }
+    uint32_t tile_e_out = (uint32_t)(((add_a & add_b) | ((add_a | add_b) & ~add_s)) >> 63);
+    const uint64_t PM = __ballot((int32_t)(uint32_t)(S0 >> 32) < 0);
+    const uint32_t lane_par = lanes_below(PM);  // bit 0: parity of the lanes before me in the tile
     const uint32_t tile_par = (uint32_t)__popcll(PM) & 1u;
+    const uint32_t lane_in32 = (uint32_t)__builtin_amdgcn_sbfe((int)lane_par, 0, 1);  // all-ones: inside a string
+    const uint64_t lane_in = u64(lane_in32, lane_in32);
+    // in_string assuming the TILE starts outside a string
+    const uint64_t in_string0 = S0 ^ lane_in;
 
     // ---- scalars (json_scanner.mojo:64-79); three-input mask operations throughout
-    const uint64_t nonscalar = cls.op | cls.ws;
-    const uint64_t nqs = lut3<MSJ_TT(~TA & ~TB)>(nonscalar, quote, quote);  // scalar & ~quote
+    const uint64_t nqs = lut3<MSJ_TT(~TA & ~TB & ~TC)>(cls.op, cls.ws, quote);  // scalar & ~quote
     const uint32_t my_ps = (uint32_t)(nqs >> 63);
-    const uint32_t prev_ps = dpp_shift_up1(my_ps, tile_ps_in);
-    uint32_t tile_ps_out = bcast(my_ps, 63);
-
-    const uint64_t lane_in = (uint64_t)(-(int64_t)lane_par);  // all-ones: inside a string
-    // in_string / string_tail assuming the TILE starts outside a string
-    const uint64_t in_string0 = S0 ^ lane_in;
-    const uint64_t follows = (nqs << 1) | prev_ps;     // json_scanner.mojo:76-79
-    // potential_structural_start = op | (scalar & ~follows)   (json_scanner.mojo:40-49)
-    const uint64_t potential = lut3<MSJ_TT(TA | (~TB & ~TC))>(cls.op, nonscalar, follows);
+    const uint32_t prev_ps = dpp_shift_up1(my_ps, tc.ps_in);
+    uint32_t tile_ps_out = bcast((uint32_t)(nqs >> 32), 63) >> 31;
+    // follows = nonquote_scalar << 1 | carry  (json_scanner.mojo:76-79)
+    const uint64_t follows = u64(((uint32_t)nqs << 1) | prev_ps, __builtin_amdgcn_alignbit((uint32_t)(nqs >> 32), (uint32_t)nqs, 31));
+    // potential_structural_start = op | (scalar & ~follows) = op | (~ws & ~follows)   (json_scanner.mojo:40-49)
+    const uint64_t potential = lut3<MSJ_TT(TA | (~TB & ~TC))>(cls.op, cls.ws, follows);
     Pending r;
     // structural_start = potential & ~string_tail, string_tail = in_string ^ quote
     // (json_scanner.mojo:24-26, json_string_scanner.mojo:40-44)
     r.T0 = lut3<MSJ_TT(TA & ~(TB ^ TC))>(potential, in_string0, quote);  // if tile s_in = 0
     r.T1 = lut3<MSJ_TT(TA & (TB ^ TC))>(potential, in_string0, quote);   // if tile s_in = 1
-    const bool partial = tile * kTileBytes + kTileBytes > len;  // uniform: the launch's last tile, cut short
+    // ---- packed inclusive scan of the per-lane structural counts
+    const uint32_t pk = (uint32_t)__popcll(r.T0) | ((uint32_t)__popcll(r.T1) << 16);
+    const uint32_t inc = dpp_add_scan(pk);
+    r.excl = inc - pk;
+    r.tile_cnt = bcast(inc, 63);
     if (partial) {
         // the carries OUT of a shard that does not end on a tile are the state after its last BYTE,
         // not after the space padding: an unescaped backslash there escapes the next shard's first
@@ -426,18 +489,20 @@ __device__ __forceinline__ Pending compute_tile(const KernelArgs &a, const uint3
         tile_e_out = bcast((uint32_t)((cls.backslash & ~escaped) >> lb) & 1u, (int)ll);
         tile_ps_out = bcast((uint32_t)(nqs >> lb) & 1u, (int)ll);
     }
-    const bool err0 = (cls.ctrl & in_string0) != 0;   // json_structural_indexer.mojo:143-145
-    const bool err1 = (cls.ctrl & ~in_string0) != 0;
+    // unescaped_chars_error |= ctrl & in_string (json_structural_indexer.mojo:143-145), for both tile states
+    const uint64_t e0 = cls.ctrl & in_string0;
+    const uint64_t me0 = __ballot(e0 != 0ull);
+    const uint64_t me1 = __ballot(e0 != cls.ctrl);
     MSJ_STAMP(tile, 4);
 
     // ---- utf8
     uint32_t tile_pend = 0;
-    bool u8err = false;
-    if (!(a.flags & kFlagNoUtf8) && (tile_u8_in != 0u || __ballot(p[7] != 0ull) != 0ull)) {
+    uint64_t mu8 = 0;
+    if (!(a.flags & kFlagNoUtf8) && (tc.u8_in != 0u || nonascii != 0ull)) {
         const Utf8Planes u8p = utf8_planes(p);
         // the lead planes moved onto the bytes they constrain; across lanes by DPP, into lane 0
         // from the carry word of the window bytes (lane_math.h: utf8_carry_out layout)
-        const uint32_t c = tile_u8_in;
+        const uint32_t c = tc.u8_in;
         Utf8Shifted sh8;
         sh8.exp1 = wave_shl_in<1>(u8p.lead234, c & 1u);
         sh8.exp2 = wave_shl_in<2>(u8p.lead34, (c >> 1) & 3u);
@@ -450,132 +515,135 @@ __device__ __forceinline__ Pending compute_tile(const KernelArgs &a, const uint3
         // a character cut by the end of a NON-final shard continues in the next one (which checks it
         // from its window bytes); only at the end of the stream is the missing continuation an error
         if (partial && !(a.flags & kFlagFinal)) u8bad &= valid;
-        u8err = u8bad != 0;
+        mu8 = __ballot(u8bad != 0ull);
         // a sequence still open at the end of the tile (the last lane's top lead bits)
         tile_pend = ((bcast((uint32_t)(u8p.lead234 >> 32), 63) >> 31) | (bcast((uint32_t)(u8p.lead34 >> 32), 63) >> 30) |
                      (bcast((uint32_t)(u8p.lead4 >> 32), 63) >> 29)) ? 1u : 0u;
     }
     MSJ_STAMP(tile, 5);
-
-    // ---- packed inclusive scan of the per-lane structural counts
-    const uint32_t pk = (uint32_t)__popcll(r.T0) | ((uint32_t)__popcll(r.T1) << 16);
-    const uint32_t inc = dpp_add_scan(pk);
-    r.excl = inc - pk;
-    r.tile_cnt = bcast(inc, 63);
-    r.tile = tile;
-    const uint64_t me0 = __ballot(err0), me1 = __ballot(err1), mu8 = __ballot(u8err);
     MSJ_STAMP(tile, 6);
-    agg_word = kAgg | ((uint64_t)tile_par << 61) | ((uint64_t)(me0 ? 1u : 0u) << 60) |
-               ((uint64_t)(me1 ? 1u : 0u) << 59) | ((uint64_t)tile_e_out << 58) |
-               ((uint64_t)tile_ps_out << 57) | ((uint64_t)(mu8 ? 1u : 0u) << 56) |
-               ((uint64_t)tile_pend << 55) | ((uint64_t)timeout << 54) |
-               ((uint64_t)(r.tile_cnt >> 16) << 15) | (uint64_t)(r.tile_cnt & 0xFFFFu);
+    // low word: the packed counts as they are; high word: status and flags
+    const uint32_t hi = (uint32_t)(kAgg >> 32) | (tile_par << 29) | ((me0 ? 1u : 0u) << 28) | ((me1 ? 1u : 0u) << 27) |
+                        (tile_e_out << 26) | (tile_ps_out << 25) | ((mu8 ? 1u : 0u) << 24) | (tile_pend << 23) |
+                        (timeout << 22);
+    agg_word = u64(r.tile_cnt, hi);
     return r;
 }
 
-// ---- BitIndexer.write (json_structural_indexer.mojo:46-58) for one computed tile, in two
+// ---- BitIndexer.write (json_structural_indexer.mojo:46-58) for one parked tile, in two
 //      steps so that the global stores of one range never sit between a load and its use:
-//      stage_indices() writes the offsets into the wave's LDS slice at their position in the
-//      output (LDS only), copy_out() turns them into aligned 16-byte
+//      emit_stage() writes the offsets into the wave's LDS slice at their position in the
+//      output (LDS only), emit_store() turns them into aligned 16-byte
 //      stores (one L2 request per 64 B instead of one per index).  Wave-local: no barrier.
-struct Emit {
-    uint32_t tlo, thi;     // the tile's structural_start mask of this lane (state resolved)
-    uint32_t vpos;         // stage slot of the lane's first index
-    uint32_t shift, vend;  // stage[j] <-> idx[base - shift + j] for j in [shift, vend)
-    uint32_t cnt;          // structurals in the tile
+// Everything that decides HOW a tile is emitted is wave-uniform and lives in scalar registers.
+enum : uint32_t { kEmitNone = 0, kEmitStaged, kEmitStaged16, kEmitRounds, kEmitGeneral };
+struct EmitU {
+    uint32_t mode;
     uint32_t tile;
+    uint32_t s_in;         // the tile's incoming in-string state
+    uint32_t shift, vend;  // stage[j] <-> idx[base - shift + j] for j in [shift, vend)
     uint64_t base;         // index of the tile's first structural in the output
-    bool live;             // something to emit
-    bool staged;           // fits one staging round (the common case)
-    bool staged16;         // fits one round with 16-bit slots (1021..2044 indices)
-    bool fits;             // the output buffer has room for all of the tile's indices
+};
+// ... and the lane's part: its structural_start mask for that state and its first stage slot
+struct EmitV {
+    uint32_t tlo, thi, vpos;
 };
 
-// Picks the masks / counts for the tile's actual incoming state from its pending slot.
-__device__ __forceinline__ Emit prepare_emit(const KernelArgs &a, Shared &sh, const uint32_t wave,
-                                             const uint32_t slot, const uint32_t lane,
-                                             const uint64_t rpre_word, const uint64_t count0,
-                                             uint32_t &timeout) {
-    Emit e;
+// Picks the counts for the tile's actual incoming state from its pending slot (scalar code).
+__device__ __forceinline__ EmitU emit_prepare(const KernelArgs &a, const Shared &sh, const uint32_t wave,
+                                              const uint32_t slot, const uint64_t rpre_word, const uint64_t count0,
+                                              uint32_t &timeout) {
+    EmitU e;
+    e.mode = kEmitNone;
+    e.s_in = e.shift = e.vend = 0;
+    e.base = 0;
     const uint4 meta = *reinterpret_cast<const uint4 *>(sh.pend_meta[wave][slot]);  // tile, tile_cnt, in_cnt, in_s
     e.tile = uniform32(meta.x);
-    e.live = e.tile != 0xFFFFFFFFu;
-    e.staged = false;
-    e.staged16 = false;
-    e.fits = false;
-    e.tlo = e.thi = e.vpos = e.shift = e.vend = e.cnt = 0;
-    e.base = 0;
-    if (!e.live) return e;
-    const uint4 m = sh.pend_masks[wave][slot][lane];
-    const uint32_t excl = sh.pend_excl[wave][slot][lane];
+    if (e.tile == 0xFFFFFFFFu) return e;
     const uint32_t tile_cnt = uniform32(meta.y);
     const uint32_t in_cnt = uniform32(meta.z);
     const uint32_t in_s = uniform32(meta.w);
     // the range's prefix (resolver) + the tile's position inside the range (local fold)
     const uint32_t q = (uint32_t)(rpre_word >> 61) & 1u;
-    const uint32_t s_in = (in_s >> q) & 1u;
+    e.s_in = (in_s >> q) & 1u;
     e.base = count0 + (uint64_t)(uint32_t)rpre_word + (q ? (in_cnt >> 16) : (in_cnt & 0xFFFFu));
     if ((rpre_word >> 54) & 1u) timeout = 1;
-    if ((a.flags & kFlagNoEmit) || timeout) {
-        e.live = false;
-        return e;
-    }
-    e.tlo = s_in ? m.z : m.x;
-    e.thi = s_in ? m.w : m.y;
-    e.cnt = s_in ? (tile_cnt >> 16) : (tile_cnt & 0xFFFFu);
-    e.shift = (uint32_t)(e.base & 3u);
-    e.vend = e.shift + e.cnt;
-    e.vpos = e.shift + (s_in ? (excl >> 16) : (excl & 0xFFFFu));
-    e.fits = e.base + e.cnt <= a.capacity;
-    e.staged = e.vend <= kStageWords && e.fits;
-    e.staged16 = !e.staged && e.vend <= 2u * kStageWords && e.fits;
+    timeout = uniform32(timeout);
+    if ((a.flags & kFlagNoEmit) || timeout) return e;
+    const uint32_t cnt = e.s_in ? (tile_cnt >> 16) : (tile_cnt & 0xFFFFu);
+    if (cnt == 0u) return e;
+    e.shift = (uint32_t)e.base & 3u;
+    e.vend = e.shift + cnt;
+    if (e.base + cnt > a.capacity)
+        e.mode = kEmitGeneral;  // the output buffer has no room for all of the tile's indices
+    else if (e.vend <= kStageWords)
+        e.mode = kEmitStaged;   // one staging round (the common case)
+    else if (e.vend <= 2u * kStageWords)
+        e.mode = kEmitStaged16; // one round with 16-bit slots (1021..2044 indices)
+    else
+        e.mode = kEmitRounds;
+    e.mode = uniform32(e.mode);
     return e;
 }
 
-__device__ __forceinline__ void stage_indices(const Emit &e, uint32_t *stage, const uint32_t lane) {
-    // the block offset is a multiple of 64, so value_base | bit == value_base + bit
-    const uint32_t v0 = e.tile * kTileBytes + lane * 64u;  // < 2^32 per launch
-    const uint32_t lds0 = (uint32_t)(uintptr_t)(stage + e.vpos);  // LDS byte address
-    const uint32_t nlo = (uint32_t)__builtin_popcount(e.tlo);
-    scatter_bits32(e.tlo, lds0, v0);
-    scatter_bits32(e.thi, lds0 + 4u * nlo, v0 | 32u);
+__device__ __forceinline__ EmitV emit_lane(const Shared &sh, const uint32_t wave, const uint32_t slot,
+                                           const uint32_t lane, const EmitU &e) {
+    EmitV v;
+    // the masks of the tile's actual state: 8 of the lane's 16 parked bytes
+    const uint2 m = reinterpret_cast<const uint2 *>(&sh.pend_masks[wave][slot][lane])[e.s_in];
+    const uint32_t excl = sh.pend_excl[wave][slot][lane];
+    v.tlo = m.x;
+    v.thi = m.y;
+    v.vpos = e.shift + __builtin_amdgcn_ubfe(excl, e.s_in * 16u, 16u);
+    return v;
 }
 
-__device__ __forceinline__ void copy_out(const KernelArgs &a, const Emit &e, const uint32_t *stage,
+__device__ __forceinline__ void stage_indices(const EmitU &e, const EmitV &v, uint32_t *stage, const uint32_t lane64) {
+    // the block offset is a multiple of 64, so value_base | bit == value_base + bit
+    const uint32_t v0 = e.tile * kTileBytes + lane64;  // < 2^32 per launch
+    const uint32_t lds0 = (uint32_t)(uintptr_t)(stage + v.vpos);  // LDS byte address
+    const uint32_t nlo = (uint32_t)__builtin_popcount(v.tlo);
+    scatter_bits32(v.tlo, lds0, v0);
+    scatter_bits32(v.thi, lds0 + 4u * nlo, v0 | 32u);
+}
+
+__device__ __forceinline__ void copy_out(const KernelArgs &a, const EmitU &e, const uint32_t *stage,
                                          const uint32_t lane) {
     // uniform 64-bit base + 32-bit lane offsets; full 16-byte quads in the body, the (at
     // most two) partial quads at the ends element by element
-    uint32_t *out = a.idx + (e.base - e.shift);     // out[v] <-> stage[v]; 16-byte aligned
+    uint8_t *out = reinterpret_cast<uint8_t *>(a.idx + (e.base - e.shift));  // out[4v] <-> stage[v]; 16-byte aligned
+    const uint8_t *src = reinterpret_cast<const uint8_t *>(stage);
     const uint32_t q_lo = (e.shift + 3u) >> 2;        // first quad with all four elements valid
     const uint32_t q_hi = e.vend >> 2;                // one past the last full quad
-    // at most kStageWords / 256 = 4 rounds of 64 quads: one address per lane, the rounds are
-    // immediate offsets of the LDS read and of the store
-    const uint32_t q0 = q_lo + lane;
-    const uint4 *src = reinterpret_cast<const uint4 *>(stage) + q0;
-    uint4 *dst = reinterpret_cast<uint4 *>(out) + q0;
+    // at most kStageWords / 256 = 4 rounds of 64 quads: one byte offset per lane, the rounds are
+    // immediate offsets of the LDS read and of the store; only the last round is partial
+    const uint32_t off = (q_lo + lane) * 16u;
 #pragma unroll
-    for (uint32_t k = 0; k < kStageWords / 256u; k++)
-        if (q0 + 64u * k < q_hi) dst[64u * k] = src[64u * k];
+    for (uint32_t k = 0; k < kStageWords / 256u; k++) {
+        if (q_lo + 64u * k >= q_hi) break;  // uniform
+        if (q_lo + 64u * (k + 1u) <= q_hi || q_lo + 64u * k + lane < q_hi)
+            *reinterpret_cast<uint4 *>(out + off + 1024u * k) = *reinterpret_cast<const uint4 *>(src + off + 1024u * k);
+    }
     // head (elements shift .. 4*q_lo) and tail (4*q_hi .. vend): < 8 elements in total, one
     // element per lane of the first eight
     if (lane < 8u) {
         const bool head = lane < 4u;
         const uint32_t v = head ? lane : 4u * q_hi + (lane - 4u);
         const bool ok = head ? (v >= e.shift && v < 4u * q_lo && v < e.vend) : (v < e.vend && v >= 4u * q_lo);
-        if (ok) out[v] = stage[v];
+        if (ok) *reinterpret_cast<uint32_t *>(out + 4u * v) = *reinterpret_cast<const uint32_t *>(src + 4u * v);
     }
 }
 
 // Medium-dense tile: 16-bit slots holding tile-relative offsets, widened in the copy-out.
-__device__ __forceinline__ void stage_indices16(const Emit &e, uint32_t *stage, const uint32_t lane) {
+__device__ __forceinline__ void stage_indices16(const EmitV &v, uint32_t *stage, const uint32_t lane64) {
     uint16_t *stage16 = reinterpret_cast<uint16_t *>(stage);
-    const uint32_t lds0 = (uint32_t)(uintptr_t)(stage16 + e.vpos);  // LDS byte address
-    const uint32_t nlo = (uint32_t)__builtin_popcount(e.tlo);
-    scatter_bits16(e.tlo, lds0, lane * 64u);
-    scatter_bits16(e.thi, lds0 + 2u * nlo, lane * 64u + 32u);
+    const uint32_t lds0 = (uint32_t)(uintptr_t)(stage16 + v.vpos);  // LDS byte address
+    const uint32_t nlo = (uint32_t)__builtin_popcount(v.tlo);
+    scatter_bits16(v.tlo, lds0, lane64);
+    scatter_bits16(v.thi, lds0 + 2u * nlo, lane64 + 32u);
 }
 
-__device__ __forceinline__ void copy_out16(const KernelArgs &a, const Emit &e, const uint32_t *stage,
+__device__ __forceinline__ void copy_out16(const KernelArgs &a, const EmitU &e, const uint32_t *stage,
                                            const uint32_t lane) {
     const uint16_t *stage16 = reinterpret_cast<const uint16_t *>(stage);
     uint32_t *out = a.idx + (e.base - e.shift);     // out[v] <-> stage16[v]; 16-byte aligned
@@ -609,20 +677,21 @@ __device__ __forceinline__ void lds_wave_sync() {
 // starts inside the window fits the slice); lanes are ordered by position, so a round is a
 // contiguous group of lanes and its indices a contiguous piece of the output.
 constexpr uint32_t kRoundSlots = kStageWords - 64u;
-__device__ __forceinline__ void emit_rounds(const KernelArgs &a, const Emit &e, uint32_t *stage,
-                                            const uint32_t lane) {
-    const uint32_t v0 = e.tile * kTileBytes + lane * 64u;
-    uint32_t *out = a.idx + (e.base - e.shift);  // out[v] <-> slot v of the tile; 16-byte aligned
-    const uint32_t nlo = (uint32_t)__builtin_popcount(e.tlo);
-    uint32_t v_begin = e.shift;
-    for (uint32_t r0 = 0; r0 < e.vend; r0 += kRoundSlots) {  // uniform; kRoundSlots is a multiple of 4
-        const bool mine = e.vpos >= r0 && e.vpos < r0 + kRoundSlots;
+__device__ __noinline__ void emit_rounds(uint32_t *idx, const uint32_t tile, const uint64_t base, const uint32_t shift,
+                                         const uint32_t vend, const uint32_t tlo, const uint32_t thi,
+                                         const uint32_t vpos, uint32_t *stage, const uint32_t lane) {
+    const uint32_t v0 = tile * kTileBytes + lane * 64u;
+    uint32_t *out = idx + (base - shift);  // out[v] <-> slot v of the tile; 16-byte aligned
+    const uint32_t nlo = (uint32_t)__builtin_popcount(tlo);
+    uint32_t v_begin = shift;
+    for (uint32_t r0 = 0; r0 < vend; r0 += kRoundSlots) {  // uniform; kRoundSlots is a multiple of 4
+        const bool mine = vpos >= r0 && vpos < r0 + kRoundSlots;
         // this round's indices end where the next round's first lane starts
-        const uint64_t later = __ballot(e.vpos >= r0 + kRoundSlots);
-        const uint32_t v_end = later ? bcast(e.vpos, (int)__builtin_ctzll(later)) : e.vend;
-        const uint32_t lds0 = (uint32_t)(uintptr_t)(stage + (e.vpos - r0));
-        scatter_bits32(mine ? e.tlo : 0u, lds0, v0);
-        scatter_bits32(mine ? e.thi : 0u, lds0 + 4u * nlo, v0 | 32u);
+        const uint64_t later = __ballot(vpos >= r0 + kRoundSlots);
+        const uint32_t v_end = later ? bcast(vpos, (int)__builtin_ctzll(later)) : vend;
+        const uint32_t lds0 = (uint32_t)(uintptr_t)(stage + (vpos - r0));
+        scatter_bits32(mine ? tlo : 0u, lds0, v0);
+        scatter_bits32(mine ? thi : 0u, lds0 + 4u * nlo, v0 | 32u);
         lds_wave_sync();
         // copy out slots [v_begin, v_end): full quads in the body, partial quads element-wise
         const uint32_t q_lo = (v_begin + 3u) >> 2, q_hi = v_end >> 2;
@@ -641,11 +710,12 @@ __device__ __forceinline__ void emit_rounds(const KernelArgs &a, const Emit &e, 
 }
 
 // An index buffer that is too small (the launch reports CAPACITY): element-wise, clipped.
-__device__ __forceinline__ void emit_general(const KernelArgs &a, const Emit &e, uint32_t *stage,
-                                             const uint32_t lane) {
-    const uint32_t v0 = e.tile * kTileBytes + lane * 64u;
-    uint32_t tlo = e.tlo, thi = e.thi, vpos = e.vpos;
-    for (uint32_t r0 = 0; r0 < e.vend; r0 += kStageWords) {
+__device__ __noinline__ void emit_general(uint32_t *idx, const uint64_t capacity, const uint32_t tile,
+                                          const uint64_t base, const uint32_t shift, const uint32_t vend,
+                                          uint32_t tlo, uint32_t thi, uint32_t vpos, uint32_t *stage,
+                                          const uint32_t lane) {
+    const uint32_t v0 = tile * kTileBytes + lane * 64u;
+    for (uint32_t r0 = 0; r0 < vend; r0 += kStageWords) {
         const uint32_t r1 = r0 + kStageWords;
         while (tlo && vpos < r1) {
             stage[vpos - r0] = v0 + (uint32_t)__builtin_ctz(tlo);
@@ -662,20 +732,20 @@ __device__ __forceinline__ void emit_general(const KernelArgs &a, const Emit &e,
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        const uint32_t lim = e.vend < r1 ? e.vend : r1;
-        const uint64_t gbase = e.base - e.shift + r0;
+        const uint32_t lim = vend < r1 ? vend : r1;
+        const uint64_t gbase = base - shift + r0;
         for (uint32_t q = lane; 4u * q < lim - r0; q += 64u) {
             const uint32_t vq = r0 + 4u * q;
             const uint4 val = *reinterpret_cast<const uint4 *>(&stage[4u * q]);
             const uint64_t g = gbase + 4u * q;
-            if (vq >= e.shift && vq + 4u <= lim && g + 4u <= a.capacity) {
-                *reinterpret_cast<uint4 *>(&a.idx[g]) = val;
+            if (vq >= shift && vq + 4u <= lim && g + 4u <= capacity) {
+                *reinterpret_cast<uint4 *>(&idx[g]) = val;
             } else {
                 const uint32_t vv[4] = {val.x, val.y, val.z, val.w};
 #pragma unroll
                 for (uint32_t j = 0; j < 4; j++) {
                     const uint32_t v = vq + j;
-                    if (v >= e.shift && v < lim && g + j < a.capacity) a.idx[g + j] = vv[j];
+                    if (v >= shift && v < lim && g + j < capacity) idx[g + j] = vv[j];
                 }
             }
         }
@@ -685,14 +755,13 @@ __device__ __forceinline__ void emit_general(const KernelArgs &a, const Emit &e,
     }
 }
 
-
 // Range prefix for this wave: requested once per range, polled only if the resolver
 // had not published it yet.
-__device__ __forceinline__ uint64_t range_prefix(const uint64_t *rpre, uint32_t range_id, uint64_t word,
-                                                 uint32_t &timeout) {
+__device__ __forceinline__ uint64_t range_prefix(const KernelArgs &a, const uint64_t *rpre, uint32_t range_id,
+                                                 uint64_t word, uint32_t &timeout) {
     if ((word >> 62) == 0ull) {
         uint32_t to = 0;
-        word = wait_desc(&rpre[range_id], &to);
+        word = wait_desc(&rpre[range_id], a.wait_ticks, &to);
         if (to) {
             timeout = 1;
             word = kPre | (1ull << 54);
@@ -703,30 +772,29 @@ __device__ __forceinline__ uint64_t range_prefix(const uint64_t *rpre, uint32_t 
 
 // The two halves of one parked tile's emission: LDS-only staging (the one-round cases), then
 // everything that stores to global memory (copy-out, or the multi-round / clipped paths).
-__device__ __forceinline__ void stage_tile(const Emit &e, uint32_t *stage, const uint32_t lane) {
-    if (!e.live) return;  // uniform
-    if (e.staged)
-        stage_indices(e, stage, lane);
-    else if (e.staged16)
-        stage_indices16(e, stage, lane);
+__device__ __forceinline__ void emit_stage(const Shared &sh, const EmitU &e, const uint32_t wave, const uint32_t slot,
+                                           uint32_t *stage, const uint32_t lane, const uint32_t lane64) {
+    if (e.mode == kEmitStaged) {  // uniform
+        const EmitV v = emit_lane(sh, wave, slot, lane, e);
+        stage_indices(e, v, stage, lane64);
+    } else if (e.mode == kEmitStaged16) {
+        const EmitV v = emit_lane(sh, wave, slot, lane, e);
+        stage_indices16(v, stage, lane64);
+    }
 }
-__device__ __forceinline__ void store_tile(const KernelArgs &a, const Emit &e, uint32_t *stage, const uint32_t lane) {
-    if (!e.live) return;  // uniform
-    if (e.staged)
+__device__ __forceinline__ void emit_store(const KernelArgs &a, const Shared &sh, const EmitU &e, const uint32_t wave,
+                                           const uint32_t slot, uint32_t *stage, const uint32_t lane) {
+    if (e.mode == kEmitStaged) {  // uniform
         copy_out(a, e, stage, lane);
-    else if (e.staged16)
+    } else if (e.mode == kEmitStaged16) {
         copy_out16(a, e, stage, lane);
-    else if (e.fits)
-        emit_rounds(a, e, stage, lane);
-    else
-        emit_general(a, e, stage, lane);
-}
-__device__ __forceinline__ Emit no_emit() {
-    Emit e;
-    e.live = e.staged = e.staged16 = e.fits = false;
-    e.tlo = e.thi = e.vpos = e.shift = e.vend = e.cnt = e.tile = 0;
-    e.base = 0;
-    return e;
+    } else if (e.mode == kEmitRounds) {
+        const EmitV v = emit_lane(sh, wave, slot, lane, e);
+        emit_rounds(a.idx, e.tile, e.base, e.shift, e.vend, v.tlo, v.thi, v.vpos, stage, lane);
+    } else if (e.mode == kEmitGeneral) {
+        const EmitV v = emit_lane(sh, wave, slot, lane, e);
+        emit_general(a.idx, a.capacity, e.tile, e.base, e.shift, e.vend, v.tlo, v.thi, v.vpos, stage, lane);
+    }
 }
 
 // ---- worker: one wave, persistent ---------------------------------------------------
@@ -757,6 +825,11 @@ __device__ __forceinline__ Emit no_emit() {
 // The workgroup holding the smallest unpublished range therefore never waits on anything
 // that needs a later range, whatever the dispatch order or residency, and the resolver
 // publishes a range's prefix as soon as every earlier range is in (partial progress).
+//
+// Vector instructions are what this kernel runs out of (profiles/): everything wave-uniform --
+// tile numbers, addresses, counts, the emission's mode -- is kept in scalar registers, lane-derived
+// offsets are loop invariants, and the rare cases (errors in a range, a tile cut by the end of
+// the input, escapes that cross a block) branch off uniformly.
 __device__ __forceinline__ void worker_wave(const KernelArgs &a, Shared &sh, const uint32_t lane,
                                             const uint32_t wave) {
     // Ticket shard and first range: drawn at the kernel's entry (stage1_kernel), one atomic for both.
@@ -768,6 +841,8 @@ __device__ __forceinline__ void worker_wave(const KernelArgs &a, Shared &sh, con
     unsigned int *ticket_ctr = reinterpret_cast<unsigned int *>(a.ws + (uint64_t)shard * kTicketStrideWords);
     uint32_t *stage = sh.stage[wave];
     const uint32_t tid = threadIdx.x;
+    const uint32_t lane64 = lane * 64u;  // loop invariants in vector registers
+    const uint32_t lane_off[4] = {lane64, lane64 + 16u, lane64 + 32u, lane64 + 48u};
     const uint32_t ntiles = a.ntiles;
     const uint32_t nranges = (ntiles + kRange - 1u) / kRange;
     uint64_t *ragg = a.ws + kDescOffset + ntiles;
@@ -775,17 +850,13 @@ __device__ __forceinline__ void worker_wave(const KernelArgs &a, Shared &sh, con
     if (lane < kPendSlots) sh.pend_meta[wave][lane][0] = 0xFFFFFFFFu;  // all slots empty (read by this wave only)
     MSJ_RSTAMP(a.ntiles + 4096u + blockIdx.x, 2, tid == 0);
     // LDS words every lane reads identically: uniform (tile indices and all control flow stay scalar)
-    uint32_t lo_cur = uniform32(sh.range_lo[0]);
-    const uint64_t count0 = uniform64(a.carry_in->count);  // launch invariant: read once
+    uint32_t lo_cur = uniform32(sh.first_lo);
+    const uint64_t count0 = uniform64(a.carry_in->count);  // launch invariants: read once
+    const uint32_t carry0 = uniform32((a.carry_in->next_is_escaped & 1u) | ((a.carry_in->prev_scalar & 1u) << 1));
     uint32_t timeout = 0;
-    volatile uint32_t *range_seq = &sh.range_seq;
 
     Block blk[kBatch];
-#pragma unroll
-    for (uint32_t j = 0; j < kBatch; j++) {
-        const uint32_t t = lo_cur + kWaves * j + wave;
-        load_block(a, t < ntiles ? t : ntiles - 1u, lane, blk[j]);
-    }
+    load_range(a, lo_cur, wave, lane_off, lane, blk);
 #pragma unroll
     for (uint32_t j = 0; j < kBatch; j++) touch_block(blk[j]);  // loop invariant: the bytes have arrived
     MSJ_RSTAMP(a.ntiles + 4096u + blockIdx.x, 3, tid == 0);  // first bytes in registers
@@ -812,11 +883,7 @@ __device__ __forceinline__ void worker_wave(const KernelArgs &a, Shared &sh, con
             now[j].T1 = 0;
             now[j].excl = 0;
             now[j].tile_cnt = 0;
-            now[j].tile = valid_tile ? t_cur : 0xFFFFFFFFu;
-            if (valid_tile) {
-                now[j] = compute_tile(a, t_cur, lane, blk[j], timeout, agg_word);
-                now[j].tile = t_cur;
-            }
+            if (valid_tile) now[j] = compute_tile(a, t_cur, lane, blk[j], carry0, timeout, agg_word);
             if (j == 0) {
                 // the prefix word requested above has arrived (nothing younger is in flight yet) ...
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -831,60 +898,59 @@ __device__ __forceinline__ void worker_wave(const KernelArgs &a, Shared &sh, con
             }
             MSJ_STAMP(valid_tile ? t_cur : ntiles - 1u, 7);
         }
-        const uint32_t last_row = (lo_cur + kWaves * (kBatch - 1u) + wave < ntiles)
-                                      ? lo_cur + kWaves * (kBatch - 1u) + wave : ntiles - 1u;
-        const uint32_t first_row = (lo_cur + wave < ntiles) ? lo_cur + wave : ntiles - 1u;
-        (void)last_row;
-        (void)first_row;
-#ifdef MSJ_STAMPS
-        if (tid == 0 && have_old && a.stamps) a.stamps[(uint64_t)(old_range * kRange) * 16 + 11] = 1 + (rp_word >> 62);
-#endif
-        MSJ_STAMP(last_row, 8);
+        const uint32_t srow = (lo_cur + kWaves + wave < ntiles) ? lo_cur + kWaves + wave : ntiles - 1u;  // stamp row (diagnostic builds)
+        (void)srow;
+        MSJ_STAMP(srow, 8);   // both tiles computed
         // workgroup barrier for the LDS words only: the descriptor stores above need not have
         // completed (__syncthreads() would wait for them)
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-        MSJ_STAMP(last_row, 9);
+        MSJ_STAMP(srow, 9);   // barrier passed
         // wave 0 passes the next range's ticket on (drawn a compute phase ago) ...
         if (wave == 0) {
             const uint32_t v = ticket_value(req_reg);
-            if (lane == 0) sh.range_lo[par] = ticket_range(v, shard, shards) * kRange;
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            if (lane == 0) *range_seq = r + 1u;
+            if (lane == 0)
+                __hip_atomic_store(&sh.handoff, ((uint64_t)(r + 1u) << 32) | (uint64_t)(ticket_range(v, shard, shards) * kRange),
+                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         }
         // ---- 2. fold the range's kRange tile aggregates in tile order -> the range aggregate
         //      for the resolver, and every tile's state / count inside the range for both range
-        //      states.  Lane k (< kRange) holds tile k's aggregate: the in-range parity is a
-        //      ballot + mbcnt, the counts a three-step DPP scan.
+        //      states.  Lane k (< kRange) holds tile k's aggregate: the in-range parity comes from
+        //      one ballot (scalar code from there), the counts from a three-step DPP scan.
         uint32_t in_cnt[kBatch], in_state[kBatch];
         {
             const uint64_t w = sh.tagg[par][lane & (kRange - 1u)];
             const uint32_t wl = (uint32_t)w, wh = (uint32_t)(w >> 32);
-            const bool in8 = lane < kRange;
-            const uint32_t c0 = wl & 0x7FFFu, c1 = (uint32_t)(w >> 15) & 0xFFFFu;
-            const uint32_t P8 = (uint32_t)__ballot(in8 && ((wh >> 29) & 1u));  // tile parities (bit 61)
+            // lanes 8.. repeat lanes 0..7: the low byte of a ballot is what the range holds
+            const uint32_t P8 = (uint32_t)__ballot((wh & (1u << 29)) != 0u) & 0xFFu;  // tile parities (bit 61)
             const uint32_t s0 = __builtin_amdgcn_mbcnt_lo(P8, 0u) & 1u;  // tile k's state if the range starts outside a string
             // count of tile k under range state 0 | state 1 << 16  (state 1 sees the other one)
-            const uint32_t ab = s0 ? (c1 | (c0 << 16)) : (c0 | (c1 << 16));
+            const uint32_t ab = __builtin_amdgcn_alignbit(wl, wl, s0 << 4);  // the tile's packed counts, halves swapped if s0
             uint32_t inc = ab;
             inc += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)inc, 0x111, 0xF, 0xF, false);  // row_shr:1
             inc += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)inc, 0x112, 0xF, 0xF, false);  // row_shr:2
             inc += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)inc, 0x114, 0xF, 0xF, false);  // row_shr:4
             const uint32_t excl = inc - ab;
-            const uint32_t e0 = (wh >> 28) & 1u, e1 = (wh >> 27) & 1u;  // bits 60, 59
-            const uint32_t e0s = __ballot(in8 && (s0 ? e1 : e0)) != 0ull;
-            const uint32_t e1s = __ballot(in8 && (s0 ? e0 : e1)) != 0ull;
-            const uint32_t u8s = __ballot(in8 && ((wh >> 24) & 1u)) != 0ull;  // bit 56
-            const uint32_t pzs = __ballot(in8 && ((wh >> 22) & 1u)) != 0ull;  // bit 54
-            const uint32_t in_s = s0 | ((s0 ^ 1u) << 1);
+            // error / poison bits (60, 59, 56, 54): none in nearly every range
+            const uint32_t anyflag = (uint32_t)__ballot((wh & 0x19400000u) != 0u) & 0xFFu;
+            uint32_t e0s = 0, e1s = 0, u8s = 0, pzs = 0;
+            if (anyflag) {  // uniform
+                const uint32_t e0 = (wh >> 28) & 1u, e1 = (wh >> 27) & 1u;
+                e0s = ((uint32_t)__ballot((s0 ? e1 : e0) != 0u) & 0xFFu) != 0u;
+                e1s = ((uint32_t)__ballot((s0 ? e0 : e1) != 0u) & 0xFFu) != 0u;
+                u8s = ((uint32_t)__ballot(((wh >> 24) & 1u) != 0u) & 0xFFu) != 0u;  // bit 56
+                pzs = ((uint32_t)__ballot(((wh >> 22) & 1u) != 0u) & 0xFFu) != 0u;  // bit 54
+            }
 #pragma unroll
             for (uint32_t j = 0; j < kBatch; j++) {
                 const uint32_t k = kWaves * j + wave;  // this wave's tiles of the range
                 in_cnt[j] = bcast(excl, (int)k);
-                in_state[j] = bcast(in_s, (int)k);
+                // tile k's state under range state 0 (bit 0) and 1 (bit 1): parity of the tiles before it
+                const uint32_t sk = (uint32_t)__builtin_popcount(P8 & ((1u << k) - 1u)) & 1u;
+                in_state[j] = sk | ((sk ^ 1u) << 1);
             }
             if (tid == 0) {
                 const uint32_t tot = bcast(inc, (int)kRange - 1);
-                const uint32_t s_out = (uint32_t)__builtin_popcount(P8 & 0xFFu) & 1u;
+                const uint32_t s_out = (uint32_t)__builtin_popcount(P8) & 1u;
                 st_desc(&ragg[lo_cur / kRange], kAgg | ((uint64_t)s_out << 61) | ((uint64_t)e0s << 60) |
                                                     ((uint64_t)e1s << 59) | ((uint64_t)u8s << 56) |
                                                     ((uint64_t)pzs << 54) | ((uint64_t)(tot >> 16) << 16) |
@@ -903,68 +969,70 @@ __device__ __forceinline__ void worker_wave(const KernelArgs &a, Shared &sh, con
                 a.ws_clean[kDescOffset + ntiles + nranges + rid] = 0ull;
             }
         }
-        MSJ_STAMP(last_row, 10);
+        MSJ_STAMP(srow, 10);  // folded, range aggregate published
         // ... and everybody requests the next range's bytes: in flight during the whole emission
+        uint32_t lo_next;
         {
-            // one LDS word; loop control stays workgroup-uniform whatever happens: everybody
-            // continues with the LDS word
-            uint32_t spins = 0;
-            while (*range_seq != r + 1u) {
+            uint64_t h = uniform64(__hip_atomic_load(&sh.handoff, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
+            WaitClock clk;
+            while ((uint32_t)(h >> 32) != r + 1u) {
                 __builtin_amdgcn_s_sleep(1);
-                if (++spins > 64u * kSpinLimit) {
+                h = uniform64(__hip_atomic_load(&sh.handoff, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
+                if (clk.expired(a.wait_ticks)) {
+                    // wave 0 never came back with the ticket: give up (this wave drains and leaves;
+                    // a wave that has ended does not hold up the others' barrier)
                     timeout = 1;
-                    break;
+                    h = ((uint64_t)(r + 1u) << 32) | 0xFFFFFFFFull;
                 }
             }
+            lo_next = (uint32_t)h;
         }
-        const uint32_t lo_next = uniform32(sh.range_lo[par]);
-#pragma unroll
-        for (uint32_t j = 0; j < kBatch; j++) {
-            const uint32_t t = lo_next + kWaves * j + wave;
-            load_block(a, t < ntiles ? t : ntiles - 1u, lane, blk[j]);  // past the end: harmless re-read
-        }
+        load_range(a, lo_next, wave, lane_off, lane, blk);
         MSJ_RSTAMP(lo_cur, 8, tid == 0);  // range aggregate published (real time)
         // ---- 3. emit the range parked kDefer iterations ago; hand the next range over in between
         if (have_old) {
-            rp_word = uniform64(range_prefix(rpre, old_range, uniform64(rp_word), timeout));
+            rp_word = range_prefix(a, rpre, old_range, uniform64(rp_word), timeout);
             MSJ_RSTAMP(old_range * kRange, 9, tid == 0);  // its prefix is in hand (real time)
         }
-        MSJ_STAMP(last_row, 12);
+        // wave-uniform by construction; say so, or the whole emission is vector code with exec masks
+        const uint64_t rp = uniform64(rp_word);
+        timeout = uniform32(timeout);
+        MSJ_STAMP(srow, 12);  // next range known, its loads issued, the old range's prefix in hand
         static_assert(kBatch == 2, "the emission below is written for two tiles per wave and range");
-        const Emit e0 = have_old ? prepare_emit(a, sh, wave, ring * kBatch, lane, rp_word, count0, timeout) : no_emit();
-        stage_tile(e0, stage, lane);
+        const uint32_t slot0 = ring * kBatch;
+        const EmitU e0 = emit_prepare(a, sh, wave, slot0, rp, count0, timeout);
+        emit_stage(sh, e0, wave, slot0, stage, lane, lane64);
         lds_wave_sync();
-        MSJ_STAMP(first_row, 12);
-        MSJ_STAMP(first_row, 13);
-        store_tile(a, e0, stage, lane);
+        MSJ_STAMP(srow, 13);  // tile A staged
+        emit_store(a, sh, e0, wave, slot0, stage, lane);
         lds_wave_sync();  // the staging slice is reused by the next tile
-        MSJ_STAMP(first_row, 14);
-        const Emit e1 = have_old ? prepare_emit(a, sh, wave, ring * kBatch + 1u, lane, rp_word, count0, timeout) : no_emit();
-        stage_tile(e1, stage, lane);
+        MSJ_STAMP(srow, 14);  // tile A stored
+        const EmitU e1 = emit_prepare(a, sh, wave, slot0 + 1u, rp, count0, timeout);
+        emit_stage(sh, e1, wave, slot0 + 1u, stage, lane, lane64);
         lds_wave_sync();
-        MSJ_STAMP(first_row, 15);
+        MSJ_STAMP(srow, 15);  // tile B staged
         // the bytes requested above (and the first tile's stores) have had a whole staging phase
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #pragma unroll
         for (uint32_t j = 0; j < kBatch; j++) touch_block(blk[j]);
-        MSJ_STAMP(last_row, 13);
-        store_tile(a, e1, stage, lane);
+        MSJ_STAMP(srow, 11);  // the next range's bytes have arrived
+        emit_store(a, sh, e1, wave, slot0 + 1u, stage, lane);
         lds_wave_sync();
-        MSJ_STAMP(last_row, 14);
         // ---- 4. park this iteration's tiles
 #pragma unroll
         for (uint32_t j = 0; j < kBatch; j++) {
-            const uint32_t slot = ring * kBatch + j;
+            const uint32_t slot = slot0 + j;
+            const uint32_t t_cur = lo_cur + kWaves * j + wave;
             sh.pend_masks[wave][slot][lane] = make_uint4((uint32_t)now[j].T0, (uint32_t)(now[j].T0 >> 32),
                                                          (uint32_t)now[j].T1, (uint32_t)(now[j].T1 >> 32));
             sh.pend_excl[wave][slot][lane] = now[j].excl;
             if (lane == 0)
-                *reinterpret_cast<uint4 *>(sh.pend_meta[wave][slot]) = make_uint4(now[j].tile, now[j].tile_cnt, in_cnt[j], in_state[j]);
+                *reinterpret_cast<uint4 *>(sh.pend_meta[wave][slot]) =
+                    make_uint4(t_cur < ntiles ? t_cur : 0xFFFFFFFFu, now[j].tile_cnt, in_cnt[j], in_state[j]);
         }
         lo_cur = lo_next;
         r++;
         ring = (ring + 1u == kDefer) ? 0u : ring + 1u;
-        MSJ_STAMP(last_row, 15);
     }
     MSJ_RSTAMP(a.ntiles + 4096u + blockIdx.x, 4, tid == 0);  // last range computed
     // ---- drain: oldest first
@@ -972,13 +1040,15 @@ __device__ __forceinline__ void worker_wave(const KernelArgs &a, Shared &sh, con
         lds_wave_sync();
         const uint32_t old_first = uniform32(sh.pend_meta[wave][ring * kBatch][0]);
         if (old_first != 0xFFFFFFFFu) {
-            const uint64_t w = uniform64(range_prefix(rpre, old_first / kRange, 0ull, timeout));
+            const uint64_t w = uniform64(range_prefix(a, rpre, old_first / kRange, 0ull, timeout));
+            timeout = uniform32(timeout);
 #pragma unroll
             for (uint32_t j = 0; j < kBatch; j++) {
-                const Emit e = prepare_emit(a, sh, wave, ring * kBatch + j, lane, w, count0, timeout);
-                stage_tile(e, stage, lane);
+                const uint32_t slot = ring * kBatch + j;
+                const EmitU e = emit_prepare(a, sh, wave, slot, w, count0, timeout);
+                emit_stage(sh, e, wave, slot, stage, lane, lane64);
                 lds_wave_sync();
-                store_tile(a, e, stage, lane);
+                emit_store(a, sh, e, wave, slot, stage, lane);
                 lds_wave_sync();  // the staging slice is reused by the next tile
             }
         }
@@ -1045,7 +1115,8 @@ __device__ void resolver(const KernelArgs &a, Shared &sh) {
         uint64_t d[kResolveE];
 #pragma unroll
         for (int e = 0; e < kResolveE; e++) d[e] = 0;
-        uint32_t spins = 0, published = 0, force = 0;
+        uint32_t published = 0, force = 0;
+        WaitClock clk;  // restarted whenever the chunk makes progress
         MSJ_RSTAMP(a.ntiles + c, 0, lane == 0);
         uint32_t rounds = 0; (void)rounds;
         bool have_state = false, full = false, agg_done = false;
@@ -1246,9 +1317,9 @@ __device__ void resolver(const KernelArgs &a, Shared &sh) {
                     }
                 }
                 published = m;
-                spins = 0;
+                clk.restart();
             }
-            if (++spins > kSpinLimit) force = 1;  // next round substitutes poisoned identities
+            if (clk.expired(a.wait_ticks)) force = 1;  // next round substitutes poisoned identities
             // full but no state yet: spin on the LDS word only (no global traffic)
             if (!full) __builtin_amdgcn_s_sleep(1);
         }
@@ -1275,8 +1346,8 @@ __global__ __launch_bounds__(kThreads, 4) void stage1_kernel(const KernelArgs a)
         const uint32_t k = atomicAdd(reinterpret_cast<unsigned int *>(a.ws + (uint64_t)shard * kTicketStrideWords), 1u);
         sh.role = (shard == 0u && k == 0u) ? 0u : 1u;
         sh.shard = shard;
-        sh.range_lo[0] = ticket_range(k, shard, shards) * kRange;
-        sh.range_seq = 0;
+        sh.first_lo = ticket_range(k, shard, shards) * kRange;
+        sh.handoff = 0ull;
     }
     __syncthreads();
     if (sh.role == 0u) {
