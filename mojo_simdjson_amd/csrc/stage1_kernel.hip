@@ -36,6 +36,7 @@
 // No MFMA (nothing here is a contraction); integer/bitwise work on u8 input,
 // u64 masks, u32 output.
 #include <hip/hip_runtime.h>
+#include <stddef.h>
 #include <stdint.h>
 
 #include "../../include/msj_stage1.h"
@@ -108,11 +109,17 @@ __device__ __forceinline__ uint64_t uniform64(uint64_t v) {
 
 #ifdef MSJ_STAMPS
 // Diagnostic build only: phase timestamps per tile (never compiled into the product .so).
+// -DMSJ_STAMPS=2: only the real-time stamps (one per range and a few per workgroup): light enough to
+// leave the launch's timeline as it is.
+#if MSJ_STAMPS == 2
+#define MSJ_STAMP(t, k) do {} while (0)
+#else
 #define MSJ_STAMP(t, k)                                                                   \
     do {                                                                                  \
         if ((threadIdx.x & 63u) == 0 && a.stamps)                                         \
             a.stamps[(uint64_t)(t) * 16 + (k)] = __builtin_amdgcn_s_memtime();            \
     } while (0)
+#endif
 #define MSJ_RSTAMP(t, k, cond)                                                            \
     do {                                                                                  \
         if ((cond) && a.stamps)                                                           \
@@ -261,58 +268,79 @@ __device__ __forceinline__ uint32_t ticket_range(uint32_t k, uint32_t shard, uin
 }
 
 // BitIndexer.write_index (json_structural_indexer.mojo:39-44) for one 32-bit half mask:
-// writes (value_base | bit position) of every set bit, ascending, to consecutive LDS words.
-// Straight-line: 32 steps, lanes drop out through
-// EXEC as their mask runs empty (v_cmpx), the wave leaves as soon as no lane is left; the LDS
-// offsets are immediates.  (The compiler's version of this loop spends ~8 scalar
+// writes (value_base + bit position) of every set bit, ascending, to consecutive LDS slots
+// [lds_byte_addr, lds_byte_addr + 4 * popcount(t)).
+// Straight-line and from BOTH ends: a step takes the lowest and the highest set bit (v_ffbl /
+// v_ffbh), writes them to the lane's next slot from the front and from the back (immediate
+// offsets), and clears both with one three-input operation -- half the steps of a one-ended
+// chain, eight vector instructions per two indices.  A mask with one bit left writes it twice
+// (same slot, same value).  Lanes drop out through EXEC as their mask runs empty (v_cmpx), the
+// wave leaves as soon as no lane is left.  (The compiler's version of such a loop spends ~8 scalar
 // instructions per step on exec-mask bookkeeping.)
-__device__ __forceinline__ void scatter_bits32(uint32_t t, uint32_t lds_byte_addr, uint32_t value_base) {
-    uint32_t tmp1, tmp2;
+// The back slots are addressed as (addr_back + 124 - 4k): lds_byte_addr >= 128 is required (the
+// staging slices lie behind the first 128 bytes of LDS, static_assert below).
+__device__ __forceinline__ void scatter_bits32(uint32_t t, uint32_t lds_byte_addr, uint32_t nbits, uint32_t value_base) {
+    uint32_t lo, hi, tm1;
     uint64_t save;
+    const uint32_t back = lds_byte_addr + 4u * nbits - 128u;  // slot (nbits - 1 - k) = back + 124 - 4k
+    const uint32_t vb31 = value_base + 31u;
+    const uint32_t topbit = 0x80000000u;
     asm volatile(
         "s_mov_b64 %[save], exec\n"
-        ".set msj_sb_off, 0\n"
-        ".rept 32\n"
+        ".set msj_sb_k, 0\n"
+        ".rept 16\n"
         "v_cmpx_ne_u32_e32 vcc, 0, %[t]\n"
         "s_cbranch_execz 1f\n"
-        "v_ffbl_b32_e32 %[a], %[t]\n"
-        "v_or_b32_e32 %[a], %[a], %[vb]\n"
-        "ds_write_b32 %[addr], %[a] offset:msj_sb_off\n"
-        "v_add_u32_e32 %[b], -1, %[t]\n"
-        "v_and_b32_e32 %[t], %[b], %[t]\n"
-        ".set msj_sb_off, msj_sb_off+4\n"
+        "v_ffbl_b32_e32 %[lo], %[t]\n"
+        "v_ffbh_u32_e32 %[hi], %[t]\n"
+        "v_add_u32_e32 %[tm1], -1, %[t]\n"
+        "v_or_b32_e32 %[lo], %[lo], %[vb]\n"
+        "ds_write_b32 %[front], %[lo] offset:4*msj_sb_k\n"
+        "v_sub_u32_e32 %[lo], %[vb31], %[hi]\n"
+        "v_lshrrev_b32_e32 %[hi], %[hi], %[top]\n"
+        "ds_write_b32 %[back], %[lo] offset:124-4*msj_sb_k\n"
+        "v_bitop3_b32 %[t], %[t], %[tm1], %[hi] bitop3:0x40\n"
+        ".set msj_sb_k, msj_sb_k+1\n"
         ".endr\n"
         "1:\n"
         "s_mov_b64 exec, %[save]\n"
-        : [t] "+v"(t), [a] "=&v"(tmp1), [b] "=&v"(tmp2), [save] "=&s"(save)
-        : [addr] "v"(lds_byte_addr), [vb] "v"(value_base)
+        : [t] "+v"(t), [lo] "=&v"(lo), [hi] "=&v"(hi), [tm1] "=&v"(tm1), [save] "=&s"(save)
+        : [front] "v"(lds_byte_addr), [back] "v"(back), [vb] "v"(value_base), [vb31] "v"(vb31), [top] "v"(topbit)
         : "vcc", "memory");
 }
 
 // Same with 16-bit slots (tile-relative offsets fit 12 bits): twice as many indices per staging
 // round, for tiles with 1021..2044 structurals.
-__device__ __forceinline__ void scatter_bits16(uint32_t t, uint32_t lds_byte_addr, uint32_t value_base) {
-    uint32_t tmp1, tmp2;
+__device__ __forceinline__ void scatter_bits16(uint32_t t, uint32_t lds_byte_addr, uint32_t nbits, uint32_t value_base) {
+    uint32_t lo, hi, tm1;
     uint64_t save;
+    const uint32_t back = lds_byte_addr + 2u * nbits - 64u;  // slot (nbits - 1 - k) = back + 62 - 2k
+    const uint32_t vb31 = value_base + 31u;
+    const uint32_t topbit = 0x80000000u;
     asm volatile(
         "s_mov_b64 %[save], exec\n"
-        ".set msj_sb_off, 0\n"
-        ".rept 32\n"
+        ".set msj_sb_k, 0\n"
+        ".rept 16\n"
         "v_cmpx_ne_u32_e32 vcc, 0, %[t]\n"
         "s_cbranch_execz 1f\n"
-        "v_ffbl_b32_e32 %[a], %[t]\n"
-        "v_or_b32_e32 %[a], %[a], %[vb]\n"
-        "ds_write_b16 %[addr], %[a] offset:msj_sb_off\n"
-        "v_add_u32_e32 %[b], -1, %[t]\n"
-        "v_and_b32_e32 %[t], %[b], %[t]\n"
-        ".set msj_sb_off, msj_sb_off+2\n"
+        "v_ffbl_b32_e32 %[lo], %[t]\n"
+        "v_ffbh_u32_e32 %[hi], %[t]\n"
+        "v_add_u32_e32 %[tm1], -1, %[t]\n"
+        "v_or_b32_e32 %[lo], %[lo], %[vb]\n"
+        "ds_write_b16 %[front], %[lo] offset:2*msj_sb_k\n"
+        "v_sub_u32_e32 %[lo], %[vb31], %[hi]\n"
+        "v_lshrrev_b32_e32 %[hi], %[hi], %[top]\n"
+        "ds_write_b16 %[back], %[lo] offset:62-2*msj_sb_k\n"
+        "v_bitop3_b32 %[t], %[t], %[tm1], %[hi] bitop3:0x40\n"
+        ".set msj_sb_k, msj_sb_k+1\n"
         ".endr\n"
         "1:\n"
         "s_mov_b64 exec, %[save]\n"
-        : [t] "+v"(t), [a] "=&v"(tmp1), [b] "=&v"(tmp2), [save] "=&s"(save)
-        : [addr] "v"(lds_byte_addr), [vb] "v"(value_base)
+        : [t] "+v"(t), [lo] "=&v"(lo), [hi] "=&v"(hi), [tm1] "=&v"(tm1), [save] "=&s"(save)
+        : [front] "v"(lds_byte_addr), [back] "v"(back), [vb] "v"(value_base), [vb31] "v"(vb31), [top] "v"(topbit)
         : "vcc", "memory");
 }
+static_assert(offsetof(Shared, stage) >= 128, "scatter_bits32/16 address the back slots 128 / 64 bytes below the lane's end slot");
 
 // What a computed tile keeps in registers until it is parked.
 struct Pending {
@@ -602,9 +630,9 @@ __device__ __forceinline__ void stage_indices(const EmitU &e, const EmitV &v, ui
     // the block offset is a multiple of 64, so value_base | bit == value_base + bit
     const uint32_t v0 = e.tile * kTileBytes + lane64;  // < 2^32 per launch
     const uint32_t lds0 = (uint32_t)(uintptr_t)(stage + v.vpos);  // LDS byte address
-    const uint32_t nlo = (uint32_t)__builtin_popcount(v.tlo);
-    scatter_bits32(v.tlo, lds0, v0);
-    scatter_bits32(v.thi, lds0 + 4u * nlo, v0 | 32u);
+    const uint32_t nlo = (uint32_t)__builtin_popcount(v.tlo), nhi = (uint32_t)__builtin_popcount(v.thi);
+    scatter_bits32(v.tlo, lds0, nlo, v0);
+    scatter_bits32(v.thi, lds0 + 4u * nlo, nhi, v0 | 32u);
 }
 
 __device__ __forceinline__ void copy_out(const KernelArgs &a, const EmitU &e, const uint32_t *stage,
@@ -638,9 +666,9 @@ __device__ __forceinline__ void copy_out(const KernelArgs &a, const EmitU &e, co
 __device__ __forceinline__ void stage_indices16(const EmitV &v, uint32_t *stage, const uint32_t lane64) {
     uint16_t *stage16 = reinterpret_cast<uint16_t *>(stage);
     const uint32_t lds0 = (uint32_t)(uintptr_t)(stage16 + v.vpos);  // LDS byte address
-    const uint32_t nlo = (uint32_t)__builtin_popcount(v.tlo);
-    scatter_bits16(v.tlo, lds0, lane64);
-    scatter_bits16(v.thi, lds0 + 2u * nlo, lane64 + 32u);
+    const uint32_t nlo = (uint32_t)__builtin_popcount(v.tlo), nhi = (uint32_t)__builtin_popcount(v.thi);
+    scatter_bits16(v.tlo, lds0, nlo, lane64);
+    scatter_bits16(v.thi, lds0 + 2u * nlo, nhi, lane64 + 32u);
 }
 
 __device__ __forceinline__ void copy_out16(const KernelArgs &a, const EmitU &e, const uint32_t *stage,
@@ -682,7 +710,7 @@ __device__ __noinline__ void emit_rounds(uint32_t *idx, const uint32_t tile, con
                                          const uint32_t vpos, uint32_t *stage, const uint32_t lane) {
     const uint32_t v0 = tile * kTileBytes + lane * 64u;
     uint32_t *out = idx + (base - shift);  // out[v] <-> slot v of the tile; 16-byte aligned
-    const uint32_t nlo = (uint32_t)__builtin_popcount(tlo);
+    const uint32_t nlo = (uint32_t)__builtin_popcount(tlo), nhi = (uint32_t)__builtin_popcount(thi);
     uint32_t v_begin = shift;
     for (uint32_t r0 = 0; r0 < vend; r0 += kRoundSlots) {  // uniform; kRoundSlots is a multiple of 4
         const bool mine = vpos >= r0 && vpos < r0 + kRoundSlots;
@@ -690,8 +718,8 @@ __device__ __noinline__ void emit_rounds(uint32_t *idx, const uint32_t tile, con
         const uint64_t later = __ballot(vpos >= r0 + kRoundSlots);
         const uint32_t v_end = later ? bcast(vpos, (int)__builtin_ctzll(later)) : vend;
         const uint32_t lds0 = (uint32_t)(uintptr_t)(stage + (vpos - r0));
-        scatter_bits32(mine ? tlo : 0u, lds0, v0);
-        scatter_bits32(mine ? thi : 0u, lds0 + 4u * nlo, v0 | 32u);
+        scatter_bits32(mine ? tlo : 0u, lds0, nlo, v0);
+        scatter_bits32(mine ? thi : 0u, lds0 + 4u * nlo, nhi, v0 | 32u);
         lds_wave_sync();
         // copy out slots [v_begin, v_end): full quads in the body, partial quads element-wise
         const uint32_t q_lo = (v_begin + 3u) >> 2, q_hi = v_end >> 2;

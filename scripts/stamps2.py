@@ -27,7 +27,8 @@ def main():
     lib = ctypes.CDLL(os.environ.get("MSJ_STAMPS_LIB", os.path.join(ROOT, "scripts", "libmsj_stage1_stamps.so")))
     dev = torch.device("cuda", 0)
     u = synth.workload(workload, 64 << 20)
-    d_buf = torch.from_numpy(u).to(dev).repeat((1 << 30) // u.size)
+    gib = float(os.environ.get('MSJ_GIB', '1'))
+    d_buf = torch.from_numpy(u).to(dev).repeat(int(gib * (1 << 30)) // u.size)
     n = d_buf.numel()
     ntiles = (n + 4095) // 4096
     stamps = torch.zeros((ntiles + 8192) * 16, dtype=torch.int64, device=dev)
@@ -42,7 +43,8 @@ def main():
         stamps.zero_()
         assert lib.msj_stage1_device(h, d_buf.data_ptr(), n, d_idx.data_ptr(), d_idx.numel(), d_res.data_ptr(), None, flags) == 0
         torch.cuda.synchronize()
-    raw = stamps.cpu().numpy().reshape(ntiles + 8192, 16).astype(np.int64)[:ntiles]
+    allraw = stamps.cpu().numpy().reshape(ntiles + 8192, 16).astype(np.int64)
+    raw = allraw[:ntiles]
     okt = np.all(raw[:, :8] > 0, axis=1)
     print(f"workload {workload} flags {flags}: {ntiles} tiles, {okt.sum()} stamped")
     names = {1: "loop top -> compute entered", 2: "window carries", 3: "planes + classes + escape ballots",
@@ -68,6 +70,36 @@ def main():
         d = (y - x)[okr]
         d = d[(d >= 0) & (d < 10**6)]
         print(f"   {nm:36s} median {np.median(d):6.0f} mean {d.mean():7.0f}  share {100 * d.sum() / span.sum():5.1f} %")
+    # ---- real-time (100 MHz) view of the launch: start-up, tail, resolver chain
+    wg = allraw[ntiles + 4096: ntiles + 4096 + 1100]
+    wg = wg[wg[:, 0] > 0]
+    k0 = wg[:, 0].min()
+    us = lambda x: (x - k0) * 0.01
+    workers = wg[wg[:, 3] > 0]
+    print(f"workgroups: {len(wg)} started within {us(wg[:, 0]).max():.2f} us of the first")
+    for nm, c in (("prologue done", 2), ("first bytes in registers", 3), ("last range computed", 4), ("drained", 5)):
+        col = workers[:, c]
+        col = col[col > 0]
+        if col.size:
+            print(f"  {nm:26s} median {np.median(us(col)):8.2f} us   min {us(col).min():8.2f}   p10 {np.percentile(us(col), 10):8.2f}  p90 {np.percentile(us(col), 90):8.2f}  max {us(col).max():8.2f}")
+    res = allraw[ntiles:ntiles + 4096]  # resolver chunk rows
+    nch = int((res[:, 3] > 0).sum())
+    if nch:
+        rr = res[:nch]
+        print(f"resolver: {nch} chunks; first entered {us(rr[0, 0]):.2f} us, first done {us(rr[0, 3]):.2f}, last full {us(rr[-1, 1]):.2f}, last done {us(rr[-1, 3]):.2f} us")
+        q = [0, nch // 4, nch // 2, 3 * nch // 4, nch - 1]
+        print("  chunk done at (us): " + "  ".join(f"#{i}: {us(rr[i, 3]):.1f} (full {us(rr[i, 1]):.1f})" for i in q))
+    # range publish times (real time) along the launch
+    lo = np.arange(0, ntiles - 8, 8)
+    pub = raw[lo, 8]
+    mk = pub > 0
+    if mk.any():
+        pu = us(pub[mk])
+        idx = np.arange(lo.size)[mk]
+        for f in [k / 16 for k in range(17)] + [0.99]:
+            i = min(len(pu) - 1, int(f * (len(pu) - 1)))
+            print(f"  range {idx[i]:6d} ({100 * f:5.1f} %) aggregate published at {pu[i]:8.2f} us")
+        print(f"  all publishes within [{pu.min():.2f}, {pu.max():.2f}] us")
     lib.msj_ctx_destroy(h)
 
 
