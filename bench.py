@@ -157,6 +157,11 @@ def main():
     ap.add_argument("--gib-per-gpu", type=float, default=1.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-utf8", action="store_true", help="skip UTF-8 validation (not the headline config)")
+    ap.add_argument("--settle-ms", type=float, default=400.0,
+                    help="untimed back-to-back passes (this many ms of them) between the W warm-up steps and the K timed "
+                         "steps, so that the timed window sees the clocks the GPU holds under load instead of the "
+                         "transient after idle (DESIGN.md section 4); 0 = none.  The K steps right after the warm-up "
+                         "are timed too and reported as 'unsettled'")
     ap.add_argument("--no-emit", action="store_true",
                     help="diagnostic: summary pass only, no index writes (never a reported number)")
     args = ap.parse_args()
@@ -259,33 +264,58 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    def timed_window():
+        """EXACTLY K steps between two barriers; returns (wall seconds, HIP-event ms, last result)."""
+        last = None
+        barrier()
+        ev0 = torch.cuda.Event(enable_timing=True)
+        ev1 = torch.cuda.Event(enable_timing=True)
+        t0 = time.perf_counter()
+        ev0.record()
+        if world == 1:
+            for _ in range(args.steps):
+                last = step()
+        else:
+            # steps are independent passes: keep up to two submissions in flight, so that the stitch of
+            # step k (the RCCL all-gather, which may only get compute units once the persistent kernel of
+            # step k+1 drains, then the host-side verification) overlaps with the kernels of steps k+1 and
+            # k+2; all K results are in hand before the closing barrier
+            pending = []
+            for _ in range(args.steps):
+                pending.append(submit())
+                if len(pending) >= sh.DEPTH:
+                    last = sh.result(pending.pop(0))
+            while pending:
+                last = sh.result(pending.pop(0))
+        ev1.record()
+        barrier()
+        return time.perf_counter() - t0, ev0.elapsed_time(ev1), last
+
     last = None
     for _ in range(args.warmup):
         last = step()
-    barrier()
-    ev0 = torch.cuda.Event(enable_timing=True)
-    ev1 = torch.cuda.Event(enable_timing=True)
-    t0 = time.perf_counter()
-    ev0.record()
-    if world == 1:
-        for _ in range(args.steps):
-            last = step()
-    else:
-        # steps are independent passes: keep up to two submissions in flight, so that the stitch of
-        # step k (the RCCL all-gather, which may only get compute units once the persistent kernel of
-        # step k+1 drains, then the host-side verification) overlaps with the kernels of steps k+1 and
-        # k+2; all K results are in hand before the closing barrier
-        pending = []
-        for _ in range(args.steps):
-            pending.append(submit())
-            if len(pending) >= sh.DEPTH:
-                last = sh.result(pending.pop(0))
-        while pending:
-            last = sh.result(pending.pop(0))
-    ev1.record()
-    barrier()
-    dt = time.perf_counter() - t0
-    ev_ms = ev0.elapsed_time(ev1)
+    unsettled = None
+    settle_steps = 0
+    if args.settle_ms > 0:
+        # (a) the K steps as they run right after W warm-up steps on a GPU that was idle: reported, not `value`
+        u_dt, u_ev, _ = timed_window()
+        unsettled = (u_dt, u_ev)
+        # (b) keep the GPU under the same load until its clocks have settled (untimed)
+        t_end = time.perf_counter() + args.settle_ms * 1e-3
+        while True:
+            for _ in range(25):
+                last = step()
+            settle_steps += 25
+            torch.cuda.synchronize()
+            flag = torch.tensor([1.0 if time.perf_counter() < t_end else 0.0], dtype=torch.float64,
+                                device=device if (dist is None or backend == "nccl") else "cpu")
+            if dist is not None:
+                dist.all_reduce(flag, op=dist.ReduceOp.MIN)  # every rank leaves in the same round
+            if float(flag.item()) == 0.0:
+                break
+    dt, ev_ms, last_timed = timed_window()
+    if last_timed is not None:
+        last = last_timed
 
     # ---- result check (outside the timed region)
     if world == 1:
@@ -346,6 +376,8 @@ def main():
                 "structurals_total": total_count,
                 "density": round(total_count / total_len, 5),
                 "utf8_validation": not args.no_utf8,
+                "dvfs_settle": (f"{settle_steps} untimed passes ({args.settle_ms:g} ms) between the {args.warmup} warm-up "
+                                f"steps and the {args.steps} timed ones; see 'unsettled'") if args.settle_ms > 0 else "none",
                 **({"diagnostic": "no-emit summary pass: not a stage-1 result"} if args.no_emit else {}),
                 "sharding": "single GPU" if world == 1 else f"{world} byte-range shards, RCCL stitch",
             },
@@ -369,6 +401,16 @@ def main():
             },
             "cpu_baseline": cpu,
         }
+        if unsettled is not None:
+            # the same K steps timed right after the W warm-up steps, before the clocks have settled
+            u_k_ms = unsettled[1] / args.steps
+            out["unsettled"] = {
+                "ms_per_step": round(unsettled[0] / args.steps * 1e3, 4),
+                "value": round(total_len * args.steps / unsettled[0] / 1e9, 2),
+                "kernel_ms": round(u_k_ms, 4),
+                "roofline_frac": round(alg_bytes / (u_k_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
+                "note": "rank 0's clock; the first ~100 ms after idle run 10-15 % slower than the sustained rate",
+            }
         print(json.dumps(out), flush=True)
     dev.close()
     if dist is not None:
