@@ -30,7 +30,7 @@ from mojo_simdjson_amd.device import Stage1Device  # noqa: E402
 
 HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
 UNIT_BYTES = 64 << 20
-TILE = 16384  # shard bases are multiples of this (a multiple of the kernel's 4 KiB tile)
+SHARD_ALIGN = 16384  # shard bases are multiples of this (four of the kernel's 4 KiB tiles: 16-byte aligned bases)
 
 
 def build_stream_shard(d_unit, unit_len, start, length, device):
@@ -200,7 +200,7 @@ def main():
     per_gpu = int(args.gib_per_gpu * (1 << 30))
     total_len = (world * per_gpu // unit_len) * unit_len       # whole units: a valid document stream
     shard_len_nominal = -(-total_len // world)
-    shard_len_nominal = -(-shard_len_nominal // TILE) * TILE   # tile multiple => 16-byte aligned bases
+    shard_len_nominal = -(-shard_len_nominal // SHARD_ALIGN) * SHARD_ALIGN
     start = rank * shard_len_nominal
     shard_len = max(0, min(total_len, start + shard_len_nominal) - start)
     assert shard_len > 0

@@ -65,6 +65,14 @@ extern "C" {
 /* flags */
 #define MSJ_FLAG_STRICT_UTF8 1u /* return 11 when the input is not valid UTF-8 */
 #define MSJ_FLAG_NO_UTF8 2u     /* skip UTF-8 validation entirely (verdict = 0) */
+/* Index through the two-pass kernels (summary, scan, emission: no workgroup ever waits for another one)
+ * instead of the single-pass kernel.  Slower; what the library itself falls back to when a single-pass
+ * launch reports internal_error (an inter-workgroup wait ran into its 2 s bound), so that a valid document
+ * never comes back as UNEXPECTED_ERROR (24).  Same results bit for bit. */
+#define MSJ_FLAG_TWO_PASS 0x100u
+/* Test hook: the single-pass kernel's resolver idles ~2 ms before it starts (with msj_debug_set_wait_ticks
+ * this forces the wait-expiry path). */
+#define MSJ_FLAG_DEBUG_STALL 0x200u
 /* The first n (0..15) bytes of the buffer read as blanks: a window of a document stream starts at
  * a document, its 16-byte aligned base a few bytes earlier (msj_documents_device, resume_offset). */
 #define MSJ_FLAG_SKIP(n) (((uint32_t)(n) & 15u) << 24)
@@ -148,8 +156,16 @@ int32_t msj_stage1_device(msj_ctx *ctx, const uint8_t *d_buf, uint64_t len, uint
                           uint64_t idx_capacity, msj_carry *d_result, void *stream,
                           uint32_t flags);
 
-/* Blocking read-back of a device msj_carry (synchronises `stream`). */
+/* Blocking read-back of a device msj_carry (synchronises `stream`).  If it is the result of the context's last
+ * msj_stage1_device / msj_stage1_shard_device call and reports internal_error (a wait inside the single-pass
+ * kernel expired), that call is issued again through the two-pass kernels first (MSJ_FLAG_TWO_PASS), so the
+ * caller gets the document's real result. */
 int32_t msj_carry_fetch(msj_ctx *ctx, const msj_carry *d_carry, msj_carry *host_out, void *stream);
+
+/* Test hook: bound of every inter-workgroup wait of the single-pass kernel, in 10 ns ticks (default 2 s). */
+int32_t msj_debug_set_wait_ticks(msj_ctx *ctx, uint32_t ticks);
+/* Number of times this context fell back to the two-pass kernels after an expired wait. */
+uint64_t msj_fallback_count(const msj_ctx *ctx);
 
 /*
  * msj_stage1_shard_device -- one byte-range shard of a larger stream

@@ -133,6 +133,10 @@ def load():
                                          ctypes.c_uint64, ctypes.c_void_p, ctypes.c_void_p]
     lib.msj_carry_fetch.restype = ctypes.c_int32
     lib.msj_carry_fetch.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.POINTER(MsjCarry), ctypes.c_void_p]
+    lib.msj_debug_set_wait_ticks.restype = ctypes.c_int32
+    lib.msj_debug_set_wait_ticks.argtypes = [ctypes.c_void_p, ctypes.c_uint32]
+    lib.msj_fallback_count.restype = ctypes.c_uint64
+    lib.msj_fallback_count.argtypes = [ctypes.c_void_p]
     lib.msj_stage1_shard_device.restype = ctypes.c_int32
     lib.msj_stage1_shard_device.argtypes = [
         ctypes.c_void_p, u8p, ctypes.c_uint64, u32p, ctypes.c_uint64, ctypes.c_void_p,

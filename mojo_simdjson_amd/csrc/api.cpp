@@ -42,6 +42,16 @@ struct msj_ctx {
     uint8_t *d_small = nullptr;   // ... and its device side: [input][msj_carry][indices], same layout
     uint32_t grid = 0;            // persistent workgroups per launch (CUs x resident blocks per CU)
     uint32_t wait_ticks = msj::kWaitTicksDefault;  // bound of the kernel's waits (10 ns ticks)
+    uint64_t *tp = nullptr;       // workspace of the two-pass path (2 words per tile), allocated on first use
+    uint64_t tp_words = 0;
+    uint64_t fallbacks = 0;       // calls re-issued through the two-pass path after an expired wait
+    // the last shard call, so that msj_carry_fetch can re-issue it (one in-flight call per context)
+    struct {
+        bool valid = false;
+        const uint8_t *d_buf; uint64_t len; uint32_t *d_idx; uint64_t idx_capacity;
+        const msj_carry *d_carry_in; msj_carry *d_carry_out; msj_segment *d_segments; uint32_t max_segments;
+        bool has_prefix, is_final, no_emit; uint64_t trailer_len; hipStream_t stream; uint32_t flags;
+    } last;
     int32_t *tok_ws = nullptr;    // block aggregates of the token pre-pass
     uint64_t tok_ws_bytes = 0;
     uint64_t tok_doc_n = ~0ull;   // the token count whose document aggregates tok_ws holds (~0: none)
@@ -103,6 +113,11 @@ int32_t enqueue_shard(msj_ctx *ctx, const uint8_t *d_buf, uint64_t len, uint32_t
     if (nseg > kMaxChain) return MSJ_CAPACITY;
     if (d_segments && nseg > max_segments) return MSJ_CAPACITY;
     if (!hip_ok(hipSetDevice(ctx->device))) return MSJ_ERR_HIP;
+    ctx->last.valid = true;
+    ctx->last.d_buf = d_buf; ctx->last.len = len; ctx->last.d_idx = d_idx; ctx->last.idx_capacity = idx_capacity;
+    ctx->last.d_carry_in = d_carry_in; ctx->last.d_carry_out = d_carry_out; ctx->last.d_segments = d_segments;
+    ctx->last.max_segments = max_segments; ctx->last.has_prefix = has_prefix; ctx->last.is_final = is_final;
+    ctx->last.no_emit = no_emit; ctx->last.trailer_len = trailer_len; ctx->last.stream = stream; ctx->last.flags = flags;
 
     const uint64_t first_len = len < msj::kSegmentBytes ? len : msj::kSegmentBytes;
     const uint32_t max_tiles = (uint32_t)((first_len + msj::kTileBytes - 1) / msj::kTileBytes);
@@ -132,6 +147,27 @@ int32_t enqueue_shard(msj_ctx *ctx, const uint8_t *d_buf, uint64_t len, uint32_t
         if (s == 0) a.flags |= flags & (15u << msj::kFlagSkipShift);
         a.stamps = g_stamps;
         a.wait_ticks = ctx->wait_ticks;
+        a.tp = nullptr;
+        if (flags & MSJ_FLAG_DEBUG_STALL) a.flags |= msj::kFlagDebugStall;
+        if (flags & MSJ_FLAG_TWO_PASS) {
+            // three plain kernels, no inter-workgroup waiting, own workspace (need not be zeroed)
+            const uint64_t need = 2ull * max_tiles;
+            if (need > ctx->tp_words) {
+                if (ctx->tp) {
+                    (void)hipDeviceSynchronize();
+                    (void)hipFree(ctx->tp);
+                }
+                ctx->tp = nullptr;
+                ctx->tp_words = 0;
+                if (!hip_ok(hipMalloc(reinterpret_cast<void **>(&ctx->tp), need * sizeof(uint64_t)))) return MSJ_MEMALLOC;
+                ctx->tp_words = need;
+            }
+            a.tp = ctx->tp;
+            a.ws = nullptr;
+            a.ws_clean = nullptr;
+            if (msj_launch_stage1_twopass(&a, stream) != 0) return MSJ_ERR_HIP;
+            continue;
+        }
         // ticket + descriptors must read as "not ready" at launch: this launch's buffer is clean
         // already in the steady state; the other one is cleaned by this launch if its dirt has
         // this launch's layout, by a memset otherwise
@@ -206,6 +242,7 @@ void msj_ctx_destroy(msj_ctx *ctx) {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
     if (ctx->ws) (void)hipFree(ctx->ws);
+    if (ctx->tp) (void)hipFree(ctx->tp);
     if (ctx->tok_ws) (void)hipFree(ctx->tok_ws);
     if (ctx->doc_ws) (void)hipFree(ctx->doc_ws);
     if (ctx->carries) (void)hipFree(ctx->carries);
@@ -390,8 +427,32 @@ int32_t msj_carry_fetch(msj_ctx *ctx, const msj_carry *d_carry, msj_carry *host_
     if (!hip_ok(hipMemcpyAsync(host_out, d_carry, sizeof(msj_carry), hipMemcpyDeviceToHost, s)))
         return MSJ_ERR_HIP;
     if (!hip_ok(hipStreamSynchronize(s))) return MSJ_ERR_HIP;
+    if (host_out->internal_error && ctx->last.valid && ctx->last.d_carry_out == d_carry &&
+        !(ctx->last.flags & MSJ_FLAG_TWO_PASS)) {
+        // a wait inside the single-pass kernel ran into its bound (a starved GPU, a stalled resolver): the
+        // result is poisoned.  Run the call again through the two-pass kernels, which wait for nothing.
+        const auto L = ctx->last;
+        ctx->fallbacks++;
+        ctx->ws_dirty[0] = ctx->ws_dirty[1] = kAllDirty;  // the poisoned launch may have left anything behind
+        const int32_t rc = enqueue_shard(ctx, L.d_buf, L.len, L.d_idx, L.idx_capacity, L.d_carry_in, L.d_carry_out,
+                                         L.d_segments, L.max_segments, nullptr, L.has_prefix, L.is_final, L.no_emit,
+                                         L.trailer_len, L.stream, L.flags | MSJ_FLAG_TWO_PASS);
+        if (rc != MSJ_SUCCESS) return rc;
+        if (!hip_ok(hipStreamSynchronize(L.stream))) return MSJ_ERR_HIP;
+        if (!hip_ok(hipMemcpyAsync(host_out, d_carry, sizeof(msj_carry), hipMemcpyDeviceToHost, s)) ||
+            !hip_ok(hipStreamSynchronize(s)))
+            return MSJ_ERR_HIP;
+    }
     return MSJ_SUCCESS;
 }
+
+int32_t msj_debug_set_wait_ticks(msj_ctx *ctx, uint32_t ticks) {
+    if (!ctx) return MSJ_ERR_BAD_ARGUMENT;
+    ctx->wait_ticks = ticks;
+    return MSJ_SUCCESS;
+}
+
+uint64_t msj_fallback_count(const msj_ctx *ctx) { return ctx ? ctx->fallbacks : 0; }
 
 int32_t msj_stage1_ctx(msj_ctx *ctx, const uint8_t *buf, uint64_t len, uint32_t *idx_out,
                        uint64_t idx_capacity, uint64_t *n_out, int32_t *utf8_verdict_out,
@@ -421,6 +482,12 @@ int32_t msj_stage1_ctx(msj_ctx *ctx, const uint8_t *buf, uint64_t len, uint32_t 
             !hip_ok(hipStreamSynchronize(nullptr)))
             return MSJ_ERR_HIP;
         const msj_carry res = *reinterpret_cast<const msj_carry *>(ctx->h_pin + kSmallInput);
+        if (res.internal_error && !(flags & MSJ_FLAG_TWO_PASS)) {
+            // an expired wait in the single-pass kernel: once more through the two-pass kernels
+            ctx->fallbacks++;
+            ctx->ws_dirty[0] = ctx->ws_dirty[1] = kAllDirty;
+            return msj_stage1_ctx(ctx, buf, len, idx_out, idx_capacity, n_out, utf8_verdict_out, flags | MSJ_FLAG_TWO_PASS);
+        }
         if (utf8_verdict_out) *utf8_verdict_out = res.utf8_error ? MSJ_UTF8_ERROR : MSJ_SUCCESS;
         if (res.code == MSJ_UNCLOSED_STRING || res.code == MSJ_UNESCAPED_CHARS || res.code == MSJ_UNEXPECTED_ERROR ||
             res.code == MSJ_CAPACITY)

@@ -33,6 +33,7 @@ constexpr uint32_t kFlagNoUtf8 = 2u;       // == MSJ_FLAG_NO_UTF8
 constexpr uint32_t kFlagFinal = 4u;        // last segment of the stream: trailer + return code
 constexpr uint32_t kFlagHasPrefix = 8u;    // buf[-64..0) holds the preceding stream bytes
 constexpr uint32_t kFlagNoEmit = 16u;      // summary pass: no index writes
+constexpr uint32_t kFlagDebugStall = 32u;  // test hook (MSJ_FLAG_DEBUG_STALL): the resolver idles ~2 ms before it starts
 constexpr uint32_t kFlagSkipShift = 24u;   // bits 24..27 == MSJ_FLAG_SKIP(n): the first n < 16 bytes of the launch read as blanks
 
 struct KernelArgs {
@@ -52,6 +53,7 @@ struct KernelArgs {
     uint32_t flags;
     uint32_t wait_ticks;      // bound of every wait in the kernel, in s_memrealtime ticks (10 ns); expiry poisons the launch
     uint64_t *stamps;         // diagnostic builds only (-DMSJ_STAMPS): 16 words per tile, else null
+    uint64_t *tp;             // two-pass path only: 2 * ntiles words (tile aggregates, tile prefixes)
 };
 
 // ws: ticket shards (header), then per-tile carry words, range aggregates, range prefixes
@@ -64,4 +66,5 @@ inline uint64_t workspace_words(uint32_t ntiles) {
 
 // grid = number of persistent workgroups (0 = one per tile); clamped to ntiles + 1.
 extern "C" int msj_launch_stage1(const msj::KernelArgs *args, void *stream, uint32_t grid);
+extern "C" int msj_launch_stage1_twopass(const msj::KernelArgs *args, void *stream);
 extern "C" int msj_stage1_occupancy(int *blocks_per_cu);

@@ -155,15 +155,15 @@ struct Shared {
 
 // Waits are bounded by WALL TIME (s_memrealtime: a constant 100 MHz counter), not by a number
 // of polls: a.wait_ticks (default 2 s; tests lower it to force the expiry path).  The clock is read
-// once per 256 polls, for the first time after 256 (a short wait never reads it).  Expiry poisons
+// once per 16 polls, for the first time after 16 (a short wait never reads it).  Expiry poisons
 // the launch (internal_error); the host then re-runs the segment through the two-pass kernels,
 // which wait for nothing (api.cpp).
 struct WaitClock {
     uint32_t spins = 0, t0 = 0;
     __device__ __forceinline__ bool expired(const uint32_t wait_ticks) {
-        if ((++spins & 255u) != 0u) return false;
+        if ((++spins & 15u) != 0u) return false;
         const uint32_t now = (uint32_t)__builtin_amdgcn_s_memrealtime();  // 32 bits of 10 ns ticks: 42 s
-        if (spins == 256u) {
+        if (spins == 16u) {
             t0 = now;
             return false;
         }
@@ -408,7 +408,7 @@ __device__ __forceinline__ TileCarry window_carries(const KernelArgs &a, const u
 // them, and there is ONE rare branch (redo the escape scanner) instead of one per special case.
 __device__ __forceinline__ Pending compute_tile(const KernelArgs &a, const uint32_t tile,
                                                 const uint32_t lane, const Block &blk, const uint32_t carry0,
-                                                uint32_t &timeout, uint64_t &agg_word) {
+                                                uint32_t &timeout, uint64_t &agg_word, const uint32_t exact = 0u) {
     const uint32_t len = (uint32_t)a.len;  // < 2^32 per launch
     MSJ_STAMP(tile, 1);
     uint32_t x[16];
@@ -420,6 +420,13 @@ __device__ __forceinline__ Pending compute_tile(const KernelArgs &a, const uint3
         x[4 * k + 3] = blk.q[k].w;
     }
     TileCarry tc = window_carries(a, tile, blk.wb, carry0);
+    if (exact & 1u) {
+        // two-pass path: the escape / prev_scalar carries of a tile behind >= 63 backslashes come from the
+        // scan pass (bit 1, bit 2), never from waiting for the neighbour
+        tc.e_in = (exact >> 1) & 1u;
+        tc.ps_in = (exact >> 2) & 1u;
+        tc.resolved = true;
+    }
     // a window of a document stream starts at a document, its 16-byte aligned base up to 15 bytes
     // earlier: those bytes (the end of the previous document) read as blanks
     const uint32_t skip = tile == 0 ? (a.flags >> kFlagSkipShift) & 15u : 0u;  // uniform
@@ -1083,6 +1090,82 @@ __device__ __forceinline__ void worker_wave(const KernelArgs &a, Shared &sh, con
         ring = (ring + 1u == kDefer) ? 0u : ring + 1u;
     }
     MSJ_RSTAMP(a.ntiles + 4096u + blockIdx.x, 5, tid == 0);  // drained
+    // A wait that expired after this wave's last aggregate was published (in the drain, typically) can no
+    // longer travel with an aggregate: flag the result directly.  The resolver zeroes the word when the
+    // launch starts and ORs its own verdict in at the end, so the two cannot undo each other.
+    if (uniform32(timeout) && lane == 0) atomicOr(&a.carry_out->internal_error, 1u);
+}
+
+// ---- finish(): json_structural_indexer.mojo:147-186, by one lane, once every tile of the launch is
+//      folded: cs = in-string state at the end, cc = structurals of this launch, ce / cu / cx = sticky
+//      unescaped-character, UTF-8 and internal (timeout) errors.
+__device__ __forceinline__ void finish_launch(const KernelArgs &a, const uint32_t cs, const uint32_t cc,
+                                              const uint32_t ce, const uint32_t cu, const uint32_t cx,
+                                              const uint64_t *tile_agg = nullptr, const bool late_poison = false) {
+    const msj_carry cin = *a.carry_in;
+    if (!tile_agg) tile_agg = a.ws + kDescOffset;
+    const uint64_t last = ld_desc(&tile_agg[a.ntiles - 1u]);  // last TILE's carries
+    const bool do_utf8 = !(a.flags & kFlagNoUtf8);
+    msj_carry out;
+    const uint64_t n = cin.count + cc;
+    out.count = n;
+    out.bytes = cin.bytes + a.len;
+    out.in_string = cs;
+    out.next_is_escaped = (uint32_t)(last >> 58) & 1u;
+    out.prev_scalar = (uint32_t)(last >> 57) & 1u;
+    out.unescaped_error = (cin.unescaped_error | ce) ? 1u : 0u;
+    uint32_t u8e = cin.utf8_error | cu;
+    // a multi-byte sequence cut exactly at the end of the last full tile
+    if ((a.flags & kFlagFinal) && do_utf8 && (a.len % kTileBytes) == 0 && ((last >> 55) & 1u)) u8e = 1;
+    out.utf8_error = u8e ? 1u : 0u;
+    out.internal_error = (cin.internal_error | cx) ? 1u : 0u;
+    int32_t code = MSJ_SUCCESS;
+    if (a.flags & kFlagFinal) {
+        if (out.internal_error) {
+            code = MSJ_UNEXPECTED_ERROR;
+        } else if (cs) {
+            code = MSJ_UNCLOSED_STRING;  // :151-155
+        } else if (out.unescaped_error) {
+            code = MSJ_UNESCAPED_CHARS;  // :157-158
+        } else if (n + 3 > a.capacity) {
+            code = MSJ_CAPACITY;
+        } else {
+            if (!(a.flags & kFlagNoEmit)) {
+                a.idx[n] = (uint32_t)a.trailer_len;      // :167-169
+                a.idx[n + 1] = (uint32_t)a.trailer_len;  // :170-172
+                a.idx[n + 2] = 0;                        // :173
+            }
+            if (n == 0)
+                code = MSJ_EMPTY;  // :176-177
+            else if ((a.flags & kFlagStrictUtf8) && out.utf8_error)
+                code = MSJ_UTF8_ERROR;
+        }
+    }
+    out.code = code;
+    for (int k = 0; k < 5; k++) out.reserved[k] = 0;
+    if (late_poison) {
+        // single-pass kernel: workers may still OR a late timeout into internal_error (worker_wave), before
+        // or after this store: every other field is stored, this one is ORed
+        msj_carry *o = a.carry_out;
+        o->count = out.count;
+        o->bytes = out.bytes;
+        o->in_string = out.in_string;
+        o->next_is_escaped = out.next_is_escaped;
+        o->prev_scalar = out.prev_scalar;
+        o->unescaped_error = out.unescaped_error;
+        o->utf8_error = out.utf8_error;
+        o->code = out.code;
+        for (int k = 0; k < 5; k++) o->reserved[k] = 0;
+        if (out.internal_error) atomicOr(&o->internal_error, 1u);
+    } else {
+        *a.carry_out = out;
+    }
+    if (a.segment) {
+        a.segment->byte_base = a.segment_byte_base;
+        a.segment->byte_len = a.len;
+        a.segment->index_begin = cin.count;
+        a.segment->count = cc;
+    }
 }
 
 // ---- resolver: the four waves of one workgroup turn tile aggregates into tile
@@ -1110,11 +1193,6 @@ struct SubBlock {
     uint32_t bl;     // parity of the lanes below me in the sub-block
 };
 
-__device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v, uint32_t lane) {
-    (void)lane;
-    return dpp_add_scan(v);
-}
-
 __device__ void resolver(const KernelArgs &a, Shared &sh) {
     const uint32_t tid = threadIdx.x;
     const uint32_t lane = tid & 63u, wave = tid >> 6;
@@ -1127,6 +1205,8 @@ __device__ void resolver(const KernelArgs &a, Shared &sh) {
         a.ws_clean[(uint64_t)tid * kTicketStrideWords] = 0ull;  // ticket counters
     }
     if (tid == 0) {
+        // sticky from the stream so far; workers OR late timeouts into it (worker_wave), finish() ORs its own
+        a.carry_out->internal_error = a.carry_in->internal_error & 1u;
         sh.rs_seq = 0;
         sh.rs_s = a.carry_in->in_string & 1u;
         sh.rs_cnt = 0;
@@ -1135,6 +1215,11 @@ __device__ void resolver(const KernelArgs &a, Shared &sh) {
         sh.rs_poison = 0;
     }
     __syncthreads();
+    if (a.flags & kFlagDebugStall) {
+        // test hook: ~2 ms in which no range prefix appears, so that the workers' waits expire (with
+        // a lowered wait_ticks) and the host's two-pass fallback is exercised
+        for (uint32_t i = 0; i < 600u; i++) __builtin_amdgcn_s_sleep(127);
+    }
     const uint64_t below = (1ull << lane) - 1ull;
     volatile uint32_t *seq = &sh.rs_seq;
     __builtin_amdgcn_s_setprio(3);  // the serial chain of the whole launch runs here
@@ -1184,8 +1269,8 @@ __device__ void resolver(const KernelArgs &a, Shared &sh) {
                     sb[e].bl = bl;
                     sb[e].a = bl ? c1 : c0;
                     sb[e].b = c0 + c1;
-                    sb[e].scanA = wave_incl_scan(sb[e].a, lane);
-                    sb[e].scanB = wave_incl_scan(sb[e].b, lane);
+                    sb[e].scanA = dpp_add_scan(sb[e].a);
+                    sb[e].scanB = dpp_add_scan(sb[e].b);
                     tot0[e] = bcast(sb[e].scanA, 63);
                     totB[e] = bcast(sb[e].scanB, 63);
                     par[e] = (uint32_t)__popcll(PM) & 1u;
@@ -1252,58 +1337,7 @@ __device__ void resolver(const KernelArgs &a, Shared &sh) {
 #ifdef MSJ_STAMPS
                 if (lane == 0 && a.stamps) { a.stamps[(uint64_t)(a.ntiles + c) * 16 + 3] = __builtin_amdgcn_s_memrealtime(); a.stamps[(uint64_t)(a.ntiles + c) * 16 + 4] = rounds; a.stamps[(uint64_t)(a.ntiles + c) * 16 + 5] = published; }
 #endif
-                if (c + 1u == nchunks && lane == 0) {
-                    // ---- finish(): json_structural_indexer.mojo:147-186
-                    const msj_carry cin = *a.carry_in;
-                    const uint64_t last = ld_desc(&a.ws[kDescOffset + a.ntiles - 1u]);  // last TILE's carries
-                    const bool do_utf8 = !(a.flags & kFlagNoUtf8);
-                    msj_carry out;
-                    const uint64_t n = cin.count + cc;
-                    out.count = n;
-                    out.bytes = cin.bytes + a.len;
-                    out.in_string = cs;
-                    out.next_is_escaped = (uint32_t)(last >> 58) & 1u;
-                    out.prev_scalar = (uint32_t)(last >> 57) & 1u;
-                    out.unescaped_error = (cin.unescaped_error | ce) ? 1u : 0u;
-                    uint32_t u8e = cin.utf8_error | cu;
-                    // a multi-byte sequence cut exactly at the end of the last full tile
-                    if ((a.flags & kFlagFinal) && do_utf8 && (a.len % kTileBytes) == 0 &&
-                        ((last >> 55) & 1u))
-                        u8e = 1;
-                    out.utf8_error = u8e ? 1u : 0u;
-                    out.internal_error = (cin.internal_error | cx) ? 1u : 0u;
-                    int32_t code = MSJ_SUCCESS;
-                    if (a.flags & kFlagFinal) {
-                        if (out.internal_error) {
-                            code = MSJ_UNEXPECTED_ERROR;
-                        } else if (cs) {
-                            code = MSJ_UNCLOSED_STRING;  // :151-155
-                        } else if (out.unescaped_error) {
-                            code = MSJ_UNESCAPED_CHARS;  // :157-158
-                        } else if (n + 3 > a.capacity) {
-                            code = MSJ_CAPACITY;
-                        } else {
-                            if (!(a.flags & kFlagNoEmit)) {
-                                a.idx[n] = (uint32_t)a.trailer_len;      // :167-169
-                                a.idx[n + 1] = (uint32_t)a.trailer_len;  // :170-172
-                                a.idx[n + 2] = 0;                        // :173
-                            }
-                            if (n == 0)
-                                code = MSJ_EMPTY;  // :176-177
-                            else if ((a.flags & kFlagStrictUtf8) && out.utf8_error)
-                                code = MSJ_UTF8_ERROR;
-                        }
-                    }
-                    out.code = code;
-                    for (int k = 0; k < 5; k++) out.reserved[k] = 0;
-                    *a.carry_out = out;
-                    if (a.segment) {
-                        a.segment->byte_base = a.segment_byte_base;
-                        a.segment->byte_len = a.len;
-                        a.segment->index_begin = cin.count;
-                        a.segment->count = cc;
-                    }
-                }
+                if (c + 1u == nchunks && lane == 0) finish_launch(a, cs, cc, ce, cu, cx, nullptr, true);
                 break;
             }
             if (have_state && m > published) {
@@ -1325,7 +1359,7 @@ __device__ void resolver(const KernelArgs &a, Shared &sh) {
                         const uint64_t PM = __ballot(p != 0u);
                         const uint32_t in_l = cs ^ ((uint32_t)__popcll(PM & below) & 1u);
                         const uint32_t mine = in_l ? c1 : c0;
-                        const uint32_t incl = wave_incl_scan(mine, lane);
+                        const uint32_t incl = dpp_add_scan(mine);
                         const uint64_t EM = __ballot((in_l ? e1 : e0) != 0u);
                         const uint64_t U = __ballot(((de >> 56) & 1ull) != 0ull);
                         const uint64_t X = __ballot(((de >> 54) & 1ull) != 0ull);
@@ -1352,6 +1386,130 @@ __device__ void resolver(const KernelArgs &a, Shared &sh) {
             if (!full) __builtin_amdgcn_s_sleep(1);
         }
     }
+}
+
+
+// ---- the two-pass path: three plain kernels in which no workgroup ever waits for another one --------
+// What the host falls back to when a single-pass launch expires a wait (internal_error, api.cpp), and
+// what MSJ_FLAG_TWO_PASS asks for directly: slower (the input is read twice, the scan pass is one wave)
+// but there is nothing in it that could time out, so a valid document never comes back as code 24.
+//   pass 1  one wave per tile: the tile aggregate (tp[t]); a tile whose carries the 64 bytes in front of it
+//           do not decide (>= 63 backslashes) is left to the scan pass (status 3)
+//   scan    one wave walks the aggregates in order, 64 tiles per step (the resolver's arithmetic); a left-over
+//           tile is computed right there with the exact carries of its predecessor; writes per tile the state
+//           and the count in front of it (tp[ntiles + t]), then finish()
+//   pass 2  one wave per tile: the masks again, its state and position from the scan, emission as in the
+//           single-pass kernel (through one parked slot)
+constexpr uint64_t kTpUnresolved = 3ull << 62;
+
+__global__ __launch_bounds__(kThreads) void twopass_summary_kernel(const KernelArgs a) {
+    const uint32_t lane = threadIdx.x & 63u, wave = uniform32(threadIdx.x >> 6);
+    const uint32_t tile = blockIdx.x * kWaves + wave;
+    if (tile >= a.ntiles) return;
+    const uint32_t lane64 = lane * 64u;
+    const uint32_t lane_off[4] = {lane64, lane64 + 16u, lane64 + 32u, lane64 + 48u};
+    const uint32_t carry0 = uniform32((a.carry_in->next_is_escaped & 1u) | ((a.carry_in->prev_scalar & 1u) << 1));
+    Block blk;
+    load_block(a, tile, lane_off, lane, blk);
+    uint64_t *tp = a.tp;
+    if (!window_carries(a, tile, blk.wb, carry0).resolved) {
+        if (lane == 0) tp[tile] = kTpUnresolved;
+        return;
+    }
+    uint32_t timeout = 0;
+    uint64_t agg_word;
+    (void)compute_tile(a, tile, lane, blk, carry0, timeout, agg_word);
+    if (lane == 0) tp[tile] = agg_word;
+}
+
+__global__ __launch_bounds__(64) void twopass_scan_kernel(const KernelArgs a) {
+    const uint32_t lane = threadIdx.x;
+    const uint32_t ntiles = a.ntiles;
+    uint64_t *agg = a.tp, *pre = a.tp + ntiles;
+    const uint32_t lane64 = lane * 64u;
+    const uint32_t lane_off[4] = {lane64, lane64 + 16u, lane64 + 32u, lane64 + 48u};
+    const uint32_t carry0 = uniform32((a.carry_in->next_is_escaped & 1u) | ((a.carry_in->prev_scalar & 1u) << 1));
+    const uint64_t below = (1ull << lane) - 1ull;
+    uint32_t cs = uniform32(a.carry_in->in_string & 1u), cc = 0, ce = 0, cu = 0;
+    uint32_t e_prev = carry0 & 1u, ps_prev = (carry0 >> 1) & 1u;  // carries out of the tile before
+    for (uint32_t base = 0; base < ntiles; base += 64u) {  // uniform
+        const uint32_t t = base + lane;
+        uint64_t w = t < ntiles ? agg[t] : kAgg;  // past the end: identity
+        const uint64_t unres = __ballot((w >> 62) == 3ull);
+        if (unres == 0ull) {
+            const uint32_t p = (uint32_t)(w >> 61) & 1u;
+            const uint32_t c0 = (uint32_t)w & 0xFFFFu, c1 = (uint32_t)(w >> 16) & 0xFFFFu;
+            const uint32_t e0 = (uint32_t)(w >> 60) & 1u, e1 = (uint32_t)(w >> 59) & 1u;
+            const uint64_t PM = __ballot(p != 0u);
+            const uint32_t in_l = cs ^ ((uint32_t)__popcll(PM & below) & 1u);
+            const uint32_t mine = in_l ? c1 : c0;
+            const uint32_t incl = dpp_add_scan(mine);
+            const uint64_t EM = __ballot((in_l ? e1 : e0) != 0u);
+            const uint64_t U = __ballot(((w >> 56) & 1ull) != 0ull);
+            if (t < ntiles) pre[t] = kPre | ((uint64_t)in_l << 61) | (uint64_t)(cc + incl - mine);
+            cc += bcast(incl, 63);
+            ce |= EM ? 1u : 0u;
+            cu |= U ? 1u : 0u;
+            cs ^= (uint32_t)__popcll(PM) & 1u;
+            const uint32_t last = (ntiles - base < 64u ? ntiles - base : 64u) - 1u;  // last tile of the group
+            const uint32_t wh = bcast((uint32_t)(w >> 32), (int)last);
+            e_prev = (wh >> 26) & 1u;
+            ps_prev = (wh >> 25) & 1u;
+        } else {
+            // a tile of this group was left to the scan: walk the group tile by tile
+            const uint32_t cnt = ntiles - base < 64u ? ntiles - base : 64u;
+            for (uint32_t k = 0; k < cnt; k++) {  // uniform
+                uint64_t wk = u64(bcast((uint32_t)w, (int)k), bcast((uint32_t)(w >> 32), (int)k));
+                uint32_t exact = 0;
+                if ((wk >> 62) == 3ull) {
+                    Block blk;
+                    load_block(a, base + k, lane_off, lane, blk);
+                    uint32_t timeout = 0;
+                    exact = 1u | (e_prev << 1) | (ps_prev << 2);
+                    (void)compute_tile(a, base + k, lane, blk, carry0, timeout, wk, exact);
+                    if (lane == 0) agg[base + k] = wk;  // the launch's last tile: finish() reads its carries
+                }
+                const uint32_t c = cs ? (uint32_t)(wk >> 16) & 0xFFFFu : (uint32_t)wk & 0xFFFFu;
+                if (lane == 0) pre[base + k] = kPre | ((uint64_t)cs << 61) | ((uint64_t)exact << 50) | (uint64_t)cc;
+                cc += c;
+                ce |= (uint32_t)(wk >> (cs ? 59 : 60)) & 1u;
+                cu |= (uint32_t)(wk >> 56) & 1u;
+                cs ^= (uint32_t)(wk >> 61) & 1u;
+                e_prev = (uint32_t)(wk >> 58) & 1u;
+                ps_prev = (uint32_t)(wk >> 57) & 1u;
+            }
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    if (lane == 0) finish_launch(a, cs, cc, ce, cu, 0u, agg);
+}
+
+__global__ __launch_bounds__(kThreads) void twopass_emit_kernel(const KernelArgs a) {
+    __shared__ Shared sh;
+    const uint32_t lane = threadIdx.x & 63u, wave = uniform32(threadIdx.x >> 6);
+    const uint32_t tile = blockIdx.x * kWaves + wave;
+    if (tile >= a.ntiles) return;
+    const uint32_t lane64 = lane * 64u;
+    const uint32_t lane_off[4] = {lane64, lane64 + 16u, lane64 + 32u, lane64 + 48u};
+    const uint32_t carry0 = uniform32((a.carry_in->next_is_escaped & 1u) | ((a.carry_in->prev_scalar & 1u) << 1));
+    const uint64_t count0 = uniform64(a.carry_in->count);
+    Block blk;
+    load_block(a, tile, lane_off, lane, blk);
+    const uint64_t pw = uniform64(a.tp[a.ntiles + tile]);  // state and count in front of the tile (scan pass)
+    uint32_t timeout = 0;
+    uint64_t agg_word;
+    const Pending r = compute_tile(a, tile, lane, blk, carry0, timeout, agg_word, (uint32_t)(pw >> 50) & 7u);
+    // through one parked slot, like a tile of the single-pass kernel whose range starts at the tile itself
+    const uint32_t s_in = (uint32_t)(pw >> 61) & 1u;
+    sh.pend_masks[wave][0][lane] = make_uint4((uint32_t)r.T0, (uint32_t)(r.T0 >> 32), (uint32_t)r.T1, (uint32_t)(r.T1 >> 32));
+    sh.pend_excl[wave][0][lane] = r.excl;
+    if (lane == 0) *reinterpret_cast<uint4 *>(sh.pend_meta[wave][0]) = make_uint4(tile, r.tile_cnt, 0u, s_in | (s_in << 1));
+    lds_wave_sync();
+    uint32_t *stage = sh.stage[wave];
+    const EmitU e = emit_prepare(a, sh, wave, 0, kPre | (uint64_t)(uint32_t)pw, count0, timeout);
+    emit_stage(sh, e, wave, 0, stage, lane, lane64);
+    lds_wave_sync();
+    emit_store(a, sh, e, wave, 0, stage, lane);
 }
 
 __global__ __launch_bounds__(kThreads, 4) void stage1_kernel(const KernelArgs a) {
@@ -1395,6 +1553,17 @@ extern "C" int msj_launch_stage1(const msj::KernelArgs *args, void *stream, uint
     const uint32_t g = (grid == 0 || grid > need) ? need : grid;
     hipLaunchKernelGGL(msj::stage1_kernel, dim3(g < 2u ? 2u : g), dim3(msj::kThreads), 0,
                        static_cast<hipStream_t>(stream), a);
+    return (int)hipGetLastError();
+}
+
+// The two-pass path for one segment: summary, scan, emission (a.tp: 2 * ntiles words, need not be zeroed).
+extern "C" int msj_launch_stage1_twopass(const msj::KernelArgs *args, void *stream) {
+    const msj::KernelArgs a = *args;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const uint32_t wgs = (a.ntiles + msj::kWaves - 1u) / msj::kWaves;
+    hipLaunchKernelGGL(msj::twopass_summary_kernel, dim3(wgs), dim3(msj::kThreads), 0, s, a);
+    hipLaunchKernelGGL(msj::twopass_scan_kernel, dim3(1), dim3(64), 0, s, a);
+    if (!(a.flags & msj::kFlagNoEmit)) hipLaunchKernelGGL(msj::twopass_emit_kernel, dim3(wgs), dim3(msj::kThreads), 0, s, a);
     return (int)hipGetLastError();
 }
 

@@ -166,6 +166,14 @@ class Stage1Device:
             return d_doc_first, d_result
         return d_doc_first, _lib.MsjDocumentsResult.from_buffer_copy(d_result.cpu().numpy().tobytes())
 
+    def set_wait_ticks(self, ticks):
+        """Test hook: bound of the single-pass kernel's inter-workgroup waits in 10 ns ticks (default 2 s)."""
+        self.lib.msj_debug_set_wait_ticks(self.ctx, int(ticks))
+
+    def fallback_count(self):
+        """How often this context re-issued a call through the two-pass kernels after an expired wait."""
+        return int(self.lib.msj_fallback_count(self.ctx))
+
     def fetch(self, d_carry):
         """Blocking read-back of a device ``msj_carry``."""
         out = _lib.MsjCarry()
@@ -174,7 +182,3 @@ class Stage1Device:
             raise RuntimeError(f"msj_carry_fetch failed: {rc}")
         return out
 
-
-def reference_code(carry, strict_utf8=False):
-    """Return code in the reference's precedence from a fetched final carry."""
-    return int(carry.code)

@@ -17,7 +17,7 @@ from tests import helpers
 
 pytestmark = pytest.mark.gpu
 
-TILE = 16384
+TILE = 16384  # test sizes are built from this: four of the kernel's 4 KiB tiles, half a 32 KiB ticket range
 
 
 @pytest.fixture(scope="module")
@@ -46,10 +46,14 @@ def host_stage1(data, flags=0):
     return rc, p
 
 
-def assert_matches_oracle(oracle, data, where=""):
+FLAG_TWO_PASS = 0x100
+FLAG_DEBUG_STALL = 0x200
+
+
+def assert_matches_oracle(oracle, data, where="", flags=0):
     data = bytes(data)
     want = helpers.run_oracle(oracle.msj_oracle_stage1, data)
-    rc, p = host_stage1(data)
+    rc, p = host_stage1(data, flags)
     assert rc == want[0], f"{where}: code {rc} != oracle {want[0]} (len {len(data)})"
     if want[1] is not None:
         n = want[1]
@@ -353,6 +357,104 @@ def test_full_size_1gib_replication_property(torch_mod, dev, oracle, name):
             assert res3.code == 11
             d_buf[off] = saved
 
+
+
+@pytest.mark.parametrize("kind,density", [(5, 0.4), (4, 0.5), (1, 2 / 3), (0, 1.0)])
+def test_full_size_density_extremes(torch_mod, dev, oracle, kind, density):
+    """BASELINE.json config 4's synthetic extremes at full size (1 GiB): [1234,...] d = 0.4 and [123,...]
+    d = 0.5 (one staging round of 16-bit slots per tile, or rounds when the alignment shift pushes a
+    tile over), [10,...] d = 0.67 and [[[[...]]]] d = 1.0 (staging in rounds over groups of lanes).
+    Same replication property as the workloads above: every unit ends with all carries at zero, so
+    the expected index array is unit_idx + k * unit_len, compared index by index on the device."""
+    torch = torch_mod
+    from mojo_simdjson_amd import synth
+
+    u = synth.extreme((64 << 20) - 52, kind)
+    b = u.tobytes()
+    assert len(b) % 4096 != 0
+    code, n, idx = helpers.run_oracle(oracle.msj_oracle_stage1, b)
+    assert code == 0 and abs(n / len(b) - density) < 0.01
+    reps = (1 << 30) // len(b)
+    d_buf = torch.from_numpy(u).to(dev.device).repeat(reps)
+    total = d_buf.numel()
+    cap = n * reps + 3
+    d_idx, res = device_indices(torch, dev, d_buf, total, cap)
+    assert res.code == 0 and res.count == n * reps and res.internal_error == 0 and res.utf8_error == 0
+    unit_idx = torch.from_numpy(idx[:n].astype(np.int64)).to(dev.device)
+    for k in range(reps):
+        got = d_idx[k * n:(k + 1) * n].to(torch.int64) & 0xFFFFFFFF
+        assert torch.equal(got, unit_idx + k * len(b)), f"repetition {k}"
+        del got
+    tail = d_idx[n * reps:n * reps + 3].to(torch.int64) & 0xFFFFFFFF
+    assert tail.tolist() == [total, total, 0]
+
+
+def test_two_pass_path_equals_oracle(oracle):
+    """MSJ_FLAG_TWO_PASS: the kernels the library falls back to when a single-pass launch expires a wait
+    (summary / scan / emission, no inter-workgroup waiting) give the oracle's result bit for bit -- fuzz,
+    the reference's fixtures, tile boundaries, every density, and the tiles the scan pass has to compute
+    itself (>= 63 backslashes in front of a tile, whole tiles of backslashes)."""
+    import random
+    from mojo_simdjson_amd import synth
+
+    for f in helpers.golden_valid_files():
+        js, _ = helpers.read_fixture(f)
+        assert_matches_oracle(oracle, js, f, FLAG_TWO_PASS)
+    for i, d in enumerate(helpers.fuzz_inputs(777, 500)):
+        assert_matches_oracle(oracle, d, f"fuzz#{i}", FLAG_TWO_PASS)
+    rng = random.Random(5)
+    alpha = b'\\\\"""[]{}:, \n\tab01-\x01\xc3\xa9tfn'
+    for n in (4095, 4096, 4097, TILE + 63, 2 * TILE + 1, 5 * TILE + 777, 70 * TILE + 5):
+        d = bytes(rng.choice(alpha) for _ in range(n))
+        assert_matches_oracle(oracle, d, f"rand len {n}", FLAG_TWO_PASS)
+    for boundary in (4096, TILE, 3 * TILE):
+        for run in (1, 62, 63, 64, 65, 129, 200):
+            for shift in (-1, 0, 1):
+                pre = boundary + shift - run - 1
+                d = b'"' + b"a" * (pre - 1) + b"\\" * run + b'" , "x" ] ' + b"1" * 40
+                assert_matches_oracle(oracle, d, f"run {run} ending at {boundary + shift}", FLAG_TWO_PASS)
+    for run in (TILE, 2 * TILE + 1, 70 * 4096 + 5):
+        for lead in (1, 100):
+            d = b" " * (lead - 1) + b'"' + b"\\" * run + b'"  "' + b"b" * 10 + b'"'
+            assert_matches_oracle(oracle, d, f"tile run {run} lead {lead}", FLAG_TWO_PASS)
+    for kind in range(6):
+        d = synth.extreme(40 * TILE + 123, kind).tobytes()
+        assert_matches_oracle(oracle, d, f"extreme kind {kind}", FLAG_TWO_PASS)
+    for name in ("minified", "utf8", "pretty4"):
+        d = synth.workload(name, 8 << 20).tobytes()
+        assert_matches_oracle(oracle, d, name, FLAG_TWO_PASS)
+    # error codes and the strict UTF-8 verdict come out of the scan pass's finish()
+    assert host_stage1(b'["abc', FLAG_TWO_PASS)[0] == 15
+    assert host_stage1(b'["a\nb"]', FLAG_TWO_PASS)[0] == 14
+    assert host_stage1(b"   ", FLAG_TWO_PASS)[0] == 13
+    assert host_stage1(b'["\xff"]', FLAG_TWO_PASS | 1)[0] == 11
+
+
+def test_expired_wait_falls_back_to_two_pass(torch_mod, dev, oracle):
+    """A single-pass launch whose waits expire (test hooks: the resolver idles ~2 ms, the bound of every wait
+    is lowered to 20 us) poisons its result; msj_carry_fetch then re-issues the call through the two-pass
+    kernels, so the caller still gets the oracle's indices and code 0 -- never UNEXPECTED_ERROR (24)."""
+    torch = torch_mod
+    from mojo_simdjson_amd import synth
+
+    u = synth.workload("minified", 32 << 20)
+    b = u.tobytes()
+    code, n, idx = helpers.run_oracle(oracle.msj_oracle_stage1, b)
+    assert code == 0
+    d_buf = torch.from_numpy(u).to(dev.device)
+    before = dev.fallback_count()
+    dev.set_wait_ticks(2000)
+    try:
+        d_idx, res = device_indices(torch, dev, d_buf, len(b), n + 3, flags=FLAG_DEBUG_STALL)
+    finally:
+        dev.set_wait_ticks(200000000)
+    assert dev.fallback_count() == before + 1, "the stalled launch did not expire a wait"
+    assert res.code == 0 and res.count == n and res.internal_error == 0
+    assert np.array_equal(d_idx[: n + 3].cpu().numpy().view(np.uint32), idx[: n + 3])
+    # and the context is healthy afterwards: the next single-pass launch is clean
+    d_idx2, res2 = device_indices(torch, dev, d_buf, len(b), n + 3)
+    assert dev.fallback_count() == before + 1 and res2.code == 0 and res2.count == n
+    assert torch.equal(d_idx2[: n + 3], d_idx[: n + 3])
 
 def _sharded_dataset(name):
     from mojo_simdjson_amd import synth
