@@ -197,6 +197,92 @@ int32_t msj_stage1_shard_device(msj_ctx *ctx, const uint8_t *d_buf, uint64_t len
                                 uint64_t trailer_len, void *stream, uint32_t flags);
 
 /*
+ * ---- N-GPU form: one contiguous byte-range shard of one stream per rank (SURVEY.md section 8b
+ * `msj_stage1_sharded`, section 8e; one process per GPU) ----------------------------------------
+ * The reference is single-threaded (no parallelism of any kind); what a Mojo host
+ * calling DomParserImplementation.stage1 (include/generic/dom_parser_implementation.mojo:65-69) on a stream
+ * that is spread over the GPUs of a node binds is the pair msj_stage1_sharded_submit / _result below.
+ * Protocol (csrc/sharded.cpp): every rank assumes the carries at its shard's first byte from its own bytes
+ * (msj_shard_speculate), runs the single-pass kernel once, and ONE all-gather of a 128-byte report per rank
+ * lets every rank replay the chain (msj_shard_verify); only ranks whose assumption was refuted index again.
+ * Index arrays stay shard-local (offsets relative to the shard, or to its segments: msj_segment); the
+ * trailer is written by the last rank with `total_len`.
+ */
+typedef struct msj_shard_report {
+    msj_carry used; /* the carry this rank's launch assumed at its first byte */
+    msj_carry out;  /* the state after its last byte, its count and sticky errors */
+} msj_shard_report;
+
+/* Carries a shard may assume from its own bytes: halo = the <= 64 stream bytes in front of it (halo_len 0 at the
+ * start of the stream), head = its first <= 4096 bytes.  next_is_escaped / prev_scalar are exact unless a run of
+ * backslashes reaches halo[0]; in_string is a guess from the context of the first unescaped quote. */
+int32_t msj_shard_speculate(const uint8_t *halo, uint64_t halo_len, const uint8_t *head, uint64_t head_len,
+                            msj_carry *out);
+/* Replays the chain of all ranks' reports.  exact_in[g] (world entries) receives the exact carry at the start of
+ * shard g for every g < return value; *rerun_mask gets bit g set for every rank that has to index again with
+ * exact_in[g] (wrong in_string guess, wrong escape carries, or a poisoned launch -- the chain cannot be followed
+ * past the latter two).  Returns world and mask 0 when every report stands; < 0 on bad arguments. */
+int32_t msj_shard_verify(const msj_shard_report *reports, uint32_t world, msj_carry *exact_in, uint64_t *rerun_mask);
+/* The reference's return code for the whole stream (finish(), json_structural_indexer.mojo:147-186) and the
+ * total structural count, from reports that msj_shard_verify accepted. */
+int32_t msj_shard_global_code(const msj_shard_report *reports, uint32_t world, uint32_t flags, uint64_t *total_count);
+
+/* The one collective: all-gather of `bytes_per_rank` bytes per rank, device memory, enqueued on `stream`
+ * (or completed before returning).  Returns MSJ_SUCCESS or a negative library error. */
+typedef int32_t (*msj_allgather_fn)(void *comm, const void *d_send, void *d_recv, uint64_t bytes_per_rank, void *stream);
+typedef struct msj_exchange {
+    void *comm;                 /* passed to allgather as is */
+    msj_allgather_fn allgather;
+    uint32_t rank, world;       /* world <= 64 */
+    uint32_t owns_comm;         /* set by msj_exchange_rccl: `comm` is freed by msj_sharded_destroy */
+    uint32_t reserved;
+} msj_exchange;
+/* RCCL over xGMI: fills *out with an all-gather that calls ncclAllGather(..., ncclUint8, nccl_comm, stream).
+ * nccl_comm is the caller's ncclComm_t (passed as void*; it stays the caller's: create it with
+ * ncclCommInitRank, destroy it with ncclCommDestroy after msj_sharded_destroy).  The library does not link RCCL:
+ * the symbol is taken from `librccl_path` (NULL: "librccl.so") at run time -- pass the RCCL the communicator
+ * was created with. */
+int32_t msj_exchange_rccl(void *nccl_comm, uint32_t rank, uint32_t world, const char *librccl_path, msj_exchange *out);
+
+/* Device operations behind the protocol.  NULL in msj_sharded_create = HIP on the context's device; tests
+ * substitute host memory and a CPU shard runner to run the protocol without a GPU. */
+typedef struct msj_sharded_ops {
+    void *user;
+    int32_t (*alloc)(void *user, uint64_t bytes, int pinned_host, void **out);
+    void (*free)(void *user, void *p, int pinned_host);
+    int32_t (*copy)(void *user, void *dst, const void *src, uint64_t bytes, int to_host, void *stream);
+    int32_t (*sync)(void *user, void *stream);
+    int32_t (*run_shard)(void *user, const uint8_t *d_shard, uint64_t len, uint32_t *d_idx, uint64_t idx_capacity,
+                         const msj_carry *d_carry_in, msj_carry *d_carry_out, msj_segment *d_segments,
+                         uint32_t max_segments, int32_t has_prefix, int32_t is_final, uint64_t trailer_len,
+                         void *stream, uint32_t flags);
+} msj_sharded_ops;
+
+typedef struct msj_sharded msj_sharded;
+int32_t msj_sharded_create(msj_ctx *ctx, const msj_exchange *xchg, const msj_sharded_ops *ops, msj_sharded **out);
+void msj_sharded_destroy(msj_sharded *sh);
+uint64_t msj_sharded_reruns(const msj_sharded *sh); /* shard launches repeated by this rank (refuted guesses) */
+uint64_t msj_sharded_rounds(const msj_sharded *sh); /* all-gathers so far */
+
+/* Enqueue this rank's shard: kernel, all-gather of the reports, pinned read-back; returns at once with a ticket
+ * (up to 3 submissions may be in flight).  d_shard: 16-byte aligned device pointer; with has_prefix the 64 bytes
+ * in front of it must be readable stream bytes.  speculation: the carry to assume (e.g. what msj_shard_speculate
+ * gave for host copies of the bytes, or the carry a previous result reported as used), NULL = derived here from
+ * the device bytes (one small blocking read).  d_segments / max_segments as in msj_stage1_shard_device. */
+int32_t msj_stage1_sharded_submit(msj_sharded *sh, const uint8_t *d_shard, uint64_t shard_len, uint32_t *d_idx,
+                                  uint64_t idx_capacity, uint64_t total_len, int32_t has_prefix,
+                                  const msj_carry *speculation, msj_segment *d_segments, uint32_t max_segments,
+                                  void *stream, uint32_t flags, uint32_t *ticket_out);
+/* Wait for a submission; collective (every rank calls it for its matching ticket).  *code_out: the reference's
+ * return code for the whole stream; *total_count_out: structurals of the whole stream; *local_out: this shard's
+ * msj_carry (count = its own structurals); *used_out: the exact carry at its first byte. */
+int32_t msj_stage1_sharded_result(msj_sharded *sh, uint32_t ticket, int32_t *code_out, uint64_t *total_count_out,
+                                  msj_carry *local_out, msj_carry *used_out);
+/* Test hook: longest segment (bytes, multiple of 4096) one launch indexes; default MSJ_MAX_SEGMENT_BYTES rounded
+ * down to the tile. */
+int32_t msj_debug_set_segment_bytes(msj_ctx *ctx, uint64_t bytes);
+
+/*
  * ---- token stream for stage 2 (DERIVED, see below) -------------
  * msj_tokens_device -- from the structural indices of one segment, two coalesced arrays:
  *   d_type[i]  = buf[idx[i]]: the byte JsonIterator.advance / peek / last_structural dereference

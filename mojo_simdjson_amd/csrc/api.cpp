@@ -42,6 +42,7 @@ struct msj_ctx {
     uint8_t *d_small = nullptr;   // ... and its device side: [input][msj_carry][indices], same layout
     uint32_t grid = 0;            // persistent workgroups per launch (CUs x resident blocks per CU)
     uint32_t wait_ticks = msj::kWaitTicksDefault;  // bound of the kernel's waits (10 ns ticks)
+    uint64_t seg_bytes = msj::kSegmentBytes;  // longest segment of one launch (test hook: msj_debug_set_segment_bytes)
     uint64_t *tp = nullptr;       // workspace of the two-pass path (2 words per tile), allocated on first use
     uint64_t tp_words = 0;
     uint64_t fallbacks = 0;       // calls re-issued through the two-pass path after an expired wait
@@ -109,7 +110,8 @@ int32_t enqueue_shard(msj_ctx *ctx, const uint8_t *d_buf, uint64_t len, uint32_t
     if ((reinterpret_cast<uintptr_t>(d_buf) & 15u) != 0) return MSJ_ERR_BAD_ARGUMENT;
     if (!no_emit && !d_idx) return MSJ_ERR_BAD_ARGUMENT;
     if ((reinterpret_cast<uintptr_t>(d_idx) & 15u) != 0) return MSJ_ERR_BAD_ARGUMENT;  // 16-B stores
-    const uint64_t nseg = (len + msj::kSegmentBytes - 1) / msj::kSegmentBytes;
+    const uint64_t seg_bytes = ctx->seg_bytes;
+    const uint64_t nseg = (len + seg_bytes - 1) / seg_bytes;
     if (nseg > kMaxChain) return MSJ_CAPACITY;
     if (d_segments && nseg > max_segments) return MSJ_CAPACITY;
     if (!hip_ok(hipSetDevice(ctx->device))) return MSJ_ERR_HIP;
@@ -119,14 +121,14 @@ int32_t enqueue_shard(msj_ctx *ctx, const uint8_t *d_buf, uint64_t len, uint32_t
     ctx->last.max_segments = max_segments; ctx->last.has_prefix = has_prefix; ctx->last.is_final = is_final;
     ctx->last.no_emit = no_emit; ctx->last.trailer_len = trailer_len; ctx->last.stream = stream; ctx->last.flags = flags;
 
-    const uint64_t first_len = len < msj::kSegmentBytes ? len : msj::kSegmentBytes;
+    const uint64_t first_len = len < seg_bytes ? len : seg_bytes;
     const uint32_t max_tiles = (uint32_t)((first_len + msj::kTileBytes - 1) / msj::kTileBytes);
     int32_t rc = ensure_workspace(ctx, max_tiles);
     if (rc != MSJ_SUCCESS) return rc;
 
     for (uint64_t s = 0; s < nseg; s++) {
-        const uint64_t base = s * msj::kSegmentBytes;
-        const uint64_t seg_len = (len - base) < msj::kSegmentBytes ? (len - base) : msj::kSegmentBytes;
+        const uint64_t base = s * seg_bytes;
+        const uint64_t seg_len = (len - base) < seg_bytes ? (len - base) : seg_bytes;
         msj::KernelArgs a;
         a.buf = d_buf + base;
         a.len = seg_len;
@@ -453,6 +455,12 @@ int32_t msj_debug_set_wait_ticks(msj_ctx *ctx, uint32_t ticks) {
 }
 
 uint64_t msj_fallback_count(const msj_ctx *ctx) { return ctx ? ctx->fallbacks : 0; }
+
+int32_t msj_debug_set_segment_bytes(msj_ctx *ctx, uint64_t bytes) {
+    if (!ctx || bytes == 0 || bytes % msj::kTileBytes != 0 || bytes > msj::kSegmentBytes) return MSJ_ERR_BAD_ARGUMENT;
+    ctx->seg_bytes = bytes;
+    return MSJ_SUCCESS;
+}
 
 int32_t msj_stage1_ctx(msj_ctx *ctx, const uint8_t *buf, uint64_t len, uint32_t *idx_out,
                        uint64_t idx_capacity, uint64_t *n_out, int32_t *utf8_verdict_out,

@@ -1,0 +1,425 @@
+// sharded.cpp -- the N-GPU form of the stage-1 path (SURVEY.md section 8b `msj_stage1_sharded`, 8e):
+// one contiguous byte-range shard of one stream per rank (one process per GPU).
+//
+// The reference has no parallelism of any kind; the only state its stage 1 carries from block to
+// block is three bits and a count (json_escape_scanner.mojo:13, json_string_scanner.mojo:49,
+// json_scanner.mojo:57, json_structural_indexer.mojo:34).  A shard therefore needs the state at
+// its first byte, and the stream needs ONE tiny exchange:
+//   1. a rank derives (next_is_escaped, prev_scalar) from the 64 stream bytes in front of its shard
+//      (pure byte inspection) and SPECULATES in_string from the context of the first unescaped quote
+//      (msj_shard_speculate);
+//   2. one single-pass kernel launch per shard with that carry-in;
+//   3. ONE all-gather of a 128-byte report (carry used | carry out) per rank -- ncclAllGather over
+//      RCCL/xGMI in production (msj_exchange_rccl), any callback in tests: every rank replays the chain
+//      (msj_shard_verify), which proves or refutes every speculation at once; only the refuted ranks
+//      index again, with the now exact carry, the others contribute their cached report to the next
+//      all-gather.  The result is always exact; the guess only decides how often step 3 repeats.
+// No bulk data crosses xGMI; index arrays stay shard-local.
+//
+// Everything device-side goes through msj_sharded_ops, so that the protocol itself (submit / result /
+// re-run loop) also runs on a CPU-only box under test (tests/test_sharded_cpu.py: a fake shard runner
+// that follows the serial spec, gloo as the exchange).
+#include <dlfcn.h>
+#include <hip/hip_runtime.h>
+
+#include <cstring>
+#include <new>
+
+#include "../../include/msj_stage1.h"
+
+namespace {
+
+constexpr uint32_t kDepth = 3;  // submissions that may be in flight per rank
+
+bool is_nonscalar(uint8_t c) {
+    // op | ws, haswell.mojo:22-74 (effective sets): {09,0A,0D,20} and {0C,1A,2C,3A,5B,5D,7B,7D}
+    switch (c) {
+        case 0x09: case 0x0A: case 0x0D: case 0x20: case 0x0C: case 0x1A:
+        case 0x2C: case 0x3A: case 0x5B: case 0x5D: case 0x7B: case 0x7D:
+            return true;
+        default:
+            return false;
+    }
+}
+
+// length of the backslash run ending just before position pos of p[0..), -1 if it reaches p[0]
+int64_t run_before(const uint8_t *p, uint64_t pos) {
+    int64_t n = 0;
+    while (pos > 0 && p[pos - 1] == 0x5C) {
+        pos--;
+        n++;
+    }
+    return pos > 0 ? n : -1;
+}
+
+// ---- default device operations: HIP
+int32_t hip_alloc(void *, uint64_t bytes, int pinned_host, void **out) {
+    const hipError_t e = pinned_host ? hipHostMalloc(out, bytes, hipHostMallocDefault) : hipMalloc(out, bytes);
+    return e == hipSuccess ? MSJ_SUCCESS : MSJ_MEMALLOC;
+}
+void hip_free(void *, void *p, int pinned_host) {
+    if (!p) return;
+    if (pinned_host)
+        (void)hipHostFree(p);
+    else
+        (void)hipFree(p);
+}
+int32_t hip_copy(void *, void *dst, const void *src, uint64_t bytes, int to_host, void *stream) {
+    return hipMemcpyAsync(dst, src, bytes, to_host ? hipMemcpyDeviceToHost : hipMemcpyHostToDevice,
+                          static_cast<hipStream_t>(stream)) == hipSuccess
+               ? MSJ_SUCCESS
+               : MSJ_ERR_HIP;
+}
+int32_t hip_sync(void *, void *stream) {
+    return hipStreamSynchronize(static_cast<hipStream_t>(stream)) == hipSuccess ? MSJ_SUCCESS : MSJ_ERR_HIP;
+}
+int32_t hip_run_shard(void *user, const uint8_t *d_shard, uint64_t len, uint32_t *d_idx, uint64_t cap,
+                      const msj_carry *d_in, msj_carry *d_out, msj_segment *d_segments, uint32_t max_segments,
+                      int32_t has_prefix, int32_t is_final, uint64_t trailer_len, void *stream, uint32_t flags) {
+    return msj_stage1_shard_device(static_cast<msj_ctx *>(user), d_shard, len, d_idx, cap, d_in, d_out, d_segments,
+                                   max_segments, nullptr, has_prefix, is_final, 0, trailer_len, stream, flags);
+}
+
+// ---- RCCL exchange: ncclAllGather resolved at run time (the library does not link librccl)
+typedef int (*nccl_allgather_t)(const void *, void *, size_t, int, void *, void *);
+struct RcclExchange {
+    void *comm;
+    nccl_allgather_t allgather;
+};
+int32_t rccl_allgather(void *comm, const void *d_send, void *d_recv, uint64_t bytes_per_rank, void *stream) {
+    RcclExchange *x = static_cast<RcclExchange *>(comm);
+    // ncclUint8 = 1 (rccl.h ncclDataType_t); enqueued on the caller's stream, behind the kernel
+    return x->allgather(d_send, d_recv, (size_t)bytes_per_rank, 1, x->comm, stream) == 0 ? MSJ_SUCCESS : MSJ_ERR_HIP;
+}
+
+struct Slot {
+    msj_shard_report *d_mine = nullptr;      // device: this rank's report (used | out)
+    msj_shard_report *d_gathered = nullptr;  // device: world reports
+    msj_shard_report *h_gathered = nullptr;  // pinned host copy of d_gathered
+    msj_carry *h_spec = nullptr;             // pinned host: the carry this rank's launch used
+    bool busy = false;
+    // the call, for re-runs
+    const uint8_t *d_shard;
+    uint64_t shard_len, idx_capacity, total_len;
+    uint32_t *d_idx;
+    msj_segment *d_segments;
+    uint32_t max_segments, flags;
+    int32_t has_prefix;
+    void *stream;
+};
+
+}  // namespace
+
+struct msj_sharded {
+    msj_sharded_ops ops;
+    msj_exchange x;
+    Slot slots[kDepth];
+    uint32_t next = 0;
+    uint64_t reruns = 0, rounds = 0;
+    RcclExchange *owned_rccl = nullptr;
+};
+
+extern "C" {
+
+// (next_is_escaped, prev_scalar) after the last byte of halo[0..halo_len), from those bytes alone
+// (json_escape_scanner.mojo:18-45, json_scanner.mojo:64-79: a byte is escaped iff an odd run of
+// backslashes precedes it; prev_scalar = the last byte is a scalar character that is not a real quote).
+// Returns 0 and sets *decided = 0 when the bytes cannot decide (a backslash run reaches halo[0]).
+static void halo_state(const uint8_t *halo, uint64_t n, uint32_t *e, uint32_t *ps, int *decided) {
+    *e = 0;
+    *ps = 0;
+    *decided = 1;
+    if (n == 0) return;
+    const int64_t r = run_before(halo, n);
+    if (r < 0) {
+        *decided = 0;
+        return;
+    }
+    if (r >= 1) {
+        *e = (uint32_t)(r & 1);
+        *ps = 1;
+        return;
+    }
+    const uint8_t c = halo[n - 1];
+    if (is_nonscalar(c)) return;
+    if (c != 0x22) {
+        *ps = 1;
+        return;
+    }
+    const int64_t r2 = run_before(halo, n - 1);
+    if (r2 < 0) {
+        *decided = 0;
+        return;
+    }
+    *ps = (uint32_t)(r2 & 1);  // an escaped quote is a non-quote scalar
+}
+
+int32_t msj_shard_speculate(const uint8_t *halo, uint64_t halo_len, const uint8_t *head, uint64_t head_len,
+                            msj_carry *out) {
+    if (!out || (halo_len && !halo) || (head_len && !head)) return MSJ_ERR_BAD_ARGUMENT;
+    std::memset(out, 0, sizeof *out);
+    if (halo_len == 0) return MSJ_SUCCESS;  // start of the stream: the all-zero state
+    uint32_t e, ps;
+    int decided;
+    halo_state(halo, halo_len, &e, &ps, &decided);
+    if (!decided) {  // >= 64 backslashes in front of the shard: any guess; the chain check settles it
+        e = 0;
+        ps = 1;
+    }
+    out->next_is_escaped = e;
+    out->prev_scalar = ps;
+    // in_string: the first unescaped quote of the shard opens a string if one of `: , [ {` precedes it,
+    // closes one if one of `: , ] }` follows it (blanks skipped).  Only a guess.
+    uint32_t esc = e;
+    int64_t q = -1;
+    for (uint64_t i = 0; i < head_len; i++) {
+        const uint32_t escaped = esc;
+        if (escaped)
+            esc = 0;
+        else if (head[i] == 0x5C)
+            esc = 1;
+        if (head[i] == 0x22 && !escaped) {
+            q = (int64_t)i;
+            break;
+        }
+    }
+    if (q < 0) return MSJ_SUCCESS;
+    auto at = [&](int64_t k) -> int {  // byte k of halo + head, k relative to the shard start
+        if (k < 0) return -k <= (int64_t)halo_len ? halo[(int64_t)halo_len + k] : -1;
+        return k < (int64_t)head_len ? head[k] : -1;
+    };
+    auto blank = [](int c) { return c == ' ' || c == '\t' || c == '\n' || c == '\r'; };
+    int64_t k = q - 1;
+    while (blank(at(k))) k--;
+    int c = at(k);
+    if (c == ':' || c == ',' || c == '[' || c == '{') return MSJ_SUCCESS;  // opens: outside
+    k = q + 1;
+    while (blank(at(k))) k++;
+    c = at(k);
+    if (c == ':' || c == ',' || c == ']' || c == '}') out->in_string = 1;  // closes: inside
+    return MSJ_SUCCESS;
+}
+
+int32_t msj_shard_verify(const msj_shard_report *reports, uint32_t world, msj_carry *exact_in, uint64_t *rerun_mask) {
+    if (!reports || !exact_in || !rerun_mask || world == 0 || world > 64) return MSJ_ERR_BAD_ARGUMENT;
+    // A shard's quote parity is out.in_string ^ used.in_string whatever used.in_string was, and its
+    // next_is_escaped / prev_scalar out do not depend on the string state at all: the chain can be
+    // replayed through ranks that guessed in_string wrong (they only have to index again).  It stops at a
+    // rank whose escape carries were wrong or whose launch was poisoned: what that rank reports is not
+    // reliable, so nothing behind it can be judged yet.
+    uint64_t mask = 0;
+    uint32_t s = 0, e = 0, ps = 0;
+    uint64_t count = 0;
+    uint32_t g = 0;
+    for (; g < world; g++) {
+        const msj_carry &u = reports[g].used, &o = reports[g].out;
+        std::memset(&exact_in[g], 0, sizeof(msj_carry));
+        exact_in[g].in_string = s;
+        exact_in[g].next_is_escaped = e;
+        exact_in[g].prev_scalar = ps;
+        exact_in[g].count = 0;  // index arrays stay shard-local: every shard counts from 0
+        (void)count;
+        if ((u.next_is_escaped & 1u) != e || (u.prev_scalar & 1u) != ps || o.internal_error) {
+            mask |= 1ull << g;
+            g++;
+            break;
+        }
+        if ((u.in_string & 1u) != s) mask |= 1ull << g;
+        s ^= (o.in_string ^ u.in_string) & 1u;
+        e = o.next_is_escaped & 1u;
+        ps = o.prev_scalar & 1u;
+    }
+    *rerun_mask = mask;
+    // returns the number of ranks whose exact carry-in is known (world when the chain was replayed to the end)
+    return (int32_t)g;
+}
+
+int32_t msj_shard_global_code(const msj_shard_report *reports, uint32_t world, uint32_t flags, uint64_t *total_count) {
+    if (!reports || world == 0) return MSJ_ERR_BAD_ARGUMENT;
+    uint64_t total = 0;
+    uint32_t unescaped = 0, utf8 = 0, internal = 0;
+    for (uint32_t g = 0; g < world; g++) {
+        total += reports[g].out.count;
+        unescaped |= reports[g].out.unescaped_error;
+        utf8 |= reports[g].out.utf8_error;
+        internal |= reports[g].out.internal_error;
+    }
+    if (total_count) *total_count = total;
+    // finish(), json_structural_indexer.mojo:147-186: 15, then 14, then 13, then (strict) 11
+    if (internal) return MSJ_UNEXPECTED_ERROR;
+    if (reports[world - 1].out.in_string) return MSJ_UNCLOSED_STRING;
+    if (unescaped) return MSJ_UNESCAPED_CHARS;
+    if (total == 0) return MSJ_EMPTY;
+    if ((flags & MSJ_FLAG_STRICT_UTF8) && utf8) return MSJ_UTF8_ERROR;
+    return MSJ_SUCCESS;
+}
+
+int32_t msj_exchange_rccl(void *nccl_comm, uint32_t rank, uint32_t world, const char *librccl_path, msj_exchange *out) {
+    if (!nccl_comm || !out || world == 0 || rank >= world) return MSJ_ERR_BAD_ARGUMENT;
+    void *h = dlopen(librccl_path && *librccl_path ? librccl_path : "librccl.so", RTLD_NOW | RTLD_GLOBAL);
+    if (!h) return MSJ_ERR_NO_DEVICE;
+    nccl_allgather_t fn = reinterpret_cast<nccl_allgather_t>(dlsym(h, "ncclAllGather"));
+    if (!fn) return MSJ_ERR_NO_DEVICE;
+    RcclExchange *x = new (std::nothrow) RcclExchange{nccl_comm, fn};
+    if (!x) return MSJ_MEMALLOC;
+    out->comm = x;  // owned by the msj_sharded created from this exchange (msj_sharded_destroy frees it)
+    out->allgather = rccl_allgather;
+    out->rank = rank;
+    out->world = world;
+    out->owns_comm = 1;
+    return MSJ_SUCCESS;
+}
+
+int32_t msj_sharded_create(msj_ctx *ctx, const msj_exchange *xchg, const msj_sharded_ops *ops, msj_sharded **out) {
+    if (!xchg || !out || !xchg->allgather || xchg->world == 0 || xchg->world > 64 || xchg->rank >= xchg->world)
+        return MSJ_ERR_BAD_ARGUMENT;
+    if (!ops && !ctx) return MSJ_ERR_BAD_ARGUMENT;
+    *out = nullptr;
+    msj_sharded *sh = new (std::nothrow) msj_sharded();
+    if (!sh) return MSJ_MEMALLOC;
+    if (ops) {
+        sh->ops = *ops;
+    } else {
+        sh->ops.user = ctx;
+        sh->ops.alloc = hip_alloc;
+        sh->ops.free = hip_free;
+        sh->ops.copy = hip_copy;
+        sh->ops.sync = hip_sync;
+        sh->ops.run_shard = hip_run_shard;
+    }
+    sh->x = *xchg;
+    if (xchg->owns_comm) sh->owned_rccl = static_cast<RcclExchange *>(xchg->comm);
+    const uint64_t wb = (uint64_t)xchg->world * sizeof(msj_shard_report);
+    for (Slot &sl : sh->slots) {
+        void *p = nullptr;
+        bool ok = sh->ops.alloc(sh->ops.user, sizeof(msj_shard_report), 0, &p) == MSJ_SUCCESS;
+        sl.d_mine = static_cast<msj_shard_report *>(p);
+        ok = ok && sh->ops.alloc(sh->ops.user, wb, 0, &p) == MSJ_SUCCESS;
+        if (ok) sl.d_gathered = static_cast<msj_shard_report *>(p);
+        ok = ok && sh->ops.alloc(sh->ops.user, wb, 1, &p) == MSJ_SUCCESS;
+        if (ok) sl.h_gathered = static_cast<msj_shard_report *>(p);
+        ok = ok && sh->ops.alloc(sh->ops.user, sizeof(msj_carry), 1, &p) == MSJ_SUCCESS;
+        if (ok) sl.h_spec = static_cast<msj_carry *>(p);
+        if (!ok) {
+            msj_sharded_destroy(sh);
+            return MSJ_MEMALLOC;
+        }
+    }
+    *out = sh;
+    return MSJ_SUCCESS;
+}
+
+void msj_sharded_destroy(msj_sharded *sh) {
+    if (!sh) return;
+    for (Slot &sl : sh->slots) {
+        sh->ops.free(sh->ops.user, sl.d_mine, 0);
+        sh->ops.free(sh->ops.user, sl.d_gathered, 0);
+        sh->ops.free(sh->ops.user, sl.h_gathered, 1);
+        sh->ops.free(sh->ops.user, sl.h_spec, 1);
+    }
+    delete sh->owned_rccl;
+    delete sh;
+}
+
+uint64_t msj_sharded_reruns(const msj_sharded *sh) { return sh ? sh->reruns : 0; }
+uint64_t msj_sharded_rounds(const msj_sharded *sh) { return sh ? sh->rounds : 0; }
+
+// kernel (with the carry in sl.h_spec) -> all-gather of the reports -> pinned host copy; nothing waits here
+static int32_t launch_round(msj_sharded *sh, Slot &sl, bool run_kernel, uint32_t extra_flags) {
+    const msj_sharded_ops &o = sh->ops;
+    int32_t rc;
+    if (run_kernel) {
+        rc = o.copy(o.user, &sl.d_mine->used, sl.h_spec, sizeof(msj_carry), 0, sl.stream);
+        if (rc != MSJ_SUCCESS) return rc;
+        const int32_t last = sh->x.rank + 1 == sh->x.world;
+        rc = o.run_shard(o.user, sl.d_shard, sl.shard_len, sl.d_idx, sl.idx_capacity, &sl.d_mine->used, &sl.d_mine->out,
+                         sl.d_segments, sl.max_segments, sl.has_prefix, last, sl.total_len, sl.stream,
+                         sl.flags | extra_flags);
+        if (rc != MSJ_SUCCESS) return rc;
+    }
+    rc = sh->x.allgather(sh->x.comm, sl.d_mine, sl.d_gathered, sizeof(msj_shard_report), sl.stream);
+    if (rc != MSJ_SUCCESS) return rc;
+    sh->rounds++;
+    return o.copy(o.user, sl.h_gathered, sl.d_gathered, (uint64_t)sh->x.world * sizeof(msj_shard_report), 1, sl.stream);
+}
+
+int32_t msj_stage1_sharded_submit(msj_sharded *sh, const uint8_t *d_shard, uint64_t shard_len, uint32_t *d_idx,
+                                  uint64_t idx_capacity, uint64_t total_len, int32_t has_prefix,
+                                  const msj_carry *speculation, msj_segment *d_segments, uint32_t max_segments,
+                                  void *stream, uint32_t flags, uint32_t *ticket_out) {
+    if (!sh || !d_shard || shard_len == 0 || !ticket_out) return MSJ_ERR_BAD_ARGUMENT;
+    Slot &sl = sh->slots[sh->next];
+    if (sl.busy) return MSJ_CAPACITY;  // more than kDepth submissions without a result
+    const msj_sharded_ops &o = sh->ops;
+    if (speculation) {
+        *sl.h_spec = *speculation;
+    } else if (!has_prefix) {
+        std::memset(sl.h_spec, 0, sizeof(msj_carry));
+    } else {
+        // from the shard's own bytes: the 64 stream bytes in front of it and its first <= 4 KiB
+        uint8_t ctx_bytes[64 + 4096];
+        const uint64_t head = shard_len < 4096 ? shard_len : 4096;
+        int32_t rc = o.copy(o.user, ctx_bytes, d_shard - 64, 64 + head, 1, stream);
+        if (rc == MSJ_SUCCESS) rc = o.sync(o.user, stream);
+        if (rc != MSJ_SUCCESS) return rc;
+        rc = msj_shard_speculate(ctx_bytes, 64, ctx_bytes + 64, head, sl.h_spec);
+        if (rc != MSJ_SUCCESS) return rc;
+    }
+    sl.d_shard = d_shard;
+    sl.shard_len = shard_len;
+    sl.d_idx = d_idx;
+    sl.idx_capacity = idx_capacity;
+    sl.total_len = total_len;
+    sl.has_prefix = has_prefix;
+    sl.d_segments = d_segments;
+    sl.max_segments = max_segments;
+    sl.stream = stream;
+    sl.flags = flags;
+    const int32_t rc = launch_round(sh, sl, true, 0);
+    if (rc != MSJ_SUCCESS) return rc;
+    sl.busy = true;
+    *ticket_out = sh->next;
+    sh->next = (sh->next + 1) % kDepth;
+    return MSJ_SUCCESS;
+}
+
+int32_t msj_stage1_sharded_result(msj_sharded *sh, uint32_t ticket, int32_t *code_out, uint64_t *total_count_out,
+                                  msj_carry *local_out, msj_carry *used_out) {
+    if (!sh || ticket >= kDepth || !sh->slots[ticket].busy) return MSJ_ERR_BAD_ARGUMENT;
+    Slot &sl = sh->slots[ticket];
+    const msj_sharded_ops &o = sh->ops;
+    const uint32_t world = sh->x.world, rank = sh->x.rank;
+    msj_carry exact[64];
+    for (;;) {
+        int32_t rc = o.sync(o.user, sl.stream);
+        if (rc != MSJ_SUCCESS) return rc;
+        uint64_t mask = 0;
+        const int32_t known = msj_shard_verify(sl.h_gathered, world, exact, &mask);
+        if (known < 0) return known;
+        if (mask == 0 && (uint32_t)known == world) break;
+        // every rank sees the same reports, so all agree on who indexes again; everybody else re-contributes
+        // the report it has (no kernel), because the all-gather is collective
+        const bool mine = (mask >> rank) & 1u;
+        uint32_t extra = 0;
+        if (mine) {
+            // poisoned launch (an expired wait): through the two-pass kernels this time
+            if (sl.h_gathered[rank].out.internal_error) extra = MSJ_FLAG_TWO_PASS;
+            const uint64_t keep_count = 0;
+            *sl.h_spec = exact[rank];
+            sl.h_spec->count = keep_count;
+            sh->reruns++;
+        }
+        rc = launch_round(sh, sl, mine, extra);
+        if (rc != MSJ_SUCCESS) return rc;
+    }
+    sl.busy = false;
+    uint64_t total = 0;
+    const int32_t code = msj_shard_global_code(sl.h_gathered, world, sl.flags, &total);
+    if (code_out) *code_out = code;
+    if (total_count_out) *total_count_out = total;
+    if (local_out) *local_out = sl.h_gathered[rank].out;
+    if (used_out) *used_out = sl.h_gathered[rank].used;
+    return MSJ_SUCCESS;
+}
+
+}  // extern "C"

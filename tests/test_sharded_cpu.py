@@ -1,6 +1,10 @@
-"""CPU tests of the multi-GPU stitch logic (mojo_simdjson_amd/sharded.py):
-pure-host carry resolution, and the torch.distributed exchange on `gloo` with
-world_size 2 (the GPU box uses the same code over RCCL)."""
+"""CPU tests of the N-GPU path's host protocol (mojo_simdjson_amd/csrc/sharded.cpp through
+mojo_simdjson_amd/sharded.py): the pure functions against the serial spec, and the LIVE protocol --
+the library's own msj_stage1_sharded_submit / _result, re-run loop included -- with world_size 2 on
+`gloo`, a shard runner that follows the serial spec standing in for the kernel (msj_sharded_ops) and
+host memory standing in for the device.  The GPU box runs the same C code over the HIP kernels and
+RCCL."""
+import ctypes
 import os
 import random
 import socket
@@ -11,56 +15,104 @@ import torch.distributed as dist
 import torch.multiprocessing as mp
 
 from mojo_simdjson_amd import sharded
+from mojo_simdjson_amd._lib import MsjCarry
 from tests import helpers
 
+_NONSCALAR = frozenset([0x20, 0x09, 0x0A, 0x0D, 0x0C, 0x1A, 0x2C, 0x3A, 0x5B, 0x5D, 0x7B, 0x7D])
 
-def serial_state(data):
-    """(next_is_escaped, in_string, prev_scalar) after `data` per the serial spec."""
-    esc = instr = pnq = 0
-    for c in data:
+
+def serial_run(data, esc=0, instr=0, pnq=0, base=0):
+    """The serial spec from a given state: (indices, bad, esc, instr, pnq)."""
+    idx, bad = [], 0
+    for i, c in enumerate(data):
         escaped = esc
         if escaped:
             esc = 0
         elif c == 0x5C:
             esc = 1
         quote = (c == 0x22) and not escaped
+        before = instr
         instr ^= int(quote)
-        scalar = c not in sharded._NONSCALAR
+        scalar = c not in _NONSCALAR
+        op = c in (0x0C, 0x1A, 0x2C, 0x3A, 0x5B, 0x5D, 0x7B, 0x7D)
+        if (op or (scalar and not pnq)) and not before:
+            idx.append(base + i)
+        bad |= int(c <= 0x1F and instr)
         pnq = int(scalar and not quote)
+    return idx, bad, esc, instr, pnq
+
+
+def serial_state(data):
+    _, _, esc, instr, pnq = serial_run(data)
     return esc, instr, pnq
 
 
-def test_boundary_carry_matches_serial():
-    rng = random.Random(2)
-    alpha = b'\\\\\\\\""a1 ,:[]{}\n'
-    for _ in range(3000):
-        nsh = rng.randint(1, 4)
-        shards = [bytes(rng.choice(alpha) for _ in range(rng.randint(0, 9))) for _ in range(nsh)]
-        cap = rng.choice([1, 2, 3, 100])
-        tails = [s[max(0, len(s) - cap):] for s in shards]
-        complete = [len(t) == len(s) for t, s in zip(tails, shards)]
-        got = sharded.boundary_carry(tails, complete)
-        e, _, ps = serial_state(b"".join(shards))
-        if got is not None:
-            assert got == (e, ps), (shards, cap)
-        else:
-            assert cap < max(len(s) for s in shards)  # only truncated tails may be undecided
-    # full tails always decide
-    for _ in range(500):
-        shards = [bytes(rng.choice(alpha) for _ in range(rng.randint(0, 9))) for _ in range(3)]
-        e, _, ps = serial_state(b"".join(shards))
-        assert sharded.boundary_carry(shards, [True] * 3) == (e, ps)
+def test_speculate_matches_serial():
+    """next_is_escaped / prev_scalar from the 64-byte halo are exact (unless a backslash run fills it); the
+    in_string guess is right most of the time and never trusted."""
+    rng = random.Random(4)
+    doc = (b'{"a":"x y","b":[1,2,"q:\\"z\\"",true],"c":"k:","d":"\\\\\\\\"}' * 40)
+    right = wrong = 0
+    for _ in range(600):
+        cut = rng.randint(70, len(doc) - 70)
+        halo, head = doc[cut - 64:cut], doc[cut:cut + 4096]
+        e, s, ps = serial_state(doc[:cut])
+        g, ge, gps = sharded.speculate_bytes(halo, head)
+        assert (ge, gps) == (e, ps), (cut, halo)
+        right += g == s
+        wrong += g != s
+    assert right > 450 and wrong > 0  # good but not perfect: the re-run path matters
+    # short halos (shard near the start of the stream), no halo at all, undecidable halo
+    assert sharded.speculate_bytes(b"", b'"abc') == (0, 0, 0)
+    assert sharded.speculate_bytes(b'["a', b'b",1]')[1:] == (0, 1)
+    assert sharded.speculate_bytes(b"\\" * 64, b'"x')[1:] == (0, 1)  # any guess: the chain check settles it
+    rng = random.Random(9)
+    alpha = b'\\\\\\""a1 ,:[]{}\n'
+    for _ in range(2000):
+        n = rng.randint(1, 64)
+        pre = bytes(rng.choice(alpha) for _ in range(200))
+        e, _, ps = serial_state(pre)
+        halo = pre[-n:]
+        if all(c == 0x5C for c in halo) or (halo[-1] == 0x22 and all(c == 0x5C for c in halo[:-1])):
+            continue  # the run reaches the halo's first byte: undecidable from these bytes
+        assert sharded.speculate_bytes(halo, b"x")[1:] == (e, ps), halo
 
 
-def test_parity_prefix_and_code():
-    s, last = sharded.parity_prefix([1, 0, 1, 1])
-    assert s == [0, 1, 1, 0] and last == 1
-    assert sharded.global_code(1, True, 5, True, False, True) == 15
-    assert sharded.global_code(0, True, 5, True, False, True) == 14
-    assert sharded.global_code(0, False, 0, True, False, True) == 13
-    assert sharded.global_code(0, False, 3, True, False, True) == 11
-    assert sharded.global_code(0, False, 3, True, False, False) == 0
-    assert sharded.global_code(0, False, 3, False, True, False) == 24
+def test_verify_chain():
+    """msj_shard_verify: replays the chain through wrong in_string guesses, stops at wrong escape carries or a
+    poisoned launch, and names every rank that has to index again."""
+    rng = random.Random(6)
+    doc = (b'{"a":"x y","b":[1,2,"q:\\"z\\"",true],"c":"k:","e":"\\\\"}' * 30)
+    for _ in range(300):
+        world = rng.randint(2, 8)
+        cuts = [0] + sorted(rng.sample(range(10, len(doc) - 10), world - 1)) + [len(doc)]
+        true_in = [serial_state(doc[:c]) for c in cuts[:-1]]  # (e, s, ps)
+        reports, want_mask = [], 0
+        broken_at = None
+        for g in range(world):
+            e, s, ps = true_in[g]
+            mode = rng.choice(["ok", "ok", "ok", "wrong_s", "wrong_e", "poison"]) if g else "ok"
+            us, ue, ups = s, e, ps
+            poison = 0
+            if mode == "wrong_s":
+                us ^= 1
+            elif mode == "wrong_e":
+                ue ^= 1
+            elif mode == "poison":
+                poison = 1
+            _, _, oe, os_, ops = serial_run(doc[cuts[g]:cuts[g + 1]], ue, us, ups)
+            reports.append(((us, ue, ups), (os_, oe, ops, poison)))
+            if broken_at is None:
+                if mode != "ok":
+                    want_mask |= 1 << g
+                if mode in ("wrong_e", "poison"):
+                    broken_at = g
+        known, mask, exact = sharded.verify_reports(reports)
+        assert mask == want_mask, (reports, mask, want_mask)
+        assert known == (world if broken_at is None else broken_at + 1)
+        for g in range(known):
+            e, s, ps = true_in[g]
+            assert exact[g] == (s, e, ps)
 
 
 def _free_port():
@@ -69,84 +121,145 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _worker(rank, world, port, stream_hex, cuts, q):
+class _HostOps:
+    """msj_sharded_ops over host memory: the 'device' is this process's heap, the 'kernel' is the serial spec."""
+
+    def __init__(self):
+        self.bufs = {}
+        self.launches = 0
+        O = sharded.MsjShardedOps
+        f = dict(O._fields_)
+        self.alloc = f["alloc"](self._alloc)
+        self.free = f["free"](self._free)
+        self.copy = f["copy"](self._copy)
+        self.sync = f["sync"](lambda user, stream: 0)
+        self.run_shard = f["run_shard"](self._run)
+        self.ops = O(None, self.alloc, self.free, self.copy, self.sync, self.run_shard)
+
+    def _alloc(self, user, nbytes, pinned, out):
+        b = ctypes.create_string_buffer(int(nbytes))
+        self.bufs[ctypes.addressof(b)] = b
+        out[0] = ctypes.addressof(b)
+        return 0
+
+    def _free(self, user, p, pinned):
+        self.bufs.pop(p, None)
+
+    def _copy(self, user, dst, src, nbytes, to_host, stream):
+        ctypes.memmove(dst, src, nbytes)
+        return 0
+
+    def _run(self, user, d_shard, length, d_idx, cap, d_in, d_out, d_seg, max_seg, has_prefix, is_final, trailer_len,
+             stream, flags):
+        self.launches += 1
+        data = ctypes.string_at(d_shard, length)
+        cin = MsjCarry.from_address(d_in)
+        idx, bad, esc, instr, pnq = serial_run(data, cin.next_is_escaped, cin.in_string, cin.prev_scalar)
+        out = MsjCarry.from_address(d_out)
+        ctypes.memset(d_out, 0, ctypes.sizeof(MsjCarry))
+        out.count, out.bytes = len(idx), length
+        out.in_string, out.next_is_escaped, out.prev_scalar, out.unescaped_error = instr, esc, pnq, bad
+        arr = (ctypes.c_uint32 * (len(idx) + 3)).from_address(d_idx)
+        for k, v in enumerate(idx):
+            arr[k] = v
+        if is_final:
+            arr[len(idx)], arr[len(idx) + 1], arr[len(idx) + 2] = trailer_len & 0xFFFFFFFF, trailer_len & 0xFFFFFFFF, 0
+        return 0
+
+
+def _live_worker(rank, world, port, cases, q):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
-        data = bytes.fromhex(stream_hex)
-        lo, hi = cuts[rank], cuts[rank + 1]
-        shard = data[lo:hi]
-        dev = torch.device("cpu")
-        cap = 4
-        while True:  # same retry loop as ShardedStage1.boundary_exchange
-            tails, lens = sharded.exchange_tails(shard[max(0, len(shard) - cap):], len(shard), dev,
-                                                 tail_cap=cap)
-            res = sharded.resolve_boundaries(tails, lens)
-            if all(r is not None for r in res):
-                break
-            cap *= 16
-        e_in, ps_in = res[rank]
-        # parity of my shard given my exact escape carry (stand-in for the summary pass)
-        esc, par = e_in, 0
-        for c in shard:
-            escaped = esc
-            if escaped:
-                esc = 0
-            elif c == 0x5C:
-                esc = 1
-            par ^= int(c == 0x22 and not escaped)
-        got = sharded.exchange_words([par], dev)
-        s_list, _ = sharded.parity_prefix([int(w[0]) for w in got])
-        q.put((rank, e_in, ps_in, s_list[rank]))
+        L = sharded.lib()
+        host = _HostOps()
+
+        def allgather(comm, d_send, d_recv, nbytes, stream):
+            mine = torch.frombuffer(bytearray(ctypes.string_at(d_send, nbytes)), dtype=torch.uint8)
+            gathered = torch.empty(world * nbytes, dtype=torch.uint8)
+            dist.all_gather_into_tensor(gathered, mine)
+            blob = gathered.numpy().tobytes()
+            ctypes.memmove(d_recv, blob, len(blob))
+            return 0
+
+        cb = sharded.ALLGATHER_FN(allgather)
+        x = sharded.MsjExchange(None, cb, rank, world, 0, 0)
+        h = ctypes.c_void_p()
+        assert L.msj_sharded_create(None, ctypes.byref(x), ctypes.byref(host.ops), ctypes.byref(h)) == 0
+        results = []
+        for data_hex, cuts in cases:
+            data = bytes.fromhex(data_hex)
+            lo, hi = cuts[rank], cuts[rank + 1]
+            # the "device" holds the 64-byte halo in front of the shard, like a placed shard does
+            halo = 64 if rank > 0 else 0
+            pad = bytes(64 - min(64, lo)) if rank > 0 else b""
+            alloc = ctypes.create_string_buffer(pad + data[max(0, lo - 64):hi], len(pad) + hi - max(0, lo - 64))
+            d_shard = ctypes.addressof(alloc) + (len(pad) + min(64, lo) if rank > 0 else 0)
+            idx = (ctypes.c_uint32 * (hi - lo + 3))()
+            ticket = ctypes.c_uint32()
+            before = host.launches
+            rc = L.msj_stage1_sharded_submit(h, d_shard, hi - lo, ctypes.addressof(idx), hi - lo + 3, len(data), int(rank > 0),
+                                             None, None, 0, None, 0, ctypes.byref(ticket))
+            assert rc == 0 and halo in (0, 64)
+            code, total = ctypes.c_int32(), ctypes.c_uint64()
+            local, used = MsjCarry(), MsjCarry()
+            assert L.msj_stage1_sharded_result(h, ticket.value, ctypes.byref(code), ctypes.byref(total), ctypes.byref(local),
+                                               ctypes.byref(used)) == 0
+            n = int(local.count)
+            results.append((code.value, int(total.value), [int(idx[k]) + lo for k in range(n)],
+                            (used.next_is_escaped, used.in_string, used.prev_scalar), host.launches - before,
+                            [int(idx[n + k]) for k in range(3)] if rank == world - 1 else None))
+        q.put((rank, results, int(L.msj_sharded_reruns(h)), int(L.msj_sharded_rounds(h))))
+        L.msj_sharded_destroy(h)
     finally:
         dist.destroy_process_group()
 
 
-def test_gloo_world2_exchange():
+def test_gloo_world2_live_protocol():
+    """The library's submit / result loop under gloo, world 2, on CPU: right guesses take one launch and one
+    all-gather; a refuted guess makes exactly that rank launch again (the other one only re-contributes its
+    report); results equal the serial spec of the whole stream, error codes included."""
     rng = random.Random(8)
     alpha = b'\\\\\\""a1 ,:[]{}'
+    cases = []
     for trial in range(3):
-        data = bytes(rng.choice(alpha) for _ in range(200))
-        if trial == 2:  # long backslash run across the cut: forces the tail-growth retry
-            data = b'["' + b"\\" * 150 + b'\\"x"' + b",1]" * 10
-        cut = rng.randint(20, len(data) - 20) if trial != 2 else 120
-        cuts = [0, cut, len(data)]
-        ctx = mp.get_context("spawn")
-        q = ctx.Queue()
-        port = _free_port()
-        procs = [ctx.Process(target=_worker, args=(r, 2, port, data.hex(), cuts, q)) for r in range(2)]
-        for p in procs:
-            p.start()
-        res = sorted(q.get(timeout=120) for _ in range(2))
-        for p in procs:
-            p.join(timeout=60)
-            assert p.exitcode == 0
-        assert res[0][1:] == (0, 0, 0)
-        e, s, ps = serial_state(data[:cut])
-        assert res[1][1:] == (e, ps, s), (data, cut)
-
-
-def test_guess_and_verify_chain():
-    """The speculation is only a guess; verify_chain must accept exactly the right ones."""
-    rng = random.Random(4)
-    doc = (b'{"a":"x y","b":[1,2,"q:\\"z\\"",true],"c":"k:"}' * 40)
-    right = wrong = 0
-    for _ in range(400):
-        cut = rng.randint(70, len(doc) - 70)
-        halo, head = doc[cut - 64:cut], doc[cut:cut + 4096]
-        e, s, ps = serial_state(doc[:cut])
-        hc = sharded.halo_carry(halo)
-        assert hc == (e, ps)
-        g = sharded.guess_in_string(halo, head, e)
-        right += g == s
-        wrong += g != s
-        # rank 1 used guess g: the chain check must flag it iff g != s
-        e1, s1, ps1 = serial_state(doc)
-        e0, s0, ps0 = serial_state(doc[:cut])
-        rep = [dict(s_used=0, e_used=0, ps_used=0, s_out=s0, e_out=e0, ps_out=ps0),
-               dict(s_used=g, e_used=e, ps_used=ps, s_out=s1 ^ s ^ g, e_out=e1, ps_out=ps1)]
-        first_wrong, true_in = sharded.verify_chain(rep)
-        assert (first_wrong == 2) == (g == s)
-        assert true_in[1] == (s, e, ps)
-    assert right > 300 and wrong > 0  # good but not perfect: the re-run path matters
+        data = bytes(rng.choice(alpha) for _ in range(300))
+        cases.append((data, [0, rng.randint(80, 220), len(data)]))
+    # the cut falls inside a string whose closing quote follows a ':' -> rank 1's guess is refuted
+    wrong = b'["' + b"a" * 90 + b':",1,2,"zz"]'
+    cases.append((wrong, [0, 40, len(wrong)]))
+    # a long backslash run across the cut (the halo cannot decide the escape carry)
+    bs = b'["' + b"\\" * 150 + b'\\"x"' + b",1]" * 10
+    cases.append((bs, [0, 120, len(bs)]))
+    cases.append((bs, [0, 121, len(bs)]))
+    # unclosed string / control character inside a string on rank 1
+    cases.append((b'[1,2,"abc' + b" " * 80 + b'"x', [0, 50, 92]))
+    cases.append((b'["' + b"s" * 70 + b"\n" + b's"]', [0, 30, 76]))
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    payload = [(d.hex(), c) for d, c in cases]
+    procs = [ctx.Process(target=_live_worker, args=(r, 2, port, payload, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = dict((r[0], r[1:]) for r in (q.get(timeout=180) for _ in range(2)))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    total_reruns = 0
+    for k, (data, cuts) in enumerate(cases):
+        idx, bad, esc, instr, pnq = serial_run(data)
+        want_code = 15 if instr else 14 if bad else 13 if not idx else 0
+        r0, r1 = res[0][0][k], res[1][0][k]
+        assert r0[0] == r1[0] == want_code, (k, r0[0], want_code)
+        assert r0[1] == r1[1] == len(idx)
+        assert r0[2] + r1[2] == idx, f"case {k}"
+        e, s, ps = serial_state(data[:cuts[1]])
+        assert r1[3] == (e, s, ps) and r0[3] == (0, 0, 0)
+        assert r0[4] == 1 and r1[4] in (1, 2)  # rank 0 never launches twice
+        total_reruns += r1[4] - 1
+        if want_code in (0, 13):
+            assert r1[5] == [len(data), len(data), 0]
+    assert res[0][1] == 0 and res[1][1] == total_reruns and total_reruns >= 2  # the refuted-guess cases did re-run
+    assert res[0][2] == res[1][2] == len(cases) + total_reruns  # one all-gather per launch round, on every rank

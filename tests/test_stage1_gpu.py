@@ -554,6 +554,135 @@ def test_sharded_two_ranks_one_gpu(oracle):
         assert np.array_equal(merged, idx[:n].astype(np.int64)), name
 
 
+
+def test_sharded_world8_one_gpu(torch_mod, oracle):
+    """The shape of BASELINE.json config 5 (one stream over 8 ranks) on ONE GPU and in ONE process: eight
+    msj_ctx / msj_sharded pairs driven by eight threads through the library's C entry points
+    (msj_stage1_sharded_submit / _result), with a loopback exchange in place of RCCL (the GPU box admits at most
+    six processes on its card, and RCCL refuses two ranks on one device).  Cuts fall inside strings, right
+    after backslash runs, inside 4-byte characters and inside a run of 70 backslashes; one rank's shard spans
+    two uint32 segments (test hook: 64 KiB segments); several in_string guesses are refuted.  Checked against the
+    oracle on the whole stream: code, total, every index of every shard, the trailer, the UTF-8 verdict."""
+    import threading
+
+    torch = torch_mod
+    from mojo_simdjson_amd import sharded, synth
+    from mojo_simdjson_amd._lib import MsjCarry, MsjSegment
+    from mojo_simdjson_amd.device import Stage1Device
+
+    world = 8
+    u = synth.workload("utf8", 1 << 20).tobytes()
+    parts = [u, b' ["' + b"a" * 3000 + b':",1,2,"zz"] ', synth.workload("minified", 1 << 20).tobytes()]
+    p1 = len(parts[0])
+    p3 = sum(len(x) for x in parts)
+    head3 = b' ["x' + b"\\" * 70 + b'","'
+    pad = b"y" * ((2 - (p3 + len(head3))) % 4)  # the first emoji starts at an offset = 2 mod 4: an aligned cut splits one
+    parts += [head3 + pad + b"\xf0\x9f\x98\x80" * 24 + b'"] ', synth.workload("pretty2", 512 << 10).tobytes()]
+    data = b"".join(parts)
+    total = len(data)
+    code, n, idx = helpers.run_oracle(oracle.msj_oracle_stage1, data)
+    assert code == 0 and oracle.msj_oracle_utf8(data, total) == 0
+
+    def align(x):
+        return x // 16 * 16
+
+    emoji = data.index(b"\xf0\x9f\x98\x80", p3)
+    cut_emoji = align(emoji + 48)
+    assert (cut_emoji - emoji) % 4 == 2 and data[cut_emoji] in (0x98, 0x9F, 0x80)  # inside a 4-byte character
+    cuts = [0, align(p1 // 2), align(p1 + 1600),            # inside the ':"' string: a refuted guess
+            align(p1 + len(parts[1]) + 300000), align(p3 + 48),   # inside the run of 70 backslashes
+            cut_emoji, align(p3 + len(parts[3]) + 100000), align(total - 200000), total]
+    assert len(set(cuts)) == world + 1 and cuts == sorted(cuts)
+    L = sharded.lib()
+    devs = [Stage1Device(0) for _ in range(world)]
+    for d in devs:
+        assert L.msj_debug_set_segment_bytes(d.ctx, 64 << 10) == 0
+    d_data = torch.from_numpy(np.frombuffer(data, dtype=np.uint8).copy()).to(devs[0].device)
+    barrier = threading.Barrier(world)
+    mine_ptrs = [None] * world
+    lock = threading.Lock()
+    L.msj_copy_to_host.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint64, ctypes.c_void_p]
+    L.msj_copy_to_device.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_char_p, ctypes.c_uint64, ctypes.c_void_p]
+    results = [None] * world
+    errors_seen = []
+
+    def rank_main(rank):
+        try:
+            dev = devs[rank]
+            stream = torch.cuda.Stream(device=dev.device)
+            sp = ctypes.c_void_p(stream.cuda_stream)
+
+            def allgather(comm, d_send, d_recv, nbytes, st):
+                # loopback: every rank reads every rank's report straight from device memory (one process)
+                if L.msj_copy_to_host(dev.ctx, (ctypes.c_uint8 * 1)(), ctypes.c_void_p(d_send), 1, ctypes.c_void_p(st)) != 0:
+                    return -3  # (synchronises this rank's stream: its kernel has finished)
+                mine_ptrs[rank] = d_send
+                barrier.wait()
+                blob = b""
+                for g in range(world):
+                    buf = (ctypes.c_uint8 * nbytes)()
+                    if L.msj_copy_to_host(dev.ctx, buf, ctypes.c_void_p(mine_ptrs[g]), nbytes, ctypes.c_void_p(st)) != 0:
+                        return -3
+                    blob += bytes(buf)
+                rc = L.msj_copy_to_device(dev.ctx, ctypes.c_void_p(d_recv), blob, len(blob), ctypes.c_void_p(st))
+                barrier.wait()
+                return 0 if rc == 0 else -3
+
+            cb = sharded.ALLGATHER_FN(allgather)
+            x = sharded.MsjExchange(None, cb, rank, world, 0, 0)
+            h = ctypes.c_void_p()
+            assert L.msj_sharded_create(dev.ctx, ctypes.byref(x), None, ctypes.byref(h)) == 0
+            lo, hi = cuts[rank], cuts[rank + 1]
+            d_shard = d_data[lo:hi]
+            d_idx = torch.full((hi - lo + 3,), -1, dtype=torch.int32, device=dev.device)
+            nseg = -(-(hi - lo) // (64 << 10))
+            d_seg = torch.zeros(nseg * 32, dtype=torch.uint8, device=dev.device)
+            ticket = ctypes.c_uint32()
+            rc = L.msj_stage1_sharded_submit(h, ctypes.c_void_p(d_shard.data_ptr()), hi - lo, ctypes.c_void_p(d_idx.data_ptr()),
+                                             d_idx.numel(), total, int(rank > 0), None, ctypes.c_void_p(d_seg.data_ptr()), nseg,
+                                             sp, 0, ctypes.byref(ticket))
+            assert rc == 0, rc
+            rcode, rtotal = ctypes.c_int32(), ctypes.c_uint64()
+            local, used = MsjCarry(), MsjCarry()
+            rc = L.msj_stage1_sharded_result(h, ticket.value, ctypes.byref(rcode), ctypes.byref(rtotal), ctypes.byref(local),
+                                             ctypes.byref(used))
+            assert rc == 0, rc
+            stream.synchronize()
+            cnt = int(local.count)
+            segs = np.frombuffer(d_seg.cpu().numpy().tobytes(), dtype=np.uint64).reshape(nseg, 4)
+            vals = d_idx[: cnt + (3 if rank == world - 1 else 0)].cpu().numpy().view(np.uint32).astype(np.int64)
+            # indices are relative to their segment's byte_base (msj_segment): back to stream offsets
+            out = vals[:cnt].copy()
+            for base, blen, ibeg, c in segs:
+                out[int(ibeg):int(ibeg) + int(c)] += int(base) + lo
+            results[rank] = (rcode.value, int(rtotal.value), out, vals[cnt:], int(L.msj_sharded_reruns(h)),
+                             int(local.utf8_error), nseg, int(segs[:, 3].sum()) == cnt)
+            L.msj_sharded_destroy(h)
+        except BaseException as exc:  # surface failures of worker threads
+            with lock:
+                errors_seen.append((rank, repr(exc)))
+            try:
+                barrier.abort()
+            except Exception:
+                pass
+
+    threads = [threading.Thread(target=rank_main, args=(r,)) for r in range(world)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(timeout=300)
+    assert not errors_seen, errors_seen
+    assert all(r is not None for r in results)
+    merged = np.concatenate([r[2] for r in results])
+    assert all(r[0] == code and r[1] == n for r in results)
+    assert np.array_equal(merged, idx[:n].astype(np.int64))
+    assert list(results[-1][3]) == [total & 0xFFFFFFFF, total & 0xFFFFFFFF, 0]
+    assert all(r[7] for r in results) and max(r[6] for r in results) >= 2  # segment tables add up; some shard spans segments
+    assert sum(r[4] for r in results) >= 1  # at least one refuted guess was repaired by a re-run
+    assert all(r[5] == 0 for r in results)
+    for d in devs:
+        d.close()
+
 def test_multi_segment_over_4gib(torch_mod, dev, oracle):
     """> 4 GiB in one shard call: chained segments with device-resident carries, offsets
     relative to each segment's byte base (the reference's UInt32
