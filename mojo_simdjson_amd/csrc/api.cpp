@@ -7,22 +7,37 @@
 // point returns MSJ_ERR_NO_DEVICE.
 #include <hip/hip_runtime.h>
 
+#include <atomic>
+#include <chrono>
+#include <cstdlib>
+#include <condition_variable>
 #include <cstdio>
 #include <cstring>
+#include <deque>
+#include <functional>
 #include <mutex>
 #include <new>
+#include <thread>
+#include <vector>
 
 #include "../../include/msj_stage1.h"
 #include "stage1_kernel.h"
 
 // small-input path of msj_stage1: input, result and len + 3 indices fit the pinned staging buffer
 constexpr uint64_t kSmallInput = 64u << 10;
+// from here on msj_stage1 stages through pinned rings in chunks (host_pipeline)
+constexpr uint64_t kPipelineMin = 24u << 20;
 constexpr uint64_t kPinBytes = kSmallInput + 64 + (kSmallInput + 3) * sizeof(uint32_t) + 64;
 
 static_assert(sizeof(msj_carry) == 64, "the small-input staging layout assumes a 64-byte carry");
 
+namespace {
+struct HostPipe;  // pinned rings, streams and copy workers of the host-pointer entry point (below)
+}
+
 struct msj_ctx {
     int device = 0;
+    HostPipe *pipe = nullptr;     // created by the first large msj_stage1 call
     // Two workspace buffers (tickets + descriptors) used alternately.  A launch needs its
     // buffer zeroed; instead of a memset in front of every launch, each launch zeroes the
     // OTHER buffer word for word when that one was dirtied with the same layout (same ntiles).
@@ -105,7 +120,7 @@ int32_t enqueue_shard(msj_ctx *ctx, const uint8_t *d_buf, uint64_t len, uint32_t
                       uint64_t idx_capacity, const msj_carry *d_carry_in, msj_carry *d_carry_out,
                       msj_segment *d_segments, uint32_t max_segments, uint32_t *n_segments_out,
                       bool has_prefix, bool is_final, bool no_emit, uint64_t trailer_len,
-                      hipStream_t stream, uint32_t flags) {
+                      hipStream_t stream, uint32_t flags, uint32_t index_bias = 0) {
     if (!ctx || !d_buf || !d_carry_in || !d_carry_out || len == 0) return MSJ_ERR_BAD_ARGUMENT;
     if ((reinterpret_cast<uintptr_t>(d_buf) & 15u) != 0) return MSJ_ERR_BAD_ARGUMENT;
     if (!no_emit && !d_idx) return MSJ_ERR_BAD_ARGUMENT;
@@ -149,6 +164,7 @@ int32_t enqueue_shard(msj_ctx *ctx, const uint8_t *d_buf, uint64_t len, uint32_t
         if (s == 0) a.flags |= flags & (15u << msj::kFlagSkipShift);
         a.stamps = g_stamps;
         a.wait_ticks = ctx->wait_ticks;
+        a.index_bias = index_bias;
         a.tp = nullptr;
         if (flags & MSJ_FLAG_DEBUG_STALL) a.flags |= msj::kFlagDebugStall;
         if (flags & MSJ_FLAG_TWO_PASS) {
@@ -190,6 +206,281 @@ int32_t enqueue_shard(msj_ctx *ctx, const uint8_t *d_buf, uint64_t len, uint32_t
     if (n_segments_out) *n_segments_out = (uint32_t)nseg;
     return MSJ_SUCCESS;
 }
+
+// ---- host-pointer path for large inputs: library-owned pinned rings, chunked and overlapped -----------------
+// DomParserImplementation.stage1 (include/generic/dom_parser_implementation.mojo:65-69) hands over pageable host
+// memory.  Pageable hipMemcpy is synchronous and its two directions do not overlap on this platform (measured:
+// 31 GB/s of JSON for 268 MB up + 208 MB down), while pinned memory moves 57 GB/s each way at once
+// (scripts/ubench/pcie_probe.cpp).  So: the input goes up in chunks through a ring of pinned buffers, filled by a
+// few copy threads (one thread copies 32 GB/s, four 96 GB/s on the box's host); every chunk is one shard launch
+// with the carry chained in device memory (msj_stage1_shard_device); a second host thread follows the chunks'
+// counts and brings the finished part of the index array down through a second pinned ring while later chunks
+// are still on their way up -- both PCIe directions and the kernel run at the same time.
+struct CopyPool {
+    std::vector<std::thread> threads;
+    std::deque<std::function<void()>> tasks;
+    std::mutex m;
+    std::condition_variable cv;
+    bool stop = false;
+    explicit CopyPool(int n) {
+        for (int i = 0; i < n; i++)
+            threads.emplace_back([this] {
+                for (;;) {
+                    std::function<void()> f;
+                    {
+                        std::unique_lock<std::mutex> lk(m);
+                        cv.wait(lk, [this] { return stop || !tasks.empty(); });
+                        if (stop && tasks.empty()) return;
+                        f = std::move(tasks.front());
+                        tasks.pop_front();
+                    }
+                    f();
+                }
+            });
+    }
+    ~CopyPool() {
+        {
+            std::lock_guard<std::mutex> lk(m);
+            stop = true;
+        }
+        cv.notify_all();
+        for (auto &t : threads) t.join();
+    }
+    // memcpy split over `parts` workers, not waited for: *pending counts the slices still to do
+    void copy_async(void *dst, const void *src, uint64_t n, int parts, std::atomic<int> *pending) {
+        if (parts < 1) parts = 1;
+        pending->store(parts, std::memory_order_relaxed);
+        const uint64_t step = ((n / parts) + 63) & ~63ull;
+        for (int i = 0; i < parts; i++) {
+            const uint64_t lo = step * i < n ? step * i : n, hi = (i + 1 == parts || step * (i + 1) > n) ? n : step * (i + 1);
+            {
+                std::lock_guard<std::mutex> lk(m);
+                tasks.emplace_back([=] {
+                    if (hi > lo) std::memcpy(static_cast<char *>(dst) + lo, static_cast<const char *>(src) + lo, hi - lo);
+                    pending->fetch_sub(1, std::memory_order_release);
+                });
+            }
+            cv.notify_one();
+        }
+    }
+    static void wait(std::atomic<int> *pending) {
+        while (pending->load(std::memory_order_acquire) != 0) std::this_thread::yield();
+    }
+    // memcpy split over `parts` workers; returns when all of it is done
+    void copy(void *dst, const void *src, uint64_t n, int parts) {
+        if (n < (1u << 20) || parts <= 1) {
+            std::memcpy(dst, src, n);
+            return;
+        }
+        std::mutex dm;
+        std::condition_variable dcv;
+        int left = parts;
+        const uint64_t step = ((n / parts) + 63) & ~63ull;
+        for (int i = 0; i < parts; i++) {
+            const uint64_t lo = step * i < n ? step * i : n, hi = (i + 1 == parts || step * (i + 1) > n) ? n : step * (i + 1);
+            {
+                std::lock_guard<std::mutex> lk(m);
+                tasks.emplace_back([=, &dm, &dcv, &left] {
+                    if (hi > lo) std::memcpy(static_cast<char *>(dst) + lo, static_cast<const char *>(src) + lo, hi - lo);
+                    std::lock_guard<std::mutex> g(dm);
+                    if (--left == 0) dcv.notify_one();
+                });
+            }
+            cv.notify_one();
+        }
+        std::unique_lock<std::mutex> lk(dm);
+        dcv.wait(lk, [&] { return left == 0; });
+    }
+};
+
+struct HostPipe {
+    static constexpr int kInSlots = 3, kOutSlots = 2;
+    static int env_int(const char *name, int dflt) {
+        const char *v = std::getenv(name);
+        return v && *v ? std::atoi(v) : dflt;
+    }
+    // copy workers and slices per staging copy (tuning knobs; defaults measured on the MI355X box's host)
+    const int kCopyThreads = env_int("MSJ_PIPE_THREADS", 8), kParts = env_int("MSJ_PIPE_PARTS", 4);
+    const bool direct_upload = env_int("MSJ_PIPE_DIRECT_UPLOAD", 0) != 0;
+    static constexpr uint64_t kChunk = 16ull << 20;  // input bytes per chunk (a multiple of the tile)
+    static constexpr uint64_t kPiece = 16ull << 20;  // index bytes per download piece
+    uint8_t *pin_in[kInSlots] = {nullptr, nullptr, nullptr};
+    uint8_t *pin_out[kOutSlots] = {nullptr, nullptr};
+    msj_carry *h_carries = nullptr;  // pinned: the carry after every chunk
+    msj_carry *d_carries = nullptr;
+    uint64_t n_carries = 0;
+    hipStream_t s_up = nullptr, s_k = nullptr, s_down = nullptr;
+    hipEvent_t ev_in[kInSlots] = {nullptr, nullptr, nullptr};
+    hipEvent_t ev_out[kOutSlots] = {nullptr, nullptr};
+    std::vector<hipEvent_t> ev_chunk;
+    CopyPool pool{kCopyThreads};
+    bool ok = false;
+
+    HostPipe() {
+        ok = true;
+        for (auto &p : pin_in) ok = ok && hip_ok(hipHostMalloc(reinterpret_cast<void **>(&p), kChunk, hipHostMallocDefault));
+        for (auto &p : pin_out) ok = ok && hip_ok(hipHostMalloc(reinterpret_cast<void **>(&p), kPiece, hipHostMallocDefault));
+        ok = ok && hip_ok(hipStreamCreateWithFlags(&s_up, hipStreamNonBlocking)) &&
+             hip_ok(hipStreamCreateWithFlags(&s_k, hipStreamNonBlocking)) &&
+             hip_ok(hipStreamCreateWithFlags(&s_down, hipStreamNonBlocking));
+        for (auto &e : ev_in) ok = ok && hip_ok(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        for (auto &e : ev_out) ok = ok && hip_ok(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    }
+    ~HostPipe() {
+        for (auto p : pin_in)
+            if (p) (void)hipHostFree(p);
+        for (auto p : pin_out)
+            if (p) (void)hipHostFree(p);
+        if (h_carries) (void)hipHostFree(h_carries);
+        if (d_carries) (void)hipFree(d_carries);
+        for (auto e : ev_in)
+            if (e) (void)hipEventDestroy(e);
+        for (auto e : ev_out)
+            if (e) (void)hipEventDestroy(e);
+        for (auto e : ev_chunk) (void)hipEventDestroy(e);
+        if (s_up) (void)hipStreamDestroy(s_up);
+        if (s_k) (void)hipStreamDestroy(s_k);
+        if (s_down) (void)hipStreamDestroy(s_down);
+    }
+    bool reserve(uint64_t nchunks) {
+        if (nchunks + 1 > n_carries) {
+            if (h_carries) (void)hipHostFree(h_carries);
+            if (d_carries) (void)hipFree(d_carries);
+            h_carries = nullptr;
+            d_carries = nullptr;
+            n_carries = 0;
+            if (!hip_ok(hipHostMalloc(reinterpret_cast<void **>(&h_carries), (nchunks + 1) * sizeof(msj_carry), hipHostMallocDefault)) ||
+                !hip_ok(hipMalloc(reinterpret_cast<void **>(&d_carries), (nchunks + 1) * sizeof(msj_carry))))
+                return false;
+            n_carries = nchunks + 1;
+        }
+        while (ev_chunk.size() < nchunks) {
+            hipEvent_t e;
+            if (!hip_ok(hipEventCreateWithFlags(&e, hipEventDisableTiming))) return false;
+            ev_chunk.push_back(e);
+        }
+        return true;
+    }
+};
+
+// The pipelined form of msj_stage1_ctx's device staging.  Returns MSJ_ERR_HIP when anything of the machinery
+// fails (the caller then takes the plain path); otherwise fills *res with the final carry.
+int32_t host_pipeline(msj_ctx *ctx, const uint8_t *buf, uint64_t len, uint32_t *idx_out, uint64_t dev_cap, uint32_t flags,
+                      msj_carry *res) {
+    if (!ctx->pipe) {
+        ctx->pipe = new (std::nothrow) HostPipe();
+        if (!ctx->pipe) return MSJ_MEMALLOC;
+    }
+    HostPipe &P = *ctx->pipe;
+    if (!P.ok) return MSJ_ERR_HIP;
+    const uint64_t chunk = HostPipe::kChunk;
+    const uint64_t nchunks = (len + chunk - 1) / chunk;
+    if (!P.reserve(nchunks)) return MSJ_MEMALLOC;
+    if (!hip_ok(hipMemsetAsync(&P.d_carries[0], 0, sizeof(msj_carry), P.s_k))) return MSJ_ERR_HIP;
+
+    static const bool trace = std::getenv("MSJ_PIPE_TRACE") != nullptr;  // diagnostics: where the call's time goes
+    auto now = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    const double t_begin = now();
+    std::vector<double> t_chunk_done(nchunks, 0.0), t_piece;
+    // ---- the downloader: follows the chunks' cumulative counts, brings finished indices down in pieces
+    int32_t down_rc = MSJ_SUCCESS;
+    std::atomic<bool> abort{false};
+    std::atomic<uint64_t> recorded{0};  // chunks whose event the uploader has recorded (an unrecorded event reads as done)
+    std::thread down([&] {
+        (void)hipSetDevice(ctx->device);
+        uint64_t sent = 0, pieces = 0;
+        std::atomic<int> copying[HostPipe::kOutSlots];
+        for (auto &c : copying) c.store(0);
+        for (uint64_t k = 0; k < nchunks; k++) {
+            while (recorded.load(std::memory_order_acquire) <= k && !abort.load()) std::this_thread::yield();
+            if (abort.load()) break;
+            if (!hip_ok(hipEventSynchronize(P.ev_chunk[k]))) { down_rc = MSJ_ERR_HIP; break; }
+            if (abort.load()) break;
+            if (trace) t_chunk_done[k] = now() - t_begin;
+            const msj_carry &c = P.h_carries[k + 1];
+            const bool last = k + 1 == nchunks;
+            uint64_t avail = c.count;
+            if (last && (c.code == MSJ_SUCCESS || c.code == MSJ_EMPTY || c.code == MSJ_UTF8_ERROR)) avail += 3;  // the trailer
+            if (avail > dev_cap) avail = dev_cap;
+            const uint64_t piece = HostPipe::kPiece / sizeof(uint32_t);
+            while (avail - sent >= piece || (last && sent < avail)) {
+                const uint64_t n = avail - sent < piece ? avail - sent : piece;
+                const int slot = (int)(pieces % HostPipe::kOutSlots);
+                CopyPool::wait(&copying[slot]);  // the piece that used this slot has been copied out
+                // the DMA into the pinned slot (this call returns when it is done), then the copy into the
+                // caller's memory by the pool while the next piece's DMA runs
+                if (!hip_ok(hipMemcpyAsync(P.pin_out[slot], ctx->d_idx + sent, n * sizeof(uint32_t), hipMemcpyDeviceToHost, P.s_down)) ||
+                    !hip_ok(hipStreamSynchronize(P.s_down))) {
+                    down_rc = MSJ_ERR_HIP;
+                    break;
+                }
+                P.pool.copy_async(idx_out + sent, P.pin_out[slot], n * sizeof(uint32_t), P.kParts, &copying[slot]);
+                sent += n;
+                pieces++;
+                if (trace) t_piece.push_back(now() - t_begin);
+            }
+            if (down_rc != MSJ_SUCCESS) break;
+        }
+        for (auto &c : copying) CopyPool::wait(&c);
+    });
+
+    // ---- the uploader (this thread): pinned staging, H2D, one shard launch per chunk
+    double t_copy = 0, t_wait = 0;
+    int32_t rc = MSJ_SUCCESS;
+    for (uint64_t k = 0; k < nchunks && rc == MSJ_SUCCESS; k++) {
+        const uint64_t off = k * chunk, n = len - off < chunk ? len - off : chunk;
+        const int slot = (int)(k % HostPipe::kInSlots);
+        double t0 = now();
+        if (P.direct_upload) {
+            // the runtime's own pageable copy (it pins the pages in flight): no staging copy of ours
+            if (!hip_ok(hipMemcpyAsync(ctx->d_in + off, buf + off, n, hipMemcpyHostToDevice, P.s_up))) rc = MSJ_ERR_HIP;
+            t_copy += now() - t0;
+        } else {
+            if (k >= (uint64_t)HostPipe::kInSlots && !hip_ok(hipEventSynchronize(P.ev_in[slot]))) rc = MSJ_ERR_HIP;
+            double t1 = now();
+            if (rc == MSJ_SUCCESS) P.pool.copy(P.pin_in[slot], buf + off, n, P.kParts);
+            t_wait += t1 - t0;
+            t_copy += now() - t1;
+            if (rc == MSJ_SUCCESS && !hip_ok(hipMemcpyAsync(ctx->d_in + off, P.pin_in[slot], n, hipMemcpyHostToDevice, P.s_up)))
+                rc = MSJ_ERR_HIP;
+        }
+        if (rc == MSJ_SUCCESS && (!hip_ok(hipEventRecord(P.ev_in[slot], P.s_up)) || !hip_ok(hipStreamWaitEvent(P.s_k, P.ev_in[slot], 0))))
+            rc = MSJ_ERR_HIP;
+        if (rc == MSJ_SUCCESS)
+            rc = enqueue_shard(ctx, ctx->d_in + off, n, ctx->d_idx, dev_cap, &P.d_carries[k], &P.d_carries[k + 1], nullptr, 0, nullptr,
+                               k > 0, k + 1 == nchunks, false, len, P.s_k, flags, (uint32_t)off);
+        if (rc == MSJ_SUCCESS &&
+            (!hip_ok(hipMemcpyAsync(&P.h_carries[k + 1], &P.d_carries[k + 1], sizeof(msj_carry), hipMemcpyDeviceToHost, P.s_k)) ||
+             !hip_ok(hipEventRecord(P.ev_chunk[k], P.s_k))))
+            rc = MSJ_ERR_HIP;
+        if (rc == MSJ_SUCCESS) recorded.store(k + 1, std::memory_order_release);
+        if (rc != MSJ_SUCCESS) {
+            // the downloader waits on every chunk's event: record the rest so that it can leave
+            abort.store(true);
+            for (uint64_t j = k; j < nchunks; j++) (void)hipEventRecord(P.ev_chunk[j], P.s_k);
+        }
+    }
+    const double t_up = now();
+    down.join();
+    (void)hipStreamSynchronize(P.s_k);
+    if (trace)
+        std::fprintf(stderr, "msj host pipeline: %llu chunks, upload loop %.2f ms (slot waits %.2f, staging copies %.2f), "
+                             "then %.2f ms until the last index was down\n",
+                     (unsigned long long)nchunks, t_up - t_begin, t_wait, t_copy, now() - t_up);
+    if (trace) {
+        std::fprintf(stderr, "  chunk results seen at (ms):");
+        for (double t : t_chunk_done) std::fprintf(stderr, " %.2f", t);
+        std::fprintf(stderr, "\n  download pieces issued+previous copied out at (ms):");
+        for (double t : t_piece) std::fprintf(stderr, " %.2f", t);
+        std::fprintf(stderr, "\n");
+    }
+    ctx->last.valid = false;  // the chunk launches are not one call that msj_carry_fetch could re-issue
+    if (rc != MSJ_SUCCESS) return rc;
+    if (down_rc != MSJ_SUCCESS) return down_rc;
+    *res = P.h_carries[nchunks];
+    return MSJ_SUCCESS;
+}
+
 
 std::mutex g_default_mutex;
 msj_ctx *g_default_ctx = nullptr;
@@ -251,6 +542,7 @@ void msj_ctx_destroy(msj_ctx *ctx) {
     if (ctx->d_in) (void)hipFree(ctx->d_in);
     if (ctx->d_idx) (void)hipFree(ctx->d_idx);
     if (ctx->d_result) (void)hipFree(ctx->d_result);
+    delete ctx->pipe;
     if (ctx->h_pin) (void)hipHostFree(ctx->h_pin);
     if (ctx->d_small) (void)hipFree(ctx->d_small);
     delete ctx;
@@ -522,13 +814,26 @@ int32_t msj_stage1_ctx(msj_ctx *ctx, const uint8_t *buf, uint64_t len, uint32_t 
             return MSJ_MEMALLOC;
         ctx->d_idx_words = dev_cap;
     }
-    if (!hip_ok(hipMemcpy(ctx->d_in, buf, len, hipMemcpyHostToDevice))) return MSJ_ERR_HIP;
-    int32_t rc = msj_stage1_device(ctx, ctx->d_in, len, ctx->d_idx, dev_cap, ctx->d_result, nullptr,
-                                   flags);
-    if (rc != MSJ_SUCCESS) return rc;
     msj_carry res;
-    rc = msj_carry_fetch(ctx, ctx->d_result, &res, nullptr);
-    if (rc != MSJ_SUCCESS) return rc;
+    int32_t rc;
+    static const bool pipe_off = std::getenv("MSJ_PIPE_DISABLE") != nullptr;  // measurement aid: the plain staging path
+    const bool piped = len >= kPipelineMin && !(flags & MSJ_FLAG_TWO_PASS) && !pipe_off;
+    if (piped) {
+        // large inputs: pinned rings, chunks, both PCIe directions and the kernel at once
+        rc = host_pipeline(ctx, buf, len, idx_out, dev_cap, flags, &res);
+        if (rc != MSJ_SUCCESS) return rc;
+        if (res.internal_error) {  // an expired wait somewhere in the chain: once more, two-pass, plain staging
+            ctx->fallbacks++;
+            ctx->ws_dirty[0] = ctx->ws_dirty[1] = kAllDirty;
+            return msj_stage1_ctx(ctx, buf, len, idx_out, idx_capacity, n_out, utf8_verdict_out, flags | MSJ_FLAG_TWO_PASS);
+        }
+    } else {
+        if (!hip_ok(hipMemcpy(ctx->d_in, buf, len, hipMemcpyHostToDevice))) return MSJ_ERR_HIP;
+        rc = msj_stage1_device(ctx, ctx->d_in, len, ctx->d_idx, dev_cap, ctx->d_result, nullptr, flags);
+        if (rc != MSJ_SUCCESS) return rc;
+        rc = msj_carry_fetch(ctx, ctx->d_result, &res, nullptr);
+        if (rc != MSJ_SUCCESS) return rc;
+    }
     if (utf8_verdict_out) *utf8_verdict_out = res.utf8_error ? MSJ_UTF8_ERROR : MSJ_SUCCESS;
     // On UNCLOSED_STRING / UNESCAPED_CHARS the reference returns before it sets
     // n_structural_indexes or the trailer (json_structural_indexer.mojo:151-158).
@@ -536,8 +841,8 @@ int32_t msj_stage1_ctx(msj_ctx *ctx, const uint8_t *buf, uint64_t len, uint32_t 
         res.code == MSJ_UNEXPECTED_ERROR || res.code == MSJ_CAPACITY)
         return res.code;
     const uint64_t n = res.count;
-    if (!hip_ok(hipMemcpy(idx_out, ctx->d_idx, (n + 3) * sizeof(uint32_t), hipMemcpyDeviceToHost)))
-        return MSJ_ERR_HIP;
+    if (!piped && !hip_ok(hipMemcpy(idx_out, ctx->d_idx, (n + 3) * sizeof(uint32_t), hipMemcpyDeviceToHost)))
+        return MSJ_ERR_HIP;  // (the pipeline has brought the indices and the trailer down already)
     *n_out = n;
     return res.code;
 }

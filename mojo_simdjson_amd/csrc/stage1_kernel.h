@@ -51,6 +51,8 @@ struct KernelArgs {
     uint64_t trailer_len;     // value of the two `len` trailer words (FINAL only)
     uint32_t ntiles;
     uint32_t flags;
+    uint32_t index_bias;      // added to every index: byte offset of this launch's buffer inside the document
+                              // (host-pointer pipeline: one launch per uploaded chunk, offsets stay absolute)
     uint32_t wait_ticks;      // bound of every wait in the kernel, in s_memrealtime ticks (10 ns); expiry poisons the launch
     uint64_t *stamps;         // diagnostic builds only (-DMSJ_STAMPS): 16 words per tile, else null
     uint64_t *tp;             // two-pass path only: 2 * ntiles words (tile aggregates, tile prefixes)

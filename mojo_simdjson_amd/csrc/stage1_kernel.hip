@@ -575,6 +575,7 @@ enum : uint32_t { kEmitNone = 0, kEmitStaged, kEmitStaged16, kEmitRounds, kEmitG
 struct EmitU {
     uint32_t mode;
     uint32_t tile;
+    uint32_t tile_base;    // value of the tile's first byte: tile * 4096 (+ the launch's index bias)
     uint32_t s_in;         // the tile's incoming in-string state
     uint32_t shift, vend;  // stage[j] <-> idx[base - shift + j] for j in [shift, vend)
     uint64_t base;         // index of the tile's first structural in the output
@@ -594,7 +595,9 @@ __device__ __forceinline__ EmitU emit_prepare(const KernelArgs &a, const Shared 
     e.base = 0;
     const uint4 meta = *reinterpret_cast<const uint4 *>(sh.pend_meta[wave][slot]);  // tile, tile_cnt, in_cnt, in_s
     e.tile = uniform32(meta.x);
+    e.tile_base = 0;
     if (e.tile == 0xFFFFFFFFu) return e;
+    e.tile_base = e.tile * kTileBytes + a.index_bias;  // < 2^32 per document
     const uint32_t tile_cnt = uniform32(meta.y);
     const uint32_t in_cnt = uniform32(meta.z);
     const uint32_t in_s = uniform32(meta.w);
@@ -635,7 +638,7 @@ __device__ __forceinline__ EmitV emit_lane(const Shared &sh, const uint32_t wave
 
 __device__ __forceinline__ void stage_indices(const EmitU &e, const EmitV &v, uint32_t *stage, const uint32_t lane64) {
     // the block offset is a multiple of 64, so value_base | bit == value_base + bit
-    const uint32_t v0 = e.tile * kTileBytes + lane64;  // < 2^32 per launch
+    const uint32_t v0 = e.tile_base + lane64;
     const uint32_t lds0 = (uint32_t)(uintptr_t)(stage + v.vpos);  // LDS byte address
     const uint32_t nlo = (uint32_t)__builtin_popcount(v.tlo), nhi = (uint32_t)__builtin_popcount(v.thi);
     scatter_bits32(v.tlo, lds0, nlo, v0);
@@ -682,7 +685,7 @@ __device__ __forceinline__ void copy_out16(const KernelArgs &a, const EmitU &e, 
                                            const uint32_t lane) {
     const uint16_t *stage16 = reinterpret_cast<const uint16_t *>(stage);
     uint32_t *out = a.idx + (e.base - e.shift);     // out[v] <-> stage16[v]; 16-byte aligned
-    const uint32_t tb = e.tile * kTileBytes;          // < 2^32 per launch
+    const uint32_t tb = e.tile_base;
     const uint32_t q_lo = (e.shift + 3u) >> 2, q_hi = e.vend >> 2;
     for (uint32_t q = q_lo + lane; q < q_hi; q += 64u) {
         const uint2 h = *reinterpret_cast<const uint2 *>(stage16 + 4u * q);
@@ -712,10 +715,10 @@ __device__ __forceinline__ void lds_wave_sync() {
 // starts inside the window fits the slice); lanes are ordered by position, so a round is a
 // contiguous group of lanes and its indices a contiguous piece of the output.
 constexpr uint32_t kRoundSlots = kStageWords - 64u;
-__device__ __noinline__ void emit_rounds(uint32_t *idx, const uint32_t tile, const uint64_t base, const uint32_t shift,
+__device__ __noinline__ void emit_rounds(uint32_t *idx, const uint32_t tile_base, const uint64_t base, const uint32_t shift,
                                          const uint32_t vend, const uint32_t tlo, const uint32_t thi,
                                          const uint32_t vpos, uint32_t *stage, const uint32_t lane) {
-    const uint32_t v0 = tile * kTileBytes + lane * 64u;
+    const uint32_t v0 = tile_base + lane * 64u;
     uint32_t *out = idx + (base - shift);  // out[v] <-> slot v of the tile; 16-byte aligned
     const uint32_t nlo = (uint32_t)__builtin_popcount(tlo), nhi = (uint32_t)__builtin_popcount(thi);
     uint32_t v_begin = shift;
@@ -745,11 +748,11 @@ __device__ __noinline__ void emit_rounds(uint32_t *idx, const uint32_t tile, con
 }
 
 // An index buffer that is too small (the launch reports CAPACITY): element-wise, clipped.
-__device__ __noinline__ void emit_general(uint32_t *idx, const uint64_t capacity, const uint32_t tile,
+__device__ __noinline__ void emit_general(uint32_t *idx, const uint64_t capacity, const uint32_t tile_base,
                                           const uint64_t base, const uint32_t shift, const uint32_t vend,
                                           uint32_t tlo, uint32_t thi, uint32_t vpos, uint32_t *stage,
                                           const uint32_t lane) {
-    const uint32_t v0 = tile * kTileBytes + lane * 64u;
+    const uint32_t v0 = tile_base + lane * 64u;
     for (uint32_t r0 = 0; r0 < vend; r0 += kStageWords) {
         const uint32_t r1 = r0 + kStageWords;
         while (tlo && vpos < r1) {
@@ -825,10 +828,10 @@ __device__ __forceinline__ void emit_store(const KernelArgs &a, const Shared &sh
         copy_out16(a, e, stage, lane);
     } else if (e.mode == kEmitRounds) {
         const EmitV v = emit_lane(sh, wave, slot, lane, e);
-        emit_rounds(a.idx, e.tile, e.base, e.shift, e.vend, v.tlo, v.thi, v.vpos, stage, lane);
+        emit_rounds(a.idx, e.tile_base, e.base, e.shift, e.vend, v.tlo, v.thi, v.vpos, stage, lane);
     } else if (e.mode == kEmitGeneral) {
         const EmitV v = emit_lane(sh, wave, slot, lane, e);
-        emit_general(a.idx, a.capacity, e.tile, e.base, e.shift, e.vend, v.tlo, v.thi, v.vpos, stage, lane);
+        emit_general(a.idx, a.capacity, e.tile_base, e.base, e.shift, e.vend, v.tlo, v.thi, v.vpos, stage, lane);
     }
 }
 
