@@ -320,8 +320,10 @@ int32_t msj_tokens_device(msj_ctx *ctx, const uint8_t *d_buf, uint64_t len, cons
  * stream): for a string token the offset of its closing quote and whether the body holds a backslash
  * (the scan parse_string does first, generic/stage2/string_parsing.mojo:334-386); for a number token the
  * offset one past its last character and whether it is written as a float (number_parsing.mojo:22-80).
- *   d_end[i]:   string: offset of the closing quote (len if never closed); number: offset after the
- *               last of [0-9+-.eE] (0 if longer than 1024 characters); 0 for every other token
+ *   d_end[i]:   string: offset of the closing quote (len if never closed); number: the end parse_number's scan finds
+ *               (number_parsing.mojo:41-59: '-'? digits, then . e E makes it a float that ends at the first
+ *               structural or blank byte; bytes past the buffer read as blanks); 0 if longer than 1024 characters;
+ *               0 for every other token
  *   d_flags[i]: MSJ_SPAN_* bits
  */
 #define MSJ_SPAN_STRING 1u   /* the token opens a string */
@@ -329,6 +331,8 @@ int32_t msj_tokens_device(msj_ctx *ctx, const uint8_t *d_buf, uint64_t len, cons
 #define MSJ_SPAN_NUMBER 4u   /* the token starts a number */
 #define MSJ_SPAN_FLOAT 8u    /* ... written with '.', 'e' or 'E' */
 #define MSJ_SPAN_OPEN 16u    /* string not closed before the end of the buffer (d_end = len) */
+#define MSJ_SPAN_BAD 32u     /* number: the byte behind its digits is neither . e E nor structural / blank: the
+                                reference's parse_number returns NUMBER_ERROR here (number_parsing.mojo:56-57) */
 #define MSJ_SPAN_LONG 128u   /* string body over 1024 bytes: backslash flag not computed; number over 1024: not scanned */
 int32_t msj_token_spans_device(msj_ctx *ctx, const uint8_t *d_buf, uint64_t len, const uint32_t *d_idx, uint64_t n,
                                uint32_t *d_end, uint8_t *d_flags, void *stream);

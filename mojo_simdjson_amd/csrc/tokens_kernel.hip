@@ -607,6 +607,11 @@ __device__ __forceinline__ uint64_t load8(const uint8_t *p) {
     return ((uint64_t)w.y << 32) | w.x;
 }
 __device__ __forceinline__ bool is_blank(uint32_t b) { return b == 0x20u || b == 0x09u || b == 0x0Au || b == 0x0Du; }
+__device__ __forceinline__ bool is_digit(uint32_t b) { return b - 0x30u < 10u; }
+// the reference's structural_or_whitespace table (internal/jsoncharutils_tables.mojo:5-16): 09 0A 0D 20 , : [ ] { }
+__device__ __forceinline__ bool is_sow(uint32_t b) {
+    return is_blank(b) || b == ',' || b == ':' || b == '[' || b == ']' || b == '{' || b == '}';
+}
 
 // where the bytes come from: global memory, or the workgroup's stretch of the buffer staged in LDS
 struct FromGlobal {
@@ -669,47 +674,26 @@ __device__ __forceinline__ void span_of(const Src &src, uint64_t start, uint64_t
         }
         e = closed ? (uint32_t)(q - 1) : (uint32_t)len;
     } else if (c == '-' || (c >= '0' && c <= '9')) {
+        // parse_number's scan, include/generic/number_parsing.mojo:41-59: an optional '-', digits, then either
+        // one of . e E (a float: it ends at the first structural or blank byte), a structural or blank byte (an
+        // integer ends here), or anything else (the reference returns NUMBER_ERROR).  Bytes past the buffer read
+        // as blanks.  (The rare path: stretches too long for LDS; byte by byte.)
         f = MSJ_SPAN_NUMBER;
-        // the four aligned words that hold the next 25..32 bytes, requested together (numbers are short:
-        // no chain of dependent loads); bytes past the buffer read as blanks = the number ends there
-        const uint64_t w0 = start & ~7ull;
-        uint64_t W[4];
-#pragma unroll
-        for (int k = 0; k < 4; k++) W[k] = src.word(w0 + 8u * k);
-        bool done = false;
-        uint64_t j = start + 1;
-#pragma unroll
-        for (int k = 0; k < 4; k++) {
-#pragma unroll
-            for (int b = 0; b < 8; b++) {
-                const uint64_t pos = w0 + 8u * k + b;
-                if (!done && pos == j) {
-                    const uint32_t ch = (uint32_t)(W[k] >> (8 * b)) & 0xFFu;
-                    if (ch == '.' || ch == 'e' || ch == 'E') {
-                        f |= MSJ_SPAN_FLOAT;
-                        j++;
-                    } else if ((ch >= '0' && ch <= '9') || ch == '+' || ch == '-') {
-                        j++;
-                    } else {
-                        done = true;
-                    }
-                }
+        const uint64_t stop = (start + 1 + kSpanCap < len) ? start + 1 + kSpanCap : len;
+        uint64_t j = start + (c == '-' ? 1u : 0u);
+        while (j < stop && is_digit(src.byte(j))) j++;
+        const uint32_t ch = j < len ? src.byte(j) : 0x20u;
+        if (j < stop || j == len) {
+            if (ch == '.' || ch == 'e' || ch == 'E') {
+                f |= MSJ_SPAN_FLOAT;
+                while (j < stop && !is_sow(src.byte(j))) j++;
+            } else if (!is_sow(ch)) {
+                f |= MSJ_SPAN_BAD;
             }
         }
-        if (j > len) j = len;
-        if (!done && j < len) {  // longer than the four words: byte by byte (never past the next structural)
-            const uint64_t stop = (start + 1 + kSpanCap < len) ? start + 1 + kSpanCap : len;
-            for (; j < stop; j++) {
-                const uint32_t b = src.byte(j);
-                if (b == '.' || b == 'e' || b == 'E')
-                    f |= MSJ_SPAN_FLOAT;
-                else if (!((b >= '0' && b <= '9') || b == '+' || b == '-'))
-                    break;
-            }
-            if (j == stop && stop < len) {
-                f |= MSJ_SPAN_LONG;
-                j = 0;
-            }
+        if (j == stop && stop < len) {  // kSpanCap characters and still no end
+            f = (f & ~MSJ_SPAN_BAD) | MSJ_SPAN_LONG;
+            j = 0;
         }
         e = (uint32_t)j;
     }
@@ -718,9 +702,9 @@ __device__ __forceinline__ void span_of(const Src &src, uint64_t start, uint64_t
 // One thread per structural, kSpanTokens per workgroup.  The workgroup's tokens cover one contiguous
 // stretch of the buffer, [idx[first], idx[first of the next workgroup]].  It is staged in LDS with
 // coalesced 16-byte reads, and while a thread holds its 16 bytes it classifies them ONCE: one bit per
-// byte for "can be part of a number" ([0-9+-.eE]), "makes it a float" ([.eE]) and "backslash".  A
-// token then needs a handful of LDS reads: the end of a number is the first clear bit behind its
-// start, its float flag and a string's escape flag are "any bit set in a range".  Work per byte
+// byte for "digit", "structural or blank" (the reference's table, where a float ends), "backslash" and "not
+// blank".  A token then needs a handful of LDS reads: the digits of a number end at the first clear "digit"
+// bit, a float at the next set "structural or blank" bit, a string's escape flag is "any bit set in a range".  Work per byte
 // instead of work per token times its length.  A stretch over kSpanLds bytes (long strings) takes
 // the per-token path from global memory (span_of) instead.
 constexpr uint32_t kSpanThreads = 256;
@@ -804,11 +788,13 @@ __device__ __forceinline__ void staged_token(const uint8_t *stage, const uint32_
         }
         e = closed ? (uint32_t)(lo + (q - 1)) : (uint32_t)len;
     } else if (c == '-' || (c >= '0' && c <= '9')) {
+        // parse_number's scan (include/generic/number_parsing.mojo:41-59) on the bitmaps: optional '-', digits
+        // up to the first clear "digit" bit; then . e E -> float, ends at the next "structural or blank" bit;
+        // a structural or blank byte -> integer, ends here; anything else -> the reference's NUMBER_ERROR.
+        // Everything up to the next structural is staged; past the end of the buffer (rlen) reads as blank.
         f = MSJ_SPAN_NUMBER;
-        // the first byte behind the start that cannot be part of a number = the first clear bit: always
-        // at or before the next structural, which is staged -- except at the end of the buffer (rlen)
         const uint32_t stop = (rs + 1 + kSpanCap < rlen) ? rs + 1 + kSpanCap : rlen;
-        uint32_t p = rs + 1;
+        uint32_t p = rs + (c == '-' ? 1u : 0u);
         while (p < stop) {
             const uint32_t run = ~bits_at(m_num, p);
             if (run) {
@@ -818,9 +804,25 @@ __device__ __forceinline__ void staged_token(const uint8_t *stage, const uint32_
             p += 32;
         }
         if (p > stop) p = stop;
-        if (p > rs + 1 && any_bits(m_flt, rs + 1, p)) f |= MSJ_SPAN_FLOAT;
+        if (p < stop || lo + p == len) {
+            const uint32_t ch = p < rlen ? stage[p] : 0x20u;
+            if (ch == '.' || ch == 'e' || ch == 'E') {
+                f |= MSJ_SPAN_FLOAT;
+                while (p < stop) {
+                    const uint32_t hit = bits_at(m_flt, p);
+                    if (hit) {
+                        p += __ffs(hit) - 1u;
+                        break;
+                    }
+                    p += 32;
+                }
+                if (p > stop) p = stop;
+            } else if (p < rlen && !((bits_at(m_flt, p)) & 1u)) {
+                f |= MSJ_SPAN_BAD;
+            }
+        }
         if (p == stop && lo + stop < len)  // kSpanCap characters and still no end
-            f |= MSJ_SPAN_LONG;
+            f = (f & ~MSJ_SPAN_BAD) | MSJ_SPAN_LONG;
         else
             e = (uint32_t)(lo + p);
     }
@@ -886,12 +888,14 @@ __global__ __launch_bounds__(kSpanThreads) void token_spans(const uint8_t *__res
 #pragma unroll
         for (int k = 0; k < 4; k++) {
             const uint32_t x = w[k];
-            const uint32_t fl = eq_bytes(x, '.') | eq_bytes(x | 0x20202020u, 'e');
-            const uint32_t nu = fl | digit_bytes(x) | eq_bytes(x, '+') | eq_bytes(x, '-');
+            const uint32_t blank = eq_bytes(x, 0x20) | eq_bytes(x, 0x0A) | eq_bytes(x, 0x0D) | eq_bytes(x, 0x09);
+            // structural or blank: , :  and  [ ] { }  (5B 5D 7B 7D = 5B / 5D with bit 5 free)
+            const uint32_t fl = blank | eq_bytes(x, ',') | eq_bytes(x, ':') | eq_bytes(x & 0xDFDFDFDFu, '[') | eq_bytes(x & 0xDFDFDFDFu, ']');
+            const uint32_t nu = digit_bytes(x);
             num |= nibble_of(nu) << (4 * k);
             flt |= nibble_of(fl) << (4 * k);
             bs |= nibble_of(eq_bytes(x, '\\')) << (4 * k);
-            ink |= nibble_of(~(eq_bytes(x, 0x20) | eq_bytes(x, 0x0A) | eq_bytes(x, 0x0D) | eq_bytes(x, 0x09))) << (4 * k);
+            ink |= nibble_of(~blank) << (4 * k);
         }
         reinterpret_cast<uint16_t *>(m_num)[o >> 4] = (uint16_t)num;
         reinterpret_cast<uint16_t *>(m_flt)[o >> 4] = (uint16_t)flt;

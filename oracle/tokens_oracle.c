@@ -73,9 +73,91 @@ int msj_oracle_match(const uint8_t *type, uint64_t n, uint32_t *match) {
 /* Token spans (rows f2 / f4), the plain statement: scan forward from the opening quote like
  * parse_string does (generic/stage2/string_parsing.mojo:334-386) -- the first quote that is not behind a
  * backslash closes the string, any backslash on the way sets the flag; walk over the characters
- * parse_number accepts (include/generic/number_parsing.mojo:22-80).  (The HIP kernel finds the closing
+ * parse_number's scan takes (include/generic/number_parsing.mojo:41-59, restated in the number branch
+ * below and, without the cap, in msj_ref_parse_number_scan).  (The HIP kernel finds the closing
  * quote from the NEXT structural instead; the tests check that this is the same thing.)
  * Bodies over 1024 bytes: end still reported, backslash flag not (LONG); numbers over 1024: LONG, end 0. */
+/* structural_or_whitespace, internal/jsoncharutils_tables.mojo:5-16: 09 0A 0D 20 , : [ ] { } */
+static int msj_ref_structural_or_whitespace(uint8_t c) {
+    return c == 0x09 || c == 0x0A || c == 0x0D || c == 0x20 || c == ',' || c == ':' || c == '[' || c == ']' || c == '{' || c == '}';
+}
+
+/*
+ * parse_number (include/generic/number_parsing.mojo:22-80) up to the point where it hands the text to the
+ * standard library: returns 9 (NUMBER_ERROR, :56-57) or 0, *end = offset one past the number's text, *is_float.
+ * Literal: no cap, reads buf[len] as the caller's padding byte `pad` (the reference reads the String's NUL).
+ */
+int msj_ref_parse_number_scan(const uint8_t *buf, uint64_t len, uint64_t start, uint8_t pad, uint64_t *end, int *is_float) {
+#define AT(k) ((k) < len ? buf[(k)] : pad)
+    const int has_minus_sign = AT(start) == '-';           /* :42 */
+    uint64_t p = start + (uint64_t)has_minus_sign;          /* :43 */
+    while (AT(p) >= '0' && AT(p) <= '9') p++;               /* :45-46 */
+    if (AT(p) == '.' || AT(p) == 'e' || AT(p) == 'E') {     /* :49 */
+        *is_float = 1;
+        while (!msj_ref_structural_or_whitespace(AT(p)) && p < len + 1) p++;  /* :53-54 (bounded by the padding byte) */
+    } else if (!msj_ref_structural_or_whitespace(AT(p))) {  /* :56 */
+        *end = p;
+        *is_float = 0;
+        return 9;                                           /* :57 NUMBER_ERROR */
+    } else {
+        *is_float = 0;                                      /* :59 */
+    }
+    *end = p;
+    return 0;
+#undef AT
+}
+
+/*
+ * parse_string's terminator search (generic/stage2/string_parsing.mojo:334-386) over BackslashAndQuote windows of
+ * 8 bytes (include/haswell/stringparsing_defs.mojo:27-48: the load is 8 wide): `start` = offset of the first body
+ * byte.  Returns the offset of the closing quote, or -1 where the reference returns a null pointer (a bogus escape,
+ * :372-375, or a \u escape whose four hex digits are not hex -- handle_unicode_codepoint's first check; surrogate
+ * pairing is not restated: it consumes 6 or 12 bytes of valid hex and cannot hide a quote).  *escaped: a backslash
+ * was met on the way.  Bytes past the buffer read as `pad`.
+ * bytes_processed: how far a window without quote or backslash advances.  The reference advances by
+ * BackslashAndQuote.BYTES_PROCESSED = 32 (stringparsing_defs.mojo:10) although copy_and_find loads and examines 8
+ * bytes (:42 `src.load[width=8]()`): with 32 it skips 24 unexamined bytes, so on a string whose first 8 body bytes
+ * hold neither a quote nor a backslash it can run past the closing quote (upstream simdjson loads 32 and advances
+ * 32).  Literal restatement: pass 32.  What the port evidently means -- and what stage 1's own in-string logic and the
+ * HIP kernels compute -- is the advance by the width examined: pass 8.  tests/test_tokens.py checks the kernels against
+ * 8 and records where the literal 32 differs.
+ */
+int64_t msj_ref_parse_string_end(const uint8_t *buf, uint64_t len, uint64_t start, uint8_t pad, int bytes_processed, int *escaped) {
+#define AT(k) ((k) < len ? buf[(k)] : pad)
+    static const char ok_escapes[] = "\"\\/bfnrt";         /* escape_map's non-zero entries */
+    uint64_t src = start;
+    *escaped = 0;
+    for (;;) {
+        if (src > len) return -1;                           /* ran off an unterminated string (the reference would read on) */
+        uint32_t bs_bits = 0, quote_bits = 0;               /* copy_and_find: 8 bytes */
+        for (int k = 0; k < 8; k++) {
+            if (AT(src + k) == '\\') bs_bits |= 1u << k;
+            if (AT(src + k) == '"') quote_bits |= 1u << k;
+        }
+        if (((bs_bits - 1u) & quote_bits) != 0) return (int64_t)(src + (uint64_t)__builtin_ctz(quote_bits));  /* has_quote_first :358-360 */
+        if (((quote_bits - 1u) & bs_bits) != 0) {            /* has_backslash :361 */
+            const uint64_t bs_dist = (uint64_t)__builtin_ctz(bs_bits);
+            const uint8_t escape_char = AT(src + bs_dist + 1);
+            *escaped = 1;
+            if (escape_char == 'u') {                        /* :366-375 */
+                for (int k = 2; k < 6; k++) {
+                    const uint8_t h = AT(src + bs_dist + k);
+                    if (!((h >= '0' && h <= '9') || (h >= 'a' && h <= 'f') || (h >= 'A' && h <= 'F'))) return -1;
+                }
+                src += bs_dist + 6;
+            } else {
+                int ok = 0;
+                for (const char *e = ok_escapes; *e; e++) ok |= (uint8_t)*e == escape_char;
+                if (!ok) return -1;                          /* bogus escape value :379-382 */
+                src += bs_dist + 2;                          /* :384 */
+            }
+        } else {
+            src += (uint64_t)bytes_processed;                /* neither :385-386 */
+        }
+    }
+#undef AT
+}
+
 void msj_oracle_token_spans(const uint8_t *buf, uint64_t len, const uint32_t *idx, uint64_t n, uint32_t *end, uint8_t *flags) {
     const uint64_t cap = 1024;
     for (uint64_t i = 0; i < n; i++) {
@@ -98,15 +180,24 @@ void msj_oracle_token_spans(const uint8_t *buf, uint64_t len, const uint32_t *id
                 else if (esc) f |= 2;
             }
         } else if (c == '-' || (c >= '0' && c <= '9')) {
+            /* parse_number's scan restated (include/generic/number_parsing.mojo:41-59): has_minus_sign,
+             * `while is_digit(p[0])`, then  p[0] in . e E -> is_float, `while is_not_structural_or_whitespace(p[0])`;
+             * elif is_not_structural_or_whitespace(p[0]) -> NUMBER_ERROR (flag 32); else an integer that ends here.
+             * Bytes past the buffer read as blanks (the kernels' convention). */
             f = 4;
-            uint64_t j = start + 1;
-            const uint64_t stop = (j + cap < len) ? j + cap : len;
-            for (; j < stop; j++) {
-                const uint8_t b = buf[j];
-                if (b == '.' || b == 'e' || b == 'E') f |= 8;
-                else if (!((b >= '0' && b <= '9') || b == '+' || b == '-')) break;
+            const uint64_t stop = (start + 1 + cap < len) ? start + 1 + cap : len;
+            uint64_t j = start + (c == '-' ? 1 : 0);
+            while (j < stop && buf[j] >= '0' && buf[j] <= '9') j++;
+            if (j < stop || j == len) {
+                const uint8_t ch = j < len ? buf[j] : ' ';
+                if (ch == '.' || ch == 'e' || ch == 'E') {
+                    f |= 8;
+                    while (j < stop && !msj_ref_structural_or_whitespace(buf[j])) j++;
+                } else if (!msj_ref_structural_or_whitespace(ch)) {
+                    f |= 32;
+                }
             }
-            if (j == stop && stop < len) f |= 128;
+            if (j == stop && stop < len) { f = (f & ~32u) | 128; e = 0; }
             else e = (uint32_t)j;
         }
         end[i] = e;

@@ -84,6 +84,28 @@ def oracle_token_spans(data, idx):
     return end[:idx.size], flags[:idx.size]
 
 
+def ref_parse_number_scan(data, start, pad=0x20):
+    """oracle/tokens_oracle.c msj_ref_parse_number_scan: the reference's parse_number scan
+    (number_parsing.mojo:41-59) -> (code 0 / 9, end offset, is_float)."""
+    lib = ctypes.CDLL(TOKENS_SO)
+    end, flt = ctypes.c_uint64(0), ctypes.c_int(0)
+    lib.msj_ref_parse_number_scan.restype = ctypes.c_int
+    rc = lib.msj_ref_parse_number_scan(ctypes.c_char_p(bytes(data)), ctypes.c_uint64(len(data)), ctypes.c_uint64(start),
+                                       ctypes.c_uint8(pad), ctypes.byref(end), ctypes.byref(flt))
+    return rc, int(end.value), bool(flt.value)
+
+
+def ref_parse_string_end(data, body_start, bytes_processed=8, pad=0x20):
+    """oracle/tokens_oracle.c msj_ref_parse_string_end: the reference's parse_string terminator search
+    (string_parsing.mojo:334-386) -> (offset of the closing quote or -1, escaped)."""
+    lib = ctypes.CDLL(TOKENS_SO)
+    esc = ctypes.c_int(0)
+    lib.msj_ref_parse_string_end.restype = ctypes.c_int64
+    e = lib.msj_ref_parse_string_end(ctypes.c_char_p(bytes(data)), ctypes.c_uint64(len(data)), ctypes.c_uint64(body_start),
+                                     ctypes.c_uint8(pad), ctypes.c_int(bytes_processed), ctypes.byref(esc))
+    return int(e), bool(esc.value)
+
+
 def oracle_documents(data, idx, typ, dep, open_string=False, capacity=None, is_final=False):
     """Definition of the document split (oracle/tokens_oracle.c: msj_oracle_documents):
     (doc_first uint32[min(n_documents, capacity)], (n_documents, n_complete, tokens_complete, resume_offset))."""
