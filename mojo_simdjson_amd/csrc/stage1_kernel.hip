@@ -659,8 +659,13 @@ __device__ __forceinline__ void copy_out(const KernelArgs &a, const EmitU &e, co
 #pragma unroll
     for (uint32_t k = 0; k < kStageWords / 256u; k++) {
         if (q_lo + 64u * k >= q_hi) break;  // uniform
-        if (q_lo + 64u * (k + 1u) <= q_hi || q_lo + 64u * k + lane < q_hi)
+        if (q_lo + 64u * (k + 1u) <= q_hi) {  // uniform: a full round, every lane stores
             *reinterpret_cast<uint4 *>(out + off + 1024u * k) = *reinterpret_cast<const uint4 *>(src + off + 1024u * k);
+        } else {  // the last round: the first (q_hi - q_lo - 64k) lanes
+            if (lane < q_hi - q_lo - 64u * k)
+                *reinterpret_cast<uint4 *>(out + off + 1024u * k) = *reinterpret_cast<const uint4 *>(src + off + 1024u * k);
+            break;
+        }
     }
     // head (elements shift .. 4*q_lo) and tail (4*q_hi .. vend): < 8 elements in total, one
     // element per lane of the first eight

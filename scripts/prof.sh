@@ -10,8 +10,10 @@ TAG=${1:-run}; shift
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 OUT=gpurun_out/prof/$TAG
 mkdir -p "$OUT"
-ARGS="--steps 20 --warmup 3 --no-cpu-baseline $*"   # same as the default bench run: the kernel slows by ~10 % over the first launches (clocks settle)
-timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/kt" -- python3 bench.py $ARGS > "$OUT/kt.log" 2>&1 || { echo "kernel-trace pass failed"; tail -5 "$OUT/kt.log"; exit 1; }
+ARGS="--steps 20 --warmup 5 --no-cpu-baseline $*"   # the driver's command (bench.py settles the clocks for 400 ms before the timed steps)
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/kt" -- python3 bench.py $ARGS > "$OUT/kt.log" 2>&1 || { echo "kernel-trace pass failed"; tail -5 "$OUT/kt.log"; exit 1; }
+grep "\"metric\"" "$OUT/kt.log" | tail -1 > "$OUT/bench_line.json"
+ARGS="$ARGS --settle-ms 0"                             # counters do not depend on the clocks: short runs for the PMC passes
 i=0
 for PMC in "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU" \
            "SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_LDS SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_INST_CYCLES_SALU" \
