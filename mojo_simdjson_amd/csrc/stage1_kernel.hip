@@ -309,38 +309,7 @@ __device__ __forceinline__ void scatter_bits32(uint32_t t, uint32_t lds_byte_add
         : "vcc", "memory");
 }
 
-// Same with 16-bit slots (tile-relative offsets fit 12 bits): twice as many indices per staging
-// round, for tiles with 1021..2044 structurals.
-__device__ __forceinline__ void scatter_bits16(uint32_t t, uint32_t lds_byte_addr, uint32_t nbits, uint32_t value_base) {
-    uint32_t lo, hi, tm1;
-    uint64_t save;
-    const uint32_t back = lds_byte_addr + 2u * nbits - 64u;  // slot (nbits - 1 - k) = back + 62 - 2k
-    const uint32_t vb31 = value_base + 31u;
-    const uint32_t topbit = 0x80000000u;
-    asm volatile(
-        "s_mov_b64 %[save], exec\n"
-        ".set msj_sb_k, 0\n"
-        ".rept 16\n"
-        "v_cmpx_ne_u32_e32 vcc, 0, %[t]\n"
-        "s_cbranch_execz 1f\n"
-        "v_ffbl_b32_e32 %[lo], %[t]\n"
-        "v_ffbh_u32_e32 %[hi], %[t]\n"
-        "v_add_u32_e32 %[tm1], -1, %[t]\n"
-        "v_or_b32_e32 %[lo], %[lo], %[vb]\n"
-        "ds_write_b16 %[front], %[lo] offset:2*msj_sb_k\n"
-        "v_sub_u32_e32 %[lo], %[vb31], %[hi]\n"
-        "v_lshrrev_b32_e32 %[hi], %[hi], %[top]\n"
-        "ds_write_b16 %[back], %[lo] offset:62-2*msj_sb_k\n"
-        "v_bitop3_b32 %[t], %[t], %[tm1], %[hi] bitop3:0x40\n"
-        ".set msj_sb_k, msj_sb_k+1\n"
-        ".endr\n"
-        "1:\n"
-        "s_mov_b64 exec, %[save]\n"
-        : [t] "+v"(t), [lo] "=&v"(lo), [hi] "=&v"(hi), [tm1] "=&v"(tm1), [save] "=&s"(save)
-        : [front] "v"(lds_byte_addr), [back] "v"(back), [vb] "v"(value_base), [vb31] "v"(vb31), [top] "v"(topbit)
-        : "vcc", "memory");
-}
-static_assert(offsetof(Shared, stage) >= 128, "scatter_bits32/16 address the back slots 128 / 64 bytes below the lane's end slot");
+static_assert(offsetof(Shared, stage) >= 128, "scatter_bits32 addresses the back slots from 128 bytes below the lane's end slot");
 
 // What a computed tile keeps in registers until it is parked.
 struct Pending {
@@ -571,7 +540,7 @@ __device__ __forceinline__ Pending compute_tile(const KernelArgs &a, const uint3
 //      output (LDS only), emit_store() turns them into aligned 16-byte
 //      stores (one L2 request per 64 B instead of one per index).  Wave-local: no barrier.
 // Everything that decides HOW a tile is emitted is wave-uniform and lives in scalar registers.
-enum : uint32_t { kEmitNone = 0, kEmitStaged, kEmitStaged16, kEmitRounds, kEmitGeneral };
+enum : uint32_t { kEmitNone = 0, kEmitStaged, kEmitDense, kEmitGeneral };
 struct EmitU {
     uint32_t mode;
     uint32_t tile;
@@ -615,11 +584,9 @@ __device__ __forceinline__ EmitU emit_prepare(const KernelArgs &a, const Shared 
     if (e.base + cnt > a.capacity)
         e.mode = kEmitGeneral;  // the output buffer has no room for all of the tile's indices
     else if (e.vend <= kStageWords)
-        e.mode = kEmitStaged;   // one staging round (the common case)
-    else if (e.vend <= 2u * kStageWords)
-        e.mode = kEmitStaged16; // one round with 16-bit slots (1021..2044 indices)
+        e.mode = kEmitStaged;   // per-lane chains into the staging slice, 16-byte stores (up to 1020 indices: the common case)
     else
-        e.mode = kEmitRounds;
+        e.mode = kEmitDense;    // more than a quarter of the tile's bytes: block by block, straight to the output
     e.mode = uniform32(e.mode);
     return e;
 }
@@ -677,35 +644,6 @@ __device__ __forceinline__ void copy_out(const KernelArgs &a, const EmitU &e, co
     }
 }
 
-// Medium-dense tile: 16-bit slots holding tile-relative offsets, widened in the copy-out.
-__device__ __forceinline__ void stage_indices16(const EmitV &v, uint32_t *stage, const uint32_t lane64) {
-    uint16_t *stage16 = reinterpret_cast<uint16_t *>(stage);
-    const uint32_t lds0 = (uint32_t)(uintptr_t)(stage16 + v.vpos);  // LDS byte address
-    const uint32_t nlo = (uint32_t)__builtin_popcount(v.tlo), nhi = (uint32_t)__builtin_popcount(v.thi);
-    scatter_bits16(v.tlo, lds0, nlo, lane64);
-    scatter_bits16(v.thi, lds0 + 2u * nlo, nhi, lane64 + 32u);
-}
-
-__device__ __forceinline__ void copy_out16(const KernelArgs &a, const EmitU &e, const uint32_t *stage,
-                                           const uint32_t lane) {
-    const uint16_t *stage16 = reinterpret_cast<const uint16_t *>(stage);
-    uint32_t *out = a.idx + (e.base - e.shift);     // out[v] <-> stage16[v]; 16-byte aligned
-    const uint32_t tb = e.tile_base;
-    const uint32_t q_lo = (e.shift + 3u) >> 2, q_hi = e.vend >> 2;
-    for (uint32_t q = q_lo + lane; q < q_hi; q += 64u) {
-        const uint2 h = *reinterpret_cast<const uint2 *>(stage16 + 4u * q);
-        *reinterpret_cast<uint4 *>(out + 4u * q) =
-            make_uint4(tb + (h.x & 0xFFFFu), tb + (h.x >> 16), tb + (h.y & 0xFFFFu), tb + (h.y >> 16));
-    }
-    if (lane < 4u) {
-        const uint32_t vh = lane;
-        if (vh >= e.shift && vh < 4u * q_lo && vh < e.vend) out[vh] = tb + stage16[vh];
-    } else if (lane < 8u) {
-        const uint32_t vt = 4u * q_hi + (lane - 4u);
-        if (vt < e.vend && vt >= 4u * q_lo) out[vt] = tb + stage16[vt];
-    }
-}
-
 __device__ __forceinline__ void lds_wave_sync() {
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -713,42 +651,35 @@ __device__ __forceinline__ void lds_wave_sync() {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-// Dense tile (more than kStageWords indices, i.e. more than a quarter of its bytes are
-// structural) whose indices fit the output buffer: the same straight-line staging and 16-byte
-// copy-out, in rounds.  A round takes the lanes whose first index falls into a window of
-// kRoundSlots = kStageWords - 64 output slots (a lane has at most 64 indices, so whatever
-// starts inside the window fits the slice); lanes are ordered by position, so a round is a
-// contiguous group of lanes and its indices a contiguous piece of the output.
-constexpr uint32_t kRoundSlots = kStageWords - 64u;
-__device__ __noinline__ void emit_rounds(uint32_t *idx, const uint32_t tile_base, const uint64_t base, const uint32_t shift,
-                                         const uint32_t vend, const uint32_t tlo, const uint32_t thi,
-                                         const uint32_t vpos, uint32_t *stage, const uint32_t lane) {
-    const uint32_t v0 = tile_base + lane * 64u;
-    uint32_t *out = idx + (base - shift);  // out[v] <-> slot v of the tile; 16-byte aligned
-    const uint32_t nlo = (uint32_t)__builtin_popcount(tlo), nhi = (uint32_t)__builtin_popcount(thi);
-    uint32_t v_begin = shift;
-    for (uint32_t r0 = 0; r0 < vend; r0 += kRoundSlots) {  // uniform; kRoundSlots is a multiple of 4
-        const bool mine = vpos >= r0 && vpos < r0 + kRoundSlots;
-        // this round's indices end where the next round's first lane starts
-        const uint64_t later = __ballot(vpos >= r0 + kRoundSlots);
-        const uint32_t v_end = later ? bcast(vpos, (int)__builtin_ctzll(later)) : vend;
-        const uint32_t lds0 = (uint32_t)(uintptr_t)(stage + (vpos - r0));
-        scatter_bits32(mine ? tlo : 0u, lds0, nlo, v0);
-        scatter_bits32(mine ? thi : 0u, lds0 + 4u * nlo, nhi, v0 | 32u);
-        lds_wave_sync();
-        // copy out slots [v_begin, v_end): full quads in the body, partial quads element-wise
-        const uint32_t q_lo = (v_begin + 3u) >> 2, q_hi = v_end >> 2;
-        for (uint32_t q = q_lo + lane; q < q_hi; q += 64u)
-            *reinterpret_cast<uint4 *>(out + 4u * q) = *reinterpret_cast<const uint4 *>(stage + (4u * q - r0));
-        if (lane < 4u) {
-            const uint32_t vh = (v_begin & ~3u) + lane;  // head quad
-            if (vh >= v_begin && vh < 4u * q_lo && vh < v_end) out[vh] = stage[vh - r0];
-        } else if (lane < 8u) {
-            const uint32_t vt = 4u * q_hi + (lane - 4u);  // tail quad
-            if (vt < v_end && vt >= 4u * q_lo && vt >= v_begin) out[vt] = stage[vt - r0];
-        }
-        lds_wave_sync();  // the slice is reused by the next round
-        v_begin = v_end;
+// Dense tile (more than kStageWords - 4 indices: more than a quarter of its bytes are structural) whose indices
+// fit the output buffer.  Per-lane chains would run with a few lanes at a time here (a staging slice holds the
+// indices of ~15 lanes), so the roles are turned around: block by block, the block's 64-bit mask is read into
+// scalar registers and becomes the EXEC mask; lane j then stands for byte j of the block, its rank among the
+// set bits below it (v_mbcnt) is its slot, and one store instruction writes the block's indices -- up to 256
+// contiguous bytes -- straight to the output.  16 instructions per 64-byte block whatever the density; no
+// staging, no LDS.
+__device__ __noinline__ void emit_dense(uint32_t *idx, const uint32_t tile_base, const uint64_t base, const uint32_t tlo,
+                                        const uint32_t thi, const uint32_t first_slot, const uint32_t lane) {
+    // out[k] = the tile's k-th index; wave-uniform (the arguments of a called function arrive in vector registers)
+    const uint64_t out = uniform64(reinterpret_cast<uint64_t>(idx + base));
+    const uint32_t tb = uniform32(tile_base);
+    for (uint32_t b = 0; b < 64u; b++) {  // uniform
+        const uint32_t mlo = bcast(tlo, (int)b), mhi = bcast(thi, (int)b);
+        if ((mlo | mhi) == 0u) continue;
+        const uint32_t slot0 = bcast(first_slot, (int)b);  // slot of the block's first index
+        const uint32_t rank = __builtin_amdgcn_mbcnt_hi(mhi, __builtin_amdgcn_mbcnt_lo(mlo, 0u));
+        const uint32_t off = (slot0 + rank) * 4u;
+        const uint32_t val = tb + b * 64u + lane;
+        const uint64_t m = u64(mlo, mhi);
+        uint64_t save;
+        asm volatile(
+            "s_mov_b64 %[save], exec\n"
+            "s_mov_b64 exec, %[m]\n"
+            "global_store_dword %[off], %[val], %[out]\n"
+            "s_mov_b64 exec, %[save]\n"
+            : [save] "=&s"(save)
+            : [m] "s"(m), [off] "v"(off), [val] "v"(val), [out] "s"(out)
+            : "memory");
     }
 }
 
@@ -820,20 +751,15 @@ __device__ __forceinline__ void emit_stage(const Shared &sh, const EmitU &e, con
     if (e.mode == kEmitStaged) {  // uniform
         const EmitV v = emit_lane(sh, wave, slot, lane, e);
         stage_indices(e, v, stage, lane64);
-    } else if (e.mode == kEmitStaged16) {
-        const EmitV v = emit_lane(sh, wave, slot, lane, e);
-        stage_indices16(v, stage, lane64);
     }
 }
 __device__ __forceinline__ void emit_store(const KernelArgs &a, const Shared &sh, const EmitU &e, const uint32_t wave,
                                            const uint32_t slot, uint32_t *stage, const uint32_t lane) {
     if (e.mode == kEmitStaged) {  // uniform
         copy_out(a, e, stage, lane);
-    } else if (e.mode == kEmitStaged16) {
-        copy_out16(a, e, stage, lane);
-    } else if (e.mode == kEmitRounds) {
+    } else if (e.mode == kEmitDense) {
         const EmitV v = emit_lane(sh, wave, slot, lane, e);
-        emit_rounds(a.idx, e.tile_base, e.base, e.shift, e.vend, v.tlo, v.thi, v.vpos, stage, lane);
+        emit_dense(a.idx, e.tile_base, e.base, v.tlo, v.thi, v.vpos - e.shift, lane);
     } else if (e.mode == kEmitGeneral) {
         const EmitV v = emit_lane(sh, wave, slot, lane, e);
         emit_general(a.idx, a.capacity, e.tile_base, e.base, e.shift, e.vend, v.tlo, v.thi, v.vpos, stage, lane);

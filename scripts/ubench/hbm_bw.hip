@@ -40,6 +40,16 @@ __global__ __launch_bounds__(256) void k_mix(const u32x4 *__restrict__ in, u32x4
     }
 }
 
+// read n16 quads; write every quad `mult` times (mult coalesced output streams): the write-heavy mixes of the
+// dense extremes of config 4 (4 bytes out per structural: d = 0.5 -> 2 bytes out per byte in, d = 1 -> 4)
+__global__ __launch_bounds__(256) void k_expand(const u32x4 *__restrict__ in, u32x4 *__restrict__ out, size_t n16, unsigned mult) {
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += stride) {
+        u32x4 v = __builtin_nontemporal_load(in + i);
+        for (unsigned m = 0; m < mult; m++) __builtin_nontemporal_store(v, out + (size_t)m * n16 + i);
+    }
+}
+
 int main() {
     hipDeviceProp_t p; CK(hipGetDeviceProperties(&p, 0));
     printf("device %s, %d CUs\n", p.name, p.multiProcessorCount);
@@ -73,6 +83,15 @@ int main() {
             timeit(nm, 1.775 * n, [&] { hipLaunchKernelGGL(k_mix, dim3(wgs), dim3(256), 0, 0, a, b, n16, 31u, 40u); });
         }
         timeit("hipMemcpyDtoD (2N bytes)", 2.0 * n, [&] { CK(hipMemcpyAsync(b, a, n, hipMemcpyDeviceToDevice, 0)); });
+        if (gib == 1) {
+            u32x4 *big; CK(hipMalloc(&big, 4 * n));
+            for (unsigned mult : {2u, 4u}) {
+                char nm[64];
+                snprintf(nm, sizeof nm, "read N, write %uN grid 8192", mult);
+                timeit(nm, (1.0 + mult) * n, [&] { hipLaunchKernelGGL(k_expand, dim3(8192), dim3(256), 0, 0, a, big, n16, mult); });
+            }
+            CK(hipFree(big));
+        }
         CK(hipFree(a)); CK(hipFree(b)); CK(hipFree(sink));
     }
     return 0;

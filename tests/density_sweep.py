@@ -1,8 +1,9 @@
 #!/usr/bin/env python3
 """GB/s against structural density d = S/N.
 
-1 GiB streams (a 64 MiB unit repeated on the device), resident in HBM, 3 warm-up + 10 timed
-launches each (HIP events); the structural count of every run is checked against the
+1 GiB streams (a 64 MiB unit repeated on the device), resident in HBM; per workload 0.3 s of untimed
+launches (the clocks settle), then 50 timed ones (HIP events); the 20 launches right
+after 5 warm-ups are timed too ("unsettled").  The structural count of every run is checked against the
 oracle's count of the unit (checker only, outside the timed region).
 """
 import os
@@ -41,21 +42,34 @@ def main():
         want = n_unit * reps
         d_idx = torch.empty(want + 16, dtype=torch.int32, device=dev.device)
         d_res = dev.new_carry()
-        for _ in range(3):
+        import time
+        for _ in range(5):
             dev.index(d_buf, d_idx, d_res)
         torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-        for _ in range(10):
+        for _ in range(20):
             dev.index(d_buf, d_idx, d_res)
         e1.record()
         torch.cuda.synchronize()
-        ms = e0.elapsed_time(e1) / 10
+        ms_unsettled = e0.elapsed_time(e1) / 20
+        t_end = time.perf_counter() + 0.3
+        while time.perf_counter() < t_end:
+            for _ in range(25):
+                dev.index(d_buf, d_idx, d_res)
+            torch.cuda.synchronize()
+        e0.record()
+        for _ in range(50):
+            dev.index(d_buf, d_idx, d_res)
+        e1.record()
+        torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / 50
         res = dev.fetch(d_res)
         assert int(res.count) == want and res.internal_error == 0, (name, int(res.count), want)
         # the reference's code for the repeated stream: only meaningful for the valid documents
         alg = n + 4 * want
-        print(f"{name:24s} {n:12d} {want / n:8.4f} {ms:8.4f} {n / ms / 1e6:12.1f} {alg / ms / 1e6:14.1f} {alg / ms / 1e6 / 8000:14.3f}", flush=True)
+        print(f"{name:24s} {n:12d} {want / n:8.4f} {ms:8.4f} {n / ms / 1e6:12.1f} {alg / ms / 1e6:14.1f} {alg / ms / 1e6 / 8000:14.3f}"
+              f"   unsettled {ms_unsettled:.4f} ms ({alg / ms_unsettled / 1e6 / 8000:.3f})", flush=True)
         del d_buf, d_idx
     dev.close()
 

@@ -173,8 +173,8 @@ def test_strings_spanning_tiles(oracle):
 def test_density_extremes(oracle):
     from mojo_simdjson_amd import synth
 
-    # kinds 0/1: > 2 044 structurals per tile (staging in rounds); 4/5: 2 048 / 1 638 per tile
-    # (one round of 16-bit slots, or rounds when the alignment shift pushes it over); 2/3: none
+    # kinds 0/1/4/5: more than 1 020 structurals per tile (block-wise dense emission: 4 096, 2 731, 2 048, 1 638 per tile)
+    # 2/3: none
     for kind in range(6):
         for n in (3 * TILE + 1000, 40 * TILE + 123):
             d = synth.extreme(n, kind).tobytes()
