@@ -209,6 +209,52 @@ MSJ_HD Classes classify(const uint64_t p[8], uint64_t valid) {
     return c;
 }
 
+// Character classes the token-span kernel reads from a block (tokens_kernel.hip, SURVEY.md section 8 rows
+// f2 / f4), from the same bit-planes:
+//   digit      30..39                        (is_integer, include/generic/number_parsing.mojo:22-30)
+//   sow        09 0A 0D 20 , : [ ] { }       (structural_or_whitespace, internal/jsoncharutils_tables.mojo:5-16)
+//   backslash  5C
+//   blank      09 0A 0D 20
+// No `valid` mask: the kernel presents bytes past the end of the buffer as 0x20.
+struct SpanClasses {
+    uint64_t digit, sow, backslash, blank;
+};
+MSJ_HD SpanClasses span_classes(const uint64_t p[8]) {
+    const uint64_t b0 = p[0], b1 = p[1], b2 = p[2], b3 = p[3];
+    const uint64_t b4 = p[4], b5 = p[5], b6 = p[6], b7 = p[7];
+    const uint64_t g100 = lut3<MSJ_TT(TA & ~TB & ~TC)>(b2, b1, b0);      // xC
+    const uint64_t g010 = lut3<MSJ_TT(~TA & TB & ~TC)>(b2, b1, b0);      // xA
+    const uint64_t g011_101 = lut3<MSJ_TT((TA ^ TB) & TC)>(b2, b1, b0);  // xB, xD
+    const uint64_t g001_010_101 = lut3<MSJ_TT((~TA & (TB ^ TC)) | (TA & ~TB & TC))>(b2, b1, b0);  // x9 xA xD
+    const uint64_t g000 = lut3<MSJ_TT(~TA & ~TB & ~TC)>(b2, b1, b0);     // x0
+    SpanClasses c;
+    {   // 09 0A 0D: high nibble 0, b3 = 1;  20: high nibble 2, low nibble 0
+        const uint64_t w1 = lut3<MSJ_TT(~TA & TB & TC)>(b5, b3, g001_010_101);
+        const uint64_t w2 = lut3<MSJ_TT(TA & ~TB & TC)>(b5, b3, g000);
+        const uint64_t w3 = lut3<MSJ_TT((TA | TB) & ~TC)>(w1, w2, b4);
+        c.blank = lut3<MSJ_TT(TA & ~TB & ~TC)>(w3, b7, b6);
+    }
+    {   // 2C, 3A, 5B 5D 7B 7D: b3 = 1, b7 = 0; (b6 = 0: b5 = 1, b4 picks xC / xA) (b6 = 1: b4 = 1, xB / xD, b5 free)
+        const uint64_t x = lut3<MSJ_TT((TC & TB) | (~TC & TA))>(g010, g011_101, b6);  // (xA & ~b6) | (xB/xD & b6)
+        const uint64_t y = lut3<MSJ_TT(TA & ~TB & ~TC)>(g100, b6, b4);                // xC, b6 = 0, b4 = 0
+        const uint64_t z = lut3<MSJ_TT((TA & TB) | TC)>(x, b4, y);
+        const uint64_t op = lut3<MSJ_TT(TA & TB & ~TC)>(z, b3, b7);                   // 0C 2C 1A 3A 5B 5D 7B 7D
+        const uint64_t h = lut3<MSJ_TT(TA & (TB | TC))>(op, b5, b6);                  // drop 0C and 1A
+        c.sow = h | c.blank;
+    }
+    {
+        const uint64_t h5 = lut3<MSJ_TT(~TA & TB & ~TC)>(b7, b6, b5);
+        const uint64_t h5b = lut3<MSJ_TT(TA & TB & TC)>(h5, b4, b3);
+        c.backslash = h5b & g100;
+    }
+    {   // 3x with x <= 9: b3 = 0, or b2 = b1 = 0
+        const uint64_t h3 = lut3<MSJ_TT(~TA & ~TB & TC)>(b7, b6, b5);
+        const uint64_t lo = lut3<MSJ_TT(~TA | (~TB & ~TC))>(b3, b2, b1);
+        c.digit = lut3<MSJ_TT(TA & TB & TC)>(h3, b4, lo);
+    }
+    return c;
+}
+
 // Inclusive prefix XOR over 64 bits (stuff.mojo:21-28 prefix_xor, here 6
 // doubling steps instead of 64 popcounts).
 MSJ_HD uint64_t prefix_xor(uint64_t x) {

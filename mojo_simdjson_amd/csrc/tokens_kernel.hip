@@ -23,6 +23,7 @@
 #include <stdint.h>
 
 #include "../../include/msj_stage1.h"
+#include "lane_math.h"
 
 namespace msj_tokens {
 
@@ -700,58 +701,50 @@ __device__ __forceinline__ void span_of(const Src &src, uint64_t start, uint64_t
 }
 
 // One thread per structural, kSpanTokens per workgroup.  The workgroup's tokens cover one contiguous
-// stretch of the buffer, [idx[first], idx[first of the next workgroup]].  It is staged in LDS with
-// coalesced 16-byte reads, and while a thread holds its 16 bytes it classifies them ONCE: one bit per
-// byte for "digit", "structural or blank" (the reference's table, where a float ends), "backslash" and "not
-// blank".  A token then needs a handful of LDS reads: the digits of a number end at the first clear "digit"
-// bit, a float at the next set "structural or blank" bit, a string's escape flag is "any bit set in a range".  Work per byte
-// instead of work per token times its length.  A stretch over kSpanLds bytes (long strings) takes
-// the per-token path from global memory (span_of) instead.
+// stretch of the buffer, [idx[first], idx[first of the next workgroup]].  It is staged in LDS, and the
+// lane that brings in a 64-byte block classifies it ONCE the way stage 1 does (bit-plane transpose, then
+// every class is a few three-input operations on the planes: lane_math.h span_classes): one bit per byte
+// for "digit", "structural or blank" (the reference's table, where a float ends), "backslash" and "not
+// blank", ~3 operations per byte.  A token then needs a handful of LDS reads and no loop in the common
+// case: the digits of a number end at the first clear "digit" bit of a 32-bit window, a float at the
+// next set "structural or blank" bit, the closing quote is the top set bit of a "not blank" window that
+// ends at the next structural, a string's escape flag is two masked 64-bit words plus a bit per block in
+// between ("this block holds a backslash", one ballot per wave).  Work per byte instead of work per
+// token times its length.  A stretch over kSpanLds bytes (long strings) takes the per-token path from
+// global memory (span_of) instead.
 constexpr uint32_t kSpanThreads = 256;
 constexpr int kSpanPer = 2;  // tokens per thread
 constexpr uint32_t kSpanTokens = kSpanThreads * kSpanPer;  // per workgroup
 constexpr uint32_t kSpanLds = 12288;  // + four bitmaps of 1.5 KiB: 8 workgroups (32 waves) per CU
-constexpr uint32_t kSpanMaskWords = kSpanLds / 32 + 2;  // one bit per staged byte, + the word a window may reach into
+constexpr uint32_t kSpanBlocks = kSpanLds / 64;
+// a bitmap in LDS: two zero words, one bit per staged byte, zero words behind (windows reach one word
+// in front of position 0 and two words past the last staged byte)
+constexpr uint32_t kSpanMapFront = 2;
+constexpr uint32_t kSpanMapWords = kSpanMapFront + 2 * kSpanBlocks + 4;
+static_assert(kSpanBlocks <= kSpanThreads, "one lane per staged block");
 
-// bit 7 of every byte of x that equals c / that is an ASCII digit; exact (no carries between bytes)
-__device__ __forceinline__ uint32_t eq_bytes(uint32_t x, uint32_t c) {
-    const uint32_t z = x ^ (c * 0x01010101u);
-    return ~(((z & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | z) & 0x80808080u;
-}
-__device__ __forceinline__ uint32_t digit_bytes(uint32_t x) {
-    const uint32_t d = x ^ 0x30303030u;  // '0'..'9' -> 0..9
-    return ~(((d & 0x7F7F7F7Fu) + 0x76767676u) | d) & 0x80808080u;  // low 7 bits < 10 and bit 7 clear
-}
-// bits 7, 15, 23, 31 -> bits 0..3
-__device__ __forceinline__ uint32_t nibble_of(uint32_t m) { return ((((m & 0x80808080u) >> 7) * 0x01020408u) >> 24) & 0xFu; }
-
-// 32 bits of a bitmap starting at bit `pos`
+// 32 bits of a bitmap starting at bit `pos` (bit 0 of the result = position pos)
 __device__ __forceinline__ uint32_t bits_at(const uint32_t *map, uint32_t pos) {
-    const uint32_t w = pos >> 5;
+    const uint32_t w = (pos >> 5) + kSpanMapFront;
     return __funnelshift_r(map[w], map[w + 1], pos & 31u);
 }
-// any bit set in [b0, b1)?  b1 > b0
-__device__ __forceinline__ bool any_bits(const uint32_t *map, uint32_t b0, uint32_t b1) {
-    const uint32_t w0 = b0 >> 5, w1 = (b1 - 1u) >> 5;
-    uint32_t acc = 0;
-    for (uint32_t w = w0; w <= w1; w++) {
-        uint32_t m = map[w];
-        if (w == w0) m &= ~0u << (b0 & 31u);
-        if (w == w1) m &= ~0u >> (31u - ((b1 - 1u) & 31u));
-        acc |= m;
-    }
-    return acc != 0;
+// the 32 bits in front of position t (bit 31 of the result = position t - 1); positions below 0 read as 0
+__device__ __forceinline__ uint32_t bits_before(const uint32_t *map, uint32_t t) {
+    const uint32_t w = (t >> 5) + kSpanMapFront - 1u;
+    return __funnelshift_r(map[w], map[w + 1], t & 31u);
+}
+__device__ __forceinline__ uint64_t block_bits(const uint32_t *map, uint32_t blk) {
+    const uint2 v = *reinterpret_cast<const uint2 *>(map + kSpanMapFront + 2u * blk);
+    return ((uint64_t)v.y << 32) | v.x;
 }
 
 // one token from the staged stretch; offsets relative to lo (< kSpanLds)
 __device__ __forceinline__ void staged_token(const uint8_t *stage, const uint32_t *m_num, const uint32_t *m_flt, const uint32_t *m_bs,
-                                             const uint32_t *m_ink, uint64_t lo, uint32_t span, uint64_t len, uint64_t start, uint64_t next,
-                                             uint32_t &e_out, uint32_t &f_out) {
-    // offsets relative to lo from here on (< kSpanLds)
+                                             const uint32_t *m_ink, const uint32_t *bs_blocks, uint64_t lo, uint32_t span, uint64_t len,
+                                             uint32_t c, uint64_t start, uint64_t next, uint32_t &e_out, uint32_t &f_out) {
     const uint32_t rs = (uint32_t)(start - lo);
     const uint32_t rn = (uint32_t)(next - lo);
     const uint32_t rlen = (len - lo < (uint64_t)span) ? (uint32_t)(len - lo) : span;  // end of the buffer within the stretch
-    const uint32_t c = stage[rs];
     uint32_t e = 0, f = 0;
     if (c == '"') {
         f = MSJ_SPAN_STRING;
@@ -759,30 +752,52 @@ __device__ __forceinline__ void staged_token(const uint8_t *stage, const uint32_
         // input has a line break and its indentation between a value and the closing bracket
         uint32_t q = rs + 1;
         if (rn > rs + 1) {
-            const uint32_t w0 = (rs + 1) >> 5;
-            for (uint32_t w = (rn - 1) >> 5;; w--) {
-                uint32_t m = m_ink[w];
-                if (w == (rn - 1) >> 5) m &= ~0u >> (31u - ((rn - 1) & 31u));
-                if (w == w0) m &= ~0u << ((rs + 1) & 31u);
-                if (m) {
-                    q = 32u * w + 32u - __clz(m);
+            uint32_t t = rn;
+            for (;;) {  // one round unless more than 32 blanks stand in front of the next structural
+                const uint32_t d = t - (rs + 1);
+                uint32_t v = bits_before(m_ink, t);
+                if (d < 32) v &= ~0u << (32u - d);
+                if (v) {
+                    q = t - __clz(v);
                     break;
                 }
-                if (w == w0) break;
+                if (d <= 32) break;
+                t -= 32;
             }
         }
         bool closed = false;
         if (q > rs + 1 && stage[q - 1] == '"') {
-            uint32_t k = q - 1;  // unescaped iff an even number of backslashes stands right in front of it
-            while (k > rs + 1 && stage[k - 1] == '\\') k--;
-            closed = (((q - 1) - k) & 1u) == 0;
+            // unescaped iff an even number of backslashes stands right in front of it (the byte at rs is the
+            // opening quote, so the run ends there at the latest)
+            uint32_t run = 0, t = q - 1;
+            for (;;) {  // one round unless 32 backslashes in a row
+                const uint32_t v = ~bits_before(m_bs, t);
+                const uint32_t r = v ? (uint32_t)__clz(v) : 32u;
+                run += r;
+                if (r < 32) break;
+                t -= 32;
+            }
+            closed = (run & 1u) == 0;
         }
         if (closed) {
             const uint32_t b0 = rs + 1, close = q - 1;  // body = [b0, close)
-            if (close - b0 > kSpanCap)
+            if (close - b0 > kSpanCap) {
                 f |= MSJ_SPAN_LONG;
-            else if (close > b0 && any_bits(m_bs, b0, close))
-                f |= MSJ_SPAN_ESCAPED;
+            } else if (close > b0) {
+                const uint32_t last = close - 1, k0 = b0 >> 6, k1 = last >> 6;
+                const uint64_t head = block_bits(m_bs, k0) & (~0ull << (b0 & 63u));
+                const uint64_t tail = block_bits(m_bs, k1) & (~0ull >> (63u - (last & 63u)));
+                bool any;
+                if (k0 == k1) {
+                    any = (head & tail) != 0;
+                } else {  // blocks strictly between: at most kSpanCap / 64 + 1 of them, one bit each
+                    const uint32_t between = k1 - k0 - 1u;
+                    const uint32_t w = (k0 + 1u) >> 5;
+                    const uint32_t mid = __funnelshift_r(bs_blocks[w], bs_blocks[w + 1], (k0 + 1u) & 31u) & ((1u << between) - 1u);
+                    any = (head | tail | mid) != 0;
+                }
+                if (any) f |= MSJ_SPAN_ESCAPED;
+            }
         } else {
             f |= MSJ_SPAN_OPEN;  // only the last token can be like this (stage 1 reports UNCLOSED_STRING)
         }
@@ -830,6 +845,38 @@ __device__ __forceinline__ void staged_token(const uint8_t *stage, const uint32_
     f_out = f;
 }
 
+// minimum and maximum over the wave, by DPP: an inclusive scan inside each row of 16 lanes (row_shr 1, 2, 4, 8),
+// then the last lane of a row into the next row (row_bcast:15, rows 1 and 3) and lane 31 into rows 2 and 3
+// (row_bcast:31); lane 63 holds the result.  A lane without a source lane keeps its value (the instruction is
+// off for it).  One instruction per step and value; a DPP read needs two wait states after the write of its
+// source, which the other chain and an s_nop provide.
+__device__ __forceinline__ void wave_min_max(int x, int &mn_out, int &mx_out) {
+    int mn = x, mx = x;
+    asm volatile(
+        "s_nop 1\n\t"
+        "v_min_i32_dpp %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
+        "v_max_i32_dpp %1, %1, %1 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 0\n\t"
+        "v_min_i32_dpp %0, %0, %0 row_shr:2 row_mask:0xf bank_mask:0xf\n\t"
+        "v_max_i32_dpp %1, %1, %1 row_shr:2 row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 0\n\t"
+        "v_min_i32_dpp %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xf\n\t"
+        "v_max_i32_dpp %1, %1, %1 row_shr:4 row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 0\n\t"
+        "v_min_i32_dpp %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xf\n\t"
+        "v_max_i32_dpp %1, %1, %1 row_shr:8 row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 0\n\t"
+        "v_min_i32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+        "v_max_i32_dpp %1, %1, %1 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+        "s_nop 0\n\t"
+        "v_min_i32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"
+        "v_max_i32_dpp %1, %1, %1 row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"
+        "s_nop 1"
+        : "+v"(mn), "+v"(mx));
+    mn_out = __builtin_amdgcn_readlane(mn, 63);
+    mx_out = __builtin_amdgcn_readlane(mx, 63);
+}
+
 // kFused: the kernel also writes the type byte of every token and the (sum, min, max, opening brackets)
 // aggregate of its kSpanTokens tokens -- what gather_reduce computes from a second pass over the buffer.
 template <bool kFused>
@@ -837,16 +884,17 @@ __global__ __launch_bounds__(kSpanThreads) void token_spans(const uint8_t *__res
                                                            uint64_t n, uint32_t *__restrict__ end, uint8_t *__restrict__ flags, uint32_t lds_limit,
                                                            uint8_t *__restrict__ type, int4 *__restrict__ sub_agg) {
     __shared__ __attribute__((aligned(16))) uint8_t stage[kSpanLds];
-    __shared__ uint32_t m_num[kSpanMaskWords], m_flt[kSpanMaskWords], m_bs[kSpanMaskWords], m_ink[kSpanMaskWords];
+    __shared__ __attribute__((aligned(8))) uint32_t m_num[kSpanMapWords], m_flt[kSpanMapWords], m_bs[kSpanMapWords], m_ink[kSpanMapWords];
+    __shared__ uint32_t bs_blocks[2 * (kSpanThreads / 64) + 2];  // bit b: block b of the stretch holds a backslash
     const uint64_t first = (uint64_t)blockIdx.x * kSpanTokens;
     uint64_t tok[kSpanPer];  // this thread's tokens: threadIdx.x, threadIdx.x + kSpanThreads, ...
 #pragma unroll
     for (int k = 0; k < kSpanPer; k++) tok[k] = first + threadIdx.x + (uint32_t)k * kSpanThreads;
     const uint64_t after = first + kSpanTokens < n ? first + kSpanTokens : n;  // first token of the next workgroup
     // uniform: the stretch [lo, hi) -- through the byte at the next workgroup's first structural
-    const uint64_t lo = (uint64_t)idx[first] & ~15ull;
+    const uint64_t lo = (uint64_t)idx[first] & ~63ull;
     const uint64_t hi = after < n ? (uint64_t)idx[after] + 1u : len;
-    const uint64_t hi_al = (hi + 15u) & ~15ull;
+    const uint64_t hi_al = (hi + 63u) & ~63ull;
     // this thread's tokens, requested together with the stretch bounds (not behind the barrier below)
     uint64_t start[kSpanPer], next[kSpanPer];
 #pragma unroll
@@ -865,50 +913,70 @@ __global__ __launch_bounds__(kSpanThreads) void token_spans(const uint8_t *__res
             }
         }
     } else {
-    const uint32_t span = (uint32_t)(hi_al - lo);
-    for (uint32_t o = 16u * threadIdx.x; o < span; o += 16u * kSpanThreads) {
-        const uint64_t g = lo + o;
-        uint32_t w[4];
-        if (g + 16 <= len) {
-            const uint4 v = *reinterpret_cast<const uint4 *>(buf + g);
-            w[0] = v.x, w[1] = v.y, w[2] = v.z, w[3] = v.w;
-        } else {  // the buffer ends inside this piece: blanks behind it
-            w[0] = w[1] = w[2] = w[3] = 0x20202020u;
-            for (uint64_t b = g; b < len; b++) {
-                const uint32_t k = (uint32_t)(b - g);
-                const uint32_t sh = 8u * (k & 3u), v = (uint32_t)buf[b] << sh, keep = ~(0xFFu << sh);
-                if ((k >> 2) == 0) w[0] = (w[0] & keep) | v;
-                if ((k >> 2) == 1) w[1] = (w[1] & keep) | v;
-                if ((k >> 2) == 2) w[2] = (w[2] & keep) | v;
-                if ((k >> 2) == 3) w[3] = (w[3] & keep) | v;
+        const uint32_t span = (uint32_t)(hi_al - lo);
+        const uint32_t nblk = span >> 6;  // <= kSpanBlocks: lane j stages and classifies block j
+        const uint32_t j = threadIdx.x;
+        uint64_t has_bs = 0;
+        if (j < nblk) {
+            const uint64_t g = lo + 64u * j;
+            uint32_t x[16];
+            if (g + 64 <= len) {
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    const uint4 v = *reinterpret_cast<const uint4 *>(buf + g + 16 * q);
+                    x[4 * q] = v.x, x[4 * q + 1] = v.y, x[4 * q + 2] = v.z, x[4 * q + 3] = v.w;
+                }
+            } else {  // the buffer ends inside this block: blanks behind it
+#pragma unroll
+                for (int d = 0; d < 16; d++) {
+                    uint32_t w = 0x20202020u;
+#pragma unroll
+                    for (int bb = 0; bb < 4; bb++) {
+                        const uint64_t pos = g + 4u * d + bb;
+                        if (pos < len) w = (w & ~(0xFFu << (8 * bb))) | ((uint32_t)buf[pos] << (8 * bb));
+                    }
+                    x[d] = w;
+                }
             }
-        }
-        *reinterpret_cast<uint4 *>(stage + o) = make_uint4(w[0], w[1], w[2], w[3]);
-        uint32_t num = 0, flt = 0, bs = 0, ink = 0;  // ink: not a blank
 #pragma unroll
-        for (int k = 0; k < 4; k++) {
-            const uint32_t x = w[k];
-            const uint32_t blank = eq_bytes(x, 0x20) | eq_bytes(x, 0x0A) | eq_bytes(x, 0x0D) | eq_bytes(x, 0x09);
-            // structural or blank: , :  and  [ ] { }  (5B 5D 7B 7D = 5B / 5D with bit 5 free)
-            const uint32_t fl = blank | eq_bytes(x, ',') | eq_bytes(x, ':') | eq_bytes(x & 0xDFDFDFDFu, '[') | eq_bytes(x & 0xDFDFDFDFu, ']');
-            const uint32_t nu = digit_bytes(x);
-            num |= nibble_of(nu) << (4 * k);
-            flt |= nibble_of(fl) << (4 * k);
-            bs |= nibble_of(eq_bytes(x, '\\')) << (4 * k);
-            ink |= nibble_of(~blank) << (4 * k);
+            for (int q = 0; q < 4; q++)
+                *reinterpret_cast<uint4 *>(stage + 64u * j + 16 * q) = make_uint4(x[4 * q], x[4 * q + 1], x[4 * q + 2], x[4 * q + 3]);
+            uint64_t pl[8];
+            msj::bitplanes(x, pl);
+            const msj::SpanClasses cl = msj::span_classes(pl);
+            const uint32_t w = kSpanMapFront + 2u * j;
+            *reinterpret_cast<uint2 *>(m_num + w) = make_uint2((uint32_t)cl.digit, (uint32_t)(cl.digit >> 32));
+            *reinterpret_cast<uint2 *>(m_flt + w) = make_uint2((uint32_t)cl.sow, (uint32_t)(cl.sow >> 32));
+            *reinterpret_cast<uint2 *>(m_bs + w) = make_uint2((uint32_t)cl.backslash, (uint32_t)(cl.backslash >> 32));
+            *reinterpret_cast<uint2 *>(m_ink + w) = make_uint2((uint32_t)~cl.blank, (uint32_t)(~cl.blank >> 32));
+            has_bs = cl.backslash;
+        } else if (j < nblk + 2u) {  // zero words behind the maps
+            const uint32_t w = kSpanMapFront + 2u * j;
+            *reinterpret_cast<uint2 *>(m_num + w) = make_uint2(0, 0);
+            *reinterpret_cast<uint2 *>(m_flt + w) = make_uint2(0, 0);
+            *reinterpret_cast<uint2 *>(m_bs + w) = make_uint2(0, 0);
+            *reinterpret_cast<uint2 *>(m_ink + w) = make_uint2(0, 0);
         }
-        reinterpret_cast<uint16_t *>(m_num)[o >> 4] = (uint16_t)num;
-        reinterpret_cast<uint16_t *>(m_flt)[o >> 4] = (uint16_t)flt;
-        reinterpret_cast<uint16_t *>(m_bs)[o >> 4] = (uint16_t)bs;
-        reinterpret_cast<uint16_t *>(m_ink)[o >> 4] = (uint16_t)ink;
-    }
-    __syncthreads();
+        if (j == kSpanThreads - 1) {  // ... and in front of them
+            *reinterpret_cast<uint2 *>(m_num) = make_uint2(0, 0);
+            *reinterpret_cast<uint2 *>(m_flt) = make_uint2(0, 0);
+            *reinterpret_cast<uint2 *>(m_bs) = make_uint2(0, 0);
+            *reinterpret_cast<uint2 *>(m_ink) = make_uint2(0, 0);
+            bs_blocks[2 * (kSpanThreads / 64)] = 0;
+            bs_blocks[2 * (kSpanThreads / 64) + 1] = 0;
+        }
+        const uint64_t bsb = __ballot(has_bs != 0);
+        if ((j & 63u) == 0) {
+            bs_blocks[2 * (j >> 6)] = (uint32_t)bsb;
+            bs_blocks[2 * (j >> 6) + 1] = (uint32_t)(bsb >> 32);
+        }
+        __syncthreads();
 #pragma unroll
-    for (int k = 0; k < kSpanPer; k++)
-        if (tok[k] < n) {
-            staged_token(stage, m_num, m_flt, m_bs, m_ink, lo, span, len, start[k], next[k], e[k], f[k]);
-            if (kFused) c[k] = stage[start[k] - lo];
-        }
+        for (int k = 0; k < kSpanPer; k++)
+            if (tok[k] < n) {
+                c[k] = stage[start[k] - lo];
+                staged_token(stage, m_num, m_flt, m_bs, m_ink, bs_blocks, lo, span, len, c[k], start[k], next[k], e[k], f[k]);
+            }
     }
 #pragma unroll
     for (int k = 0; k < kSpanPer; k++)
@@ -928,18 +996,16 @@ __global__ __launch_bounds__(kSpanThreads) void token_spans(const uint8_t *__res
             const bool have = tok[k] < n;
             const int dk = have ? delta_of(c[k]) : 0;
             // deltas are -1 / 0 / +1: the running sum after each lane's token is a difference of two
-            // masked popcounts of ballots; min and max by butterflies
+            // counts of ballot bits below the lane; min and max by DPP row scans (a lane past the last
+            // token repeats the value in front of it: tokens are contiguous)
             const uint64_t ups = __ballot(dk > 0), downs = __ballot(dk < 0);
-            const uint64_t upto = (2ull << lane) - 1ull;  // lanes 0..lane (lane 63: all)
-            const int run = (int)__popcll(ups & upto) - (int)__popcll(downs & upto);
-            int mn = have ? run : kNone, mx = have ? run : -kNone;
-#pragma unroll
-            for (int o = 32; o > 0; o >>= 1) {
-                mn = min(mn, __shfl_xor(mn, o));
-                mx = max(mx, __shfl_xor(mx, o));
-            }
+            const int run = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(ups >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)ups, 0)) -
+                            (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(downs >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)downs, 0)) + dk;
+            int mn, mx;
+            wave_min_max(run, mn, mx);
             if (lane == 0) {
-                wave_agg[k][wave] = Agg{(int32_t)__popcll(ups) - (int32_t)__popcll(downs), mn, mx};
+                const bool any = first + (uint32_t)k * kSpanThreads + 64u * (uint32_t)wave < n;  // this wave's first token exists
+                wave_agg[k][wave] = Agg{(int32_t)__popcll(ups) - (int32_t)__popcll(downs), any ? mn : kNone, any ? mx : -kNone};
                 wave_opens[k][wave] = (int)__popcll(ups);
             }
         }

@@ -54,6 +54,16 @@ void lane_bitplanes(const uint8_t *blk64, uint64_t *planes8) {
     msj::bitplanes(x, planes8);
 }
 
+// digit, sow, backslash, blank masks of one 64-byte block (the span kernel's classes)
+void lane_span_classes(const uint8_t *blk64, uint64_t *out4) {
+    uint32_t x[16];
+    std::memcpy(x, blk64, 64);
+    uint64_t p[8];
+    msj::bitplanes(x, p);
+    msj::SpanClasses c = msj::span_classes(p);
+    out4[0] = c.digit; out4[1] = c.sow; out4[2] = c.backslash; out4[3] = c.blank;
+}
+
 uint32_t lane_top_run(uint64_t m) { return msj::top_run(m); }
 uint64_t lane_prefix_xor(uint64_t m) { return msj::prefix_xor(m); }
 }

@@ -64,6 +64,25 @@ def test_bitplanes_exhaustive(lane):
             assert pl[k] == sum(((b[i] >> k) & 1) << i for i in range(64))
 
 
+def test_span_classes_exhaustive(lane):
+    """the token-span kernel's classes against the reference's tables, every byte value at every position parity"""
+    lane.lane_span_classes.argtypes = [ctypes.c_char_p, ctypes.POINTER(ctypes.c_uint64)]
+    sow = set(b"\t\n\r ,:[]{}")
+    blank = set(b"\t\n\r ")
+    want = lambda b, cls: sum(1 << i for i in range(64) if b[i] in cls)
+    rng = np.random.default_rng(5)
+    blocks = [bytes(range(s, s + 64)) for s in range(0, 256, 64)]
+    blocks += [rng.integers(0, 256, 64, dtype=np.uint8).tobytes() for _ in range(300)]
+    blocks += [bytes(rng.choice(np.frombuffer(b'0123456789-.eE,:[]{}"\\ \t\n\r\x0c\x1a;Z', dtype=np.uint8), 64)) for _ in range(300)]
+    for b in blocks:
+        out = (ctypes.c_uint64 * 4)()
+        lane.lane_span_classes(b, out)
+        assert out[0] == want(b, set(b"0123456789"))
+        assert out[1] == want(b, sow)
+        assert out[2] == want(b, set(b"\\"))
+        assert out[3] == want(b, blank)
+
+
 def test_small_helpers(lane):
     assert lane.lane_top_run(0) == 0
     assert lane.lane_top_run(0xFFFFFFFFFFFFFFFF) == 64
