@@ -845,13 +845,85 @@ __device__ __forceinline__ void staged_token(const uint8_t *stage, const uint32_
     f_out = f;
 }
 
+// bits of m_bs in front of position pos, counted from the start of the 4 KiB the wave that staged pos covers
+// (bs_cnt: set bits in front of each 32-bit word, per wave)
+__device__ __forceinline__ uint32_t bs_before(const uint32_t *m_bs, const uint16_t *bs_cnt, uint32_t pos) {
+    const uint32_t w = (pos >> 5) + kSpanMapFront;
+    return (uint32_t)bs_cnt[w] + (uint32_t)__popc(m_bs[w] & ((1u << (pos & 31u)) - 1u));
+}
+
+// staged_token without a loop or a branch: every window is read once and both kinds of token are worked out
+// for every lane (a wave holds strings and numbers anyway).  Returns false where one round was not enough -- a
+// window came up empty, or a string body crosses the 4 KiB one wave counted backslashes over: such a lane
+// takes staged_token.  Positions relative to lo, 32 bits throughout (a segment is < 4 GiB).
+__device__ __forceinline__ bool staged_token_fast(const uint8_t *stage, const uint32_t *m_num, const uint32_t *m_flt, const uint32_t *m_bs,
+                                                  const uint16_t *bs_cnt, const uint32_t *m_ink, uint32_t lo, uint32_t span, uint32_t len,
+                                                  uint32_t c, uint32_t rs, uint32_t rn, uint32_t &e_out, uint32_t &f_out) {
+    const uint32_t rlen = min(len - lo, span);  // end of the buffer within the stretch
+    const bool is_str = c == '"';
+    const bool is_num = c == '-' || c - '0' < 10u;
+    // ---- string: behind the last non-blank byte in front of the next structural (the byte at rs is not blank, so
+    // a window that reaches rs is never empty; one that does not and is empty needs another round)
+    const uint32_t vi = bits_before(m_ink, rn);
+    const uint32_t q = (uint32_t)max((int)rn - __clz(vi), (int)rs + 1);
+    const bool more_ink = vi == 0 && rn - rs > 33u;
+    const bool isq = q > rs + 1u && stage[q - 1u] == '"';
+    const uint32_t vb = ~bits_before(m_bs, q - 1u);  // backslashes right in front of that quote
+    const bool closed = isq && ((uint32_t)__clz(vb) & 1u) == 0;
+    const bool more_bs = isq && vb == 0;
+    const uint32_t b0 = rs + 1u, close = q - 1u;  // body = [b0, close)
+    const bool esc = bs_before(m_bs, bs_cnt, close) != bs_before(m_bs, bs_cnt, b0);
+    const bool far = closed && (b0 >> 12) != (close >> 12);
+    const bool lng = close - b0 > kSpanCap;
+    const uint32_t f_str = MSJ_SPAN_STRING | (closed ? (lng ? MSJ_SPAN_LONG : (esc ? MSJ_SPAN_ESCAPED : 0u)) : MSJ_SPAN_OPEN);
+    const uint32_t e_str = closed ? lo + close : len;
+    // ---- number: parse_number's scan (include/generic/number_parsing.mojo:41-59), see staged_token
+    const uint32_t stop = min(rs + 1u + kSpanCap, rlen);
+    const uint32_t p0 = rs + (c == '-' ? 1u : 0u);
+    const uint32_t wn = ~bits_at(m_num, p0);
+    const uint32_t p = min(p0 + min((uint32_t)(__ffs(wn) - 1), 32u), stop);
+    const bool more_num = wn == 0 && p0 + 32u < stop;
+    const bool ends = p < stop || lo + p == len;
+    const uint32_t ch = p < rlen ? (uint32_t)stage[p] : 0x20u;
+    const bool flt = ends && (ch == '.' || (ch | 0x20u) == 'e');
+    const uint32_t wf = bits_at(m_flt, p);
+    const bool bad = ends && !flt && p < rlen && !(wf & 1u);
+    const uint32_t pe = flt ? min(p + min((uint32_t)(__ffs(wf) - 1), 32u), stop) : p;
+    const bool more_flt = flt && wf == 0 && p + 32u < stop;
+    const bool lng_num = pe == stop && lo + stop < len;  // kSpanCap characters and still no end
+    const uint32_t f_num = MSJ_SPAN_NUMBER | (flt ? MSJ_SPAN_FLOAT : 0u) | (lng_num ? MSJ_SPAN_LONG : (bad ? MSJ_SPAN_BAD : 0u));
+    const uint32_t e_num = lng_num ? 0u : lo + pe;
+    e_out = is_str ? e_str : (is_num ? e_num : 0u);
+    f_out = is_str ? f_str : (is_num ? f_num : 0u);
+    return !(is_str ? (more_ink || more_bs || far) : (is_num && (more_num || more_flt)));
+}
+
+// inclusive prefix sum over the wave, the same six DPP steps
+__device__ __forceinline__ uint32_t wave_incl_sum(uint32_t x) {
+    asm volatile(
+        "s_nop 1\n\t"
+        "v_add_u32_dpp %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\t"
+        "v_add_u32_dpp %0, %0, %0 row_shr:2 row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\t"
+        "v_add_u32_dpp %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\t"
+        "v_add_u32_dpp %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\t"
+        "v_add_u32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+        "s_nop 1\n\t"
+        "v_add_u32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"
+        "s_nop 1"
+        : "+v"(x));
+    return x;
+}
 // minimum and maximum over the wave, by DPP: an inclusive scan inside each row of 16 lanes (row_shr 1, 2, 4, 8),
 // then the last lane of a row into the next row (row_bcast:15, rows 1 and 3) and lane 31 into rows 2 and 3
 // (row_bcast:31); lane 63 holds the result.  A lane without a source lane keeps its value (the instruction is
 // off for it).  One instruction per step and value; a DPP read needs two wait states after the write of its
 // source, which the other chain and an s_nop provide.
-__device__ __forceinline__ void wave_min_max(int x, int &mn_out, int &mx_out) {
-    int mn = x, mx = x;
+__device__ __forceinline__ void wave_min_max(int lo, int hi, int &mn_out, int &mx_out) {  // min over lo, max over hi
+    int mn = lo, mx = hi;
     asm volatile(
         "s_nop 1\n\t"
         "v_min_i32_dpp %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
@@ -883,40 +955,50 @@ template <bool kFused>
 __global__ __launch_bounds__(kSpanThreads) void token_spans(const uint8_t *__restrict__ buf, uint64_t len, const uint32_t *__restrict__ idx,
                                                            uint64_t n, uint32_t *__restrict__ end, uint8_t *__restrict__ flags, uint32_t lds_limit,
                                                            uint8_t *__restrict__ type, int4 *__restrict__ sub_agg) {
-    __shared__ __attribute__((aligned(16))) uint8_t stage[kSpanLds];
+    __shared__ __attribute__((aligned(16))) uint8_t stage[kSpanLds + 16];  // a number may be asked for the byte behind the stretch
     __shared__ __attribute__((aligned(8))) uint32_t m_num[kSpanMapWords], m_flt[kSpanMapWords], m_bs[kSpanMapWords], m_ink[kSpanMapWords];
+    __shared__ __attribute__((aligned(4))) uint16_t bs_cnt[kSpanMapWords];  // set bits of m_bs in front of each word, from the wave's first block
     __shared__ uint32_t bs_blocks[2 * (kSpanThreads / 64) + 2];  // bit b: block b of the stretch holds a backslash
     const uint64_t first = (uint64_t)blockIdx.x * kSpanTokens;
-    uint64_t tok[kSpanPer];  // this thread's tokens: threadIdx.x, threadIdx.x + kSpanThreads, ...
-#pragma unroll
-    for (int k = 0; k < kSpanPer; k++) tok[k] = first + threadIdx.x + (uint32_t)k * kSpanThreads;
+    // this thread's tokens: two neighbours.  In a valid document a scalar is followed by an operator, so at most one
+    // of the two is a string or a number and ONE evaluation serves the pair (two scalars in a row: a second one).
+    const uint64_t tok0 = first + 2u * threadIdx.x;
+    const bool have0 = tok0 < n, have1 = tok0 + 1 < n;
     const uint64_t after = first + kSpanTokens < n ? first + kSpanTokens : n;  // first token of the next workgroup
     // uniform: the stretch [lo, hi) -- through the byte at the next workgroup's first structural
     const uint64_t lo = (uint64_t)idx[first] & ~63ull;
     const uint64_t hi = after < n ? (uint64_t)idx[after] + 1u : len;
     const uint64_t hi_al = (hi + 63u) & ~63ull;
-    // this thread's tokens, requested together with the stretch bounds (not behind the barrier below)
-    uint64_t start[kSpanPer], next[kSpanPer];
-#pragma unroll
-    for (int k = 0; k < kSpanPer; k++) {
-        start[k] = tok[k] < n ? (uint64_t)idx[tok[k]] : 0;
-        next[k] = (tok[k] + 1 < n) ? (uint64_t)idx[tok[k] + 1] : len;
+    // requested together with the stretch bounds (not behind the barrier below)
+    const bool wide = ((reinterpret_cast<uintptr_t>(idx) | reinterpret_cast<uintptr_t>(end)) & 7u) == 0 &&
+                      ((reinterpret_cast<uintptr_t>(flags) | reinterpret_cast<uintptr_t>(type)) & 1u) == 0;  // uniform
+    uint64_t start0 = 0, start1 = 0;
+    if (have1 && wide) {
+        const uint2 v = *reinterpret_cast<const uint2 *>(idx + tok0);
+        start0 = v.x, start1 = v.y;
+    } else if (have0) {
+        start0 = idx[tok0];
+        start1 = have1 ? (uint64_t)idx[tok0 + 1] : 0;
     }
+    const uint64_t next1 = tok0 + 2 < n ? (uint64_t)idx[tok0 + 2] : len;
+    const uint64_t next0 = have1 ? start1 : len;
     const bool staged = hi_al - lo <= lds_limit;  // lds_limit <= kSpanLds; uniform
-    uint32_t e[kSpanPer], f[kSpanPer], c[kSpanPer];
+    uint32_t e0 = 0, f0 = 0, c0 = 0, e1 = 0, f1 = 0, c1 = 0;
     if (!staged) {
-#pragma unroll
-        for (int k = 0; k < kSpanPer; k++) {
-            if (tok[k] < n) {
-                span_of(FromGlobal{buf, len}, start[k], next[k], len, e[k], f[k]);
-                if (kFused) c[k] = buf[start[k]];
-            }
+        if (have0) {
+            span_of(FromGlobal{buf, len}, start0, next0, len, e0, f0);
+            if (kFused) c0 = buf[start0];
+        }
+        if (have1) {
+            span_of(FromGlobal{buf, len}, start1, next1, len, e1, f1);
+            if (kFused) c1 = buf[start1];
         }
     } else {
         const uint32_t span = (uint32_t)(hi_al - lo);
         const uint32_t nblk = span >> 6;  // <= kSpanBlocks: lane j stages and classifies block j
         const uint32_t j = threadIdx.x;
         uint64_t has_bs = 0;
+        uint32_t bs_lo = 0, bs_all = 0;  // backslashes in the low word / in all of this lane's block
         if (j < nblk) {
             const uint64_t g = lo + 64u * j;
             uint32_t x[16];
@@ -950,6 +1032,8 @@ __global__ __launch_bounds__(kSpanThreads) void token_spans(const uint8_t *__res
             *reinterpret_cast<uint2 *>(m_bs + w) = make_uint2((uint32_t)cl.backslash, (uint32_t)(cl.backslash >> 32));
             *reinterpret_cast<uint2 *>(m_ink + w) = make_uint2((uint32_t)~cl.blank, (uint32_t)(~cl.blank >> 32));
             has_bs = cl.backslash;
+            bs_lo = __popc((uint32_t)cl.backslash);
+            bs_all = bs_lo + __popc((uint32_t)(cl.backslash >> 32));
         } else if (j < nblk + 2u) {  // zero words behind the maps
             const uint32_t w = kSpanMapFront + 2u * j;
             *reinterpret_cast<uint2 *>(m_num + w) = make_uint2(0, 0);
@@ -965,61 +1049,81 @@ __global__ __launch_bounds__(kSpanThreads) void token_spans(const uint8_t *__res
             bs_blocks[2 * (kSpanThreads / 64)] = 0;
             bs_blocks[2 * (kSpanThreads / 64) + 1] = 0;
         }
+        {   // all lanes: blocks in front of this lane's, within the wave
+            const uint32_t upto = wave_incl_sum(bs_all) - bs_all;
+            if (j < nblk + 2u)
+                *reinterpret_cast<uint32_t *>(bs_cnt + kSpanMapFront + 2u * j) = upto | ((upto + bs_lo) << 16);
+            if (j == kSpanThreads - 1) *reinterpret_cast<uint32_t *>(bs_cnt) = 0;
+        }
         const uint64_t bsb = __ballot(has_bs != 0);
         if ((j & 63u) == 0) {
             bs_blocks[2 * (j >> 6)] = (uint32_t)bsb;
             bs_blocks[2 * (j >> 6) + 1] = (uint32_t)(bsb >> 32);
         }
         __syncthreads();
-#pragma unroll
-        for (int k = 0; k < kSpanPer; k++)
-            if (tok[k] < n) {
-                c[k] = stage[start[k] - lo];
-                staged_token(stage, m_num, m_flt, m_bs, m_ink, bs_blocks, lo, span, len, c[k], start[k], next[k], e[k], f[k]);
+        if (have0) {
+            const uint32_t lo32 = (uint32_t)lo, len32 = (uint32_t)len;
+            const uint32_t rs0 = (uint32_t)(start0 - lo), rn0 = (uint32_t)(next0 - lo);
+            const uint32_t rs1 = have1 ? (uint32_t)(start1 - lo) : rs0, rn1 = have1 ? (uint32_t)(next1 - lo) : rn0;
+            c0 = stage[rs0];
+            c1 = have1 ? (uint32_t)stage[rs1] : 0u;
+            const bool s0 = c0 == '"' || c0 == '-' || c0 - '0' < 10u;            // a string or a number: something to work out
+            const bool s1 = have1 && (c1 == '"' || c1 == '-' || c1 - '0' < 10u);
+            const uint32_t cs = s0 ? c0 : c1, rs = s0 ? rs0 : rs1, rn = s0 ? rn0 : rn1;
+            uint32_t e, f;
+            if (!staged_token_fast(stage, m_num, m_flt, m_bs, bs_cnt, m_ink, lo32, span, len32, cs, rs, rn, e, f))
+                staged_token(stage, m_num, m_flt, m_bs, m_ink, bs_blocks, lo, span, len, cs, lo + rs, lo + rn, e, f);
+            e0 = s0 ? e : 0u, f0 = s0 ? f : 0u;
+            e1 = s0 ? 0u : e, f1 = s0 ? 0u : f;
+            if (s0 && s1) {  // two scalars in a row (not a valid document)
+                if (!staged_token_fast(stage, m_num, m_flt, m_bs, bs_cnt, m_ink, lo32, span, len32, c1, rs1, rn1, e1, f1))
+                    staged_token(stage, m_num, m_flt, m_bs, m_ink, bs_blocks, lo, span, len, c1, start1, next1, e1, f1);
             }
-    }
-#pragma unroll
-    for (int k = 0; k < kSpanPer; k++)
-        if (tok[k] < n) {
-            end[tok[k]] = e[k];
-            flags[tok[k]] = (uint8_t)f[k];
-            if (kFused) type[tok[k]] = (uint8_t)c[k];
         }
+    }
+    if (have1 && wide) {
+        *reinterpret_cast<uint2 *>(end + tok0) = make_uint2(e0, e1);
+        *reinterpret_cast<uint16_t *>(flags + tok0) = (uint16_t)(f0 | (f1 << 8));
+        if (kFused) *reinterpret_cast<uint16_t *>(type + tok0) = (uint16_t)(c0 | (c1 << 8));
+    } else if (have0) {
+        end[tok0] = e0;
+        flags[tok0] = (uint8_t)f0;
+        if (kFused) type[tok0] = (uint8_t)c0;
+        if (have1) {
+            end[tok0 + 1] = e1;
+            flags[tok0 + 1] = (uint8_t)f1;
+            if (kFused) type[tok0 + 1] = (uint8_t)c1;
+        }
+    }
     if (kFused) {
-        // ordered reduction of the running-depth monoid over the workgroup's tokens: thread t holds tokens t
-        // and t + kSpanThreads, so the order is (k = 0: waves 0..3), (k = 1: waves 0..3)
-        __shared__ Agg wave_agg[kSpanPer][kSpanThreads / 64];
-        __shared__ int wave_opens[kSpanPer][kSpanThreads / 64];
+        // ordered reduction of the running-depth monoid over the workgroup's tokens: lane t holds tokens 2t and
+        // 2t + 1.  Deltas are -1 / 0 / +1, so the running sum in front of a lane is four counts of ballot bits
+        // below it; min and max by DPP row scans (a lane past the last token repeats the value in front of it:
+        // tokens are contiguous)
+        __shared__ Agg wave_agg[kSpanThreads / 64];
+        __shared__ int wave_opens[kSpanThreads / 64];
         const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-#pragma unroll
-        for (int k = 0; k < kSpanPer; k++) {
-            const bool have = tok[k] < n;
-            const int dk = have ? delta_of(c[k]) : 0;
-            // deltas are -1 / 0 / +1: the running sum after each lane's token is a difference of two
-            // counts of ballot bits below the lane; min and max by DPP row scans (a lane past the last
-            // token repeats the value in front of it: tokens are contiguous)
-            const uint64_t ups = __ballot(dk > 0), downs = __ballot(dk < 0);
-            const int run = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(ups >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)ups, 0)) -
-                            (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(downs >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)downs, 0)) + dk;
-            int mn, mx;
-            wave_min_max(run, mn, mx);
-            if (lane == 0) {
-                const bool any = first + (uint32_t)k * kSpanThreads + 64u * (uint32_t)wave < n;  // this wave's first token exists
-                wave_agg[k][wave] = Agg{(int32_t)__popcll(ups) - (int32_t)__popcll(downs), any ? mn : kNone, any ? mx : -kNone};
-                wave_opens[k][wave] = (int)__popcll(ups);
-            }
+        const int d0 = have0 ? delta_of(c0) : 0, d1 = have1 ? delta_of(c1) : 0;
+        const uint64_t up0 = __ballot(d0 > 0), dn0 = __ballot(d0 < 0), up1 = __ballot(d1 > 0), dn1 = __ballot(d1 < 0);
+        const auto below = [](uint64_t m) { return (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0)); };
+        const int r0 = below(up0) + below(up1) - below(dn0) - below(dn1) + d0, r1 = r0 + d1;  // after token 2t / 2t + 1
+        int mn, mx;
+        wave_min_max(min(r0, r1), max(r0, r1), mn, mx);
+        if (lane == 0) {
+            const bool any = first + 128u * (uint32_t)wave < n;  // this wave's first token exists
+            const int ups = (int)__popcll(up0) + (int)__popcll(up1), downs = (int)__popcll(dn0) + (int)__popcll(dn1);
+            wave_agg[wave] = Agg{ups - downs, any ? mn : kNone, any ? mx : -kNone};
+            wave_opens[wave] = ups;
         }
         __syncthreads();
         if (threadIdx.x == 0) {
             Agg t = {0, kNone, -kNone};
             int no = 0;
 #pragma unroll
-            for (int k = 0; k < kSpanPer; k++)
-#pragma unroll
-                for (int w = 0; w < (int)kSpanThreads / 64; w++) {
-                    t = combine(t, wave_agg[k][w]);
-                    no += wave_opens[k][w];
-                }
+            for (int w = 0; w < (int)kSpanThreads / 64; w++) {
+                t = combine(t, wave_agg[w]);
+                no += wave_opens[w];
+            }
             sub_agg[blockIdx.x] = make_int4(t.sum, t.mn, t.mx, no);
         }
     }
