@@ -609,7 +609,7 @@ int32_t msj_token_spans_device(msj_ctx *ctx, const uint8_t *d_buf, uint64_t len,
                                uint32_t *d_end, uint8_t *d_flags, void *stream) {
     if (!ctx) return MSJ_ERR_BAD_ARGUMENT;
     if (n > 0 && (!d_buf || !d_idx || !d_end || !d_flags)) return MSJ_ERR_BAD_ARGUMENT;
-    if (len > MSJ_MAX_SEGMENT_BYTES) return MSJ_CAPACITY;
+    if (len > MSJ_MAX_SEGMENT_BYTES || n >= (1ull << 31)) return MSJ_CAPACITY;
     if (!hip_ok(hipSetDevice(ctx->device))) return MSJ_ERR_HIP;
     return msj_launch_token_spans(d_buf, len, d_idx, n, d_end, d_flags, stream) == 0 ? MSJ_SUCCESS : MSJ_ERR_HIP;
 }

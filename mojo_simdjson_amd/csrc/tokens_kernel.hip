@@ -25,6 +25,10 @@
 #include "../../include/msj_stage1.h"
 #include "lane_math.h"
 
+#ifndef MSJ_SPAN_ABLATE
+#define MSJ_SPAN_ABLATE 0  // diagnostic builds: 1 no token evaluation, 2 no depth aggregates, 3 no bit-plane transpose (wrong results)
+#endif
+
 namespace msj_tokens {
 
 constexpr int kThreads = 256;
@@ -959,32 +963,36 @@ __global__ __launch_bounds__(kSpanThreads) void token_spans(const uint8_t *__res
     __shared__ __attribute__((aligned(8))) uint32_t m_num[kSpanMapWords], m_flt[kSpanMapWords], m_bs[kSpanMapWords], m_ink[kSpanMapWords];
     __shared__ __attribute__((aligned(4))) uint16_t bs_cnt[kSpanMapWords];  // set bits of m_bs in front of each word, from the wave's first block
     __shared__ uint32_t bs_blocks[2 * (kSpanThreads / 64) + 2];  // bit b: block b of the stretch holds a backslash
-    const uint64_t first = (uint64_t)blockIdx.x * kSpanTokens;
+    const uint32_t nt = (uint32_t)n;  // n < 2^31 (msj_token_spans_device)
+    const uint32_t first = blockIdx.x * kSpanTokens;
     // this thread's tokens: two neighbours.  In a valid document a scalar is followed by an operator, so at most one
     // of the two is a string or a number and ONE evaluation serves the pair (two scalars in a row: a second one).
-    const uint64_t tok0 = first + 2u * threadIdx.x;
-    const bool have0 = tok0 < n, have1 = tok0 + 1 < n;
-    const uint64_t after = first + kSpanTokens < n ? first + kSpanTokens : n;  // first token of the next workgroup
+    const uint32_t tok0 = first + 2u * threadIdx.x;
+    // uniform: every lane has both tokens and a structural behind them, and the arrays take two tokens per access
+    const bool full = first + kSpanTokens < nt && (reinterpret_cast<uintptr_t>(end) & 7u) == 0 &&
+                      ((reinterpret_cast<uintptr_t>(flags) | reinterpret_cast<uintptr_t>(type)) & 1u) == 0;
+    const bool have0 = full || tok0 < nt, have1 = full || tok0 + 1 < nt;
+    // Every load below is unconditional (indices clamped to the last token, the value dropped afterwards): the
+    // requests for the stretch bounds, for this thread's tokens and -- next -- for the bytes are in flight together
+    // instead of one round trip after the other.
+    const uint32_t last = nt - 1u;  // nt >= 1: the kernel is not launched for an empty index
+    const bool more = first + kSpanTokens < nt;  // a workgroup follows
     // uniform: the stretch [lo, hi) -- through the byte at the next workgroup's first structural
-    const uint64_t lo = (uint64_t)idx[first] & ~63ull;
-    const uint64_t hi = after < n ? (uint64_t)idx[after] + 1u : len;
+    const uint32_t i_lo = idx[first], i_hi = idx[min(first + kSpanTokens, last)];
+    uint32_t i0 = idx[min(tok0, last)], i1 = idx[min(tok0 + 1u, last)], i2 = idx[min(tok0 + 2u, last)];
+    const uint64_t lo = (uint64_t)i_lo & ~63ull;
+    const uint64_t hi = more ? (uint64_t)i_hi + 1u : len;
     const uint64_t hi_al = (hi + 63u) & ~63ull;
-    // requested together with the stretch bounds (not behind the barrier below)
-    const bool wide = ((reinterpret_cast<uintptr_t>(idx) | reinterpret_cast<uintptr_t>(end)) & 7u) == 0 &&
-                      ((reinterpret_cast<uintptr_t>(flags) | reinterpret_cast<uintptr_t>(type)) & 1u) == 0;  // uniform
-    uint64_t start0 = 0, start1 = 0;
-    if (have1 && wide) {
-        const uint2 v = *reinterpret_cast<const uint2 *>(idx + tok0);
-        start0 = v.x, start1 = v.y;
-    } else if (have0) {
-        start0 = idx[tok0];
-        start1 = have1 ? (uint64_t)idx[tok0 + 1] : 0;
-    }
-    const uint64_t next1 = tok0 + 2 < n ? (uint64_t)idx[tok0 + 2] : len;
-    const uint64_t next0 = have1 ? start1 : len;
+    // (the token offsets are first looked at behind MSJ_SPAN_ARRIVED: nothing waits for them before the bytes are asked for)
+#define MSJ_SPAN_ARRIVED()                                     \
+    asm volatile("" : "+v"(i0), "+v"(i1), "+v"(i2));           \
+    const uint64_t start0 = have0 ? i0 : 0u, start1 = have1 ? i1 : 0u; \
+    const uint64_t next1 = (full || tok0 + 2u < nt) ? (uint64_t)i2 : len; \
+    const uint64_t next0 = have1 ? start1 : len
     const bool staged = hi_al - lo <= lds_limit;  // lds_limit <= kSpanLds; uniform
     uint32_t e0 = 0, f0 = 0, c0 = 0, e1 = 0, f1 = 0, c1 = 0;
     if (!staged) {
+        MSJ_SPAN_ARRIVED();
         if (have0) {
             span_of(FromGlobal{buf, len}, start0, next0, len, e0, f0);
             if (kFused) c0 = buf[start0];
@@ -1024,7 +1032,11 @@ __global__ __launch_bounds__(kSpanThreads) void token_spans(const uint8_t *__res
             for (int q = 0; q < 4; q++)
                 *reinterpret_cast<uint4 *>(stage + 64u * j + 16 * q) = make_uint4(x[4 * q], x[4 * q + 1], x[4 * q + 2], x[4 * q + 3]);
             uint64_t pl[8];
+#if MSJ_SPAN_ABLATE == 3
+            for (int q = 0; q < 8; q++) pl[q] = x[q] | ((uint64_t)x[q + 8] << 32);
+#else
             msj::bitplanes(x, pl);
+#endif
             const msj::SpanClasses cl = msj::span_classes(pl);
             const uint32_t w = kSpanMapFront + 2u * j;
             *reinterpret_cast<uint2 *>(m_num + w) = make_uint2((uint32_t)cl.digit, (uint32_t)(cl.digit >> 32));
@@ -1060,7 +1072,14 @@ __global__ __launch_bounds__(kSpanThreads) void token_spans(const uint8_t *__res
             bs_blocks[2 * (j >> 6)] = (uint32_t)bsb;
             bs_blocks[2 * (j >> 6) + 1] = (uint32_t)(bsb >> 32);
         }
+        MSJ_SPAN_ARRIVED();
         __syncthreads();
+#if MSJ_SPAN_ABLATE == 1
+        if (have0) {
+            c0 = stage[(uint32_t)(start0 - lo)];
+            c1 = have1 ? (uint32_t)stage[(uint32_t)(start1 - lo)] : 0u;
+        } else
+#endif
         if (have0) {
             const uint32_t lo32 = (uint32_t)lo, len32 = (uint32_t)len;
             const uint32_t rs0 = (uint32_t)(start0 - lo), rn0 = (uint32_t)(next0 - lo);
@@ -1081,7 +1100,7 @@ __global__ __launch_bounds__(kSpanThreads) void token_spans(const uint8_t *__res
             }
         }
     }
-    if (have1 && wide) {
+    if (full) {
         *reinterpret_cast<uint2 *>(end + tok0) = make_uint2(e0, e1);
         *reinterpret_cast<uint16_t *>(flags + tok0) = (uint16_t)(f0 | (f1 << 8));
         if (kFused) *reinterpret_cast<uint16_t *>(type + tok0) = (uint16_t)(c0 | (c1 << 8));
@@ -1095,7 +1114,7 @@ __global__ __launch_bounds__(kSpanThreads) void token_spans(const uint8_t *__res
             if (kFused) type[tok0 + 1] = (uint8_t)c1;
         }
     }
-    if (kFused) {
+    if (kFused && MSJ_SPAN_ABLATE != 2) {
         // ordered reduction of the running-depth monoid over the workgroup's tokens: lane t holds tokens 2t and
         // 2t + 1.  Deltas are -1 / 0 / +1, so the running sum in front of a lane is four counts of ballot bits
         // below it; min and max by DPP row scans (a lane past the last token repeats the value in front of it:
@@ -1110,7 +1129,7 @@ __global__ __launch_bounds__(kSpanThreads) void token_spans(const uint8_t *__res
         int mn, mx;
         wave_min_max(min(r0, r1), max(r0, r1), mn, mx);
         if (lane == 0) {
-            const bool any = first + 128u * (uint32_t)wave < n;  // this wave's first token exists
+            const bool any = first + 128u * (uint32_t)wave < nt;  // this wave's first token exists
             const int ups = (int)__popcll(up0) + (int)__popcll(up1), downs = (int)__popcll(dn0) + (int)__popcll(dn1);
             wave_agg[wave] = Agg{ups - downs, any ? mn : kNone, any ? mx : -kNone};
             wave_opens[wave] = ups;
@@ -1128,6 +1147,8 @@ __global__ __launch_bounds__(kSpanThreads) void token_spans(const uint8_t *__res
         }
     }
 }
+
+#undef MSJ_SPAN_ARRIVED
 
 // block aggregates of the token pre-pass (kBlock tokens) from those of the fused kernel (kSpanTokens tokens)
 static_assert(kBlock % kSpanTokens == 0, "a block of the depth pass is a whole number of span workgroups");
