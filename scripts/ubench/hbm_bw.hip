@@ -40,6 +40,22 @@ __global__ __launch_bounds__(256) void k_mix(const u32x4 *__restrict__ in, u32x4
     }
 }
 
+// the same with plain (temporal) loads and stores / plain loads and non-temporal stores
+template <bool kNtLoad, bool kNtStore>
+__global__ __launch_bounds__(256) void k_mix_t(const u32x4 *__restrict__ in, u32x4 *__restrict__ out, size_t n16,
+                                               unsigned num, unsigned den) {
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += stride) {
+        u32x4 v = kNtLoad ? __builtin_nontemporal_load(in + i) : in[i];
+        const size_t blk = i / den;
+        const unsigned r = (unsigned)(i % den);
+        if (r < num) {
+            if (kNtStore) __builtin_nontemporal_store(v, out + blk * num + r);
+            else out[blk * num + r] = v;
+        }
+    }
+}
+
 // read n16 quads; write every quad `mult` times (mult coalesced output streams): the write-heavy mixes of the
 // dense extremes of config 4 (4 bytes out per structural: d = 0.5 -> 2 bytes out per byte in, d = 1 -> 4)
 __global__ __launch_bounds__(256) void k_expand(const u32x4 *__restrict__ in, u32x4 *__restrict__ out, size_t n16, unsigned mult) {
@@ -81,6 +97,12 @@ int main() {
             timeit(nm, 2.0 * n, [&] { hipLaunchKernelGGL(k_mix, dim3(wgs), dim3(256), 0, 0, a, b, n16, 1u, 1u); });
             snprintf(nm, sizeof nm, "mix 31/40 grid %d (1.775N)", wgs);
             timeit(nm, 1.775 * n, [&] { hipLaunchKernelGGL(k_mix, dim3(wgs), dim3(256), 0, 0, a, b, n16, 31u, 40u); });
+        }
+        for (int rep = 0; rep < 2; rep++) {
+            timeit("mix 31/40 g8192 plain ld, plain st", 1.775 * n, [&] { hipLaunchKernelGGL((k_mix_t<false, false>), dim3(8192), dim3(256), 0, 0, a, b, n16, 31u, 40u); });
+            timeit("mix 31/40 g8192 plain ld, nt st", 1.775 * n, [&] { hipLaunchKernelGGL((k_mix_t<false, true>), dim3(8192), dim3(256), 0, 0, a, b, n16, 31u, 40u); });
+            timeit("mix 31/40 g8192 nt ld, plain st", 1.775 * n, [&] { hipLaunchKernelGGL((k_mix_t<true, false>), dim3(8192), dim3(256), 0, 0, a, b, n16, 31u, 40u); });
+            timeit("mix 31/40 g8192 nt ld, nt st", 1.775 * n, [&] { hipLaunchKernelGGL((k_mix_t<true, true>), dim3(8192), dim3(256), 0, 0, a, b, n16, 31u, 40u); });
         }
         timeit("hipMemcpyDtoD (2N bytes)", 2.0 * n, [&] { CK(hipMemcpyAsync(b, a, n, hipMemcpyDeviceToDevice, 0)); });
         if (gib == 1) {

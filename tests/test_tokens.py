@@ -243,6 +243,13 @@ def test_token_spans(dev, lds_limit, monkeypatch):
     # a long string in the middle of many short tokens: its workgroup reads from global memory, the others stage
     _check_spans(dev, b"[" + b'"a\\b",12,' * 3000 + b'"' + b"x" * 40000 + b'",' + b'"cd",3.5,' * 3000 + b"0]", "mixed paths")
     _check_spans(dev, b'["a"  ,"b\\"" , "c\\\\"  ]  ', "blanks between the closing quote and the next structural")
+    # what sends a lane from the one-round evaluation to the general loop: more than 32 blanks / backslashes / digits
+    # in a row, a body that crosses the 4 KiB one wave counts backslashes over (with and without an escape in it)
+    _check_spans(dev, b'["x"' + b" " * 33 + b',"y"' + b" " * 32 + b',"z"' + b"\n" * 100 + b', 1' + b" " * 70 + b"]" + b" " * 50,
+                 "long runs of blanks in front of the next structural")
+    for body in (b"a" * 90 + b"\\n" + b"b" * 7, b"a" * 99, b"\\\\" * 17 + b"c" * 65, b"\\" * 33 + b"\\" + b"d"):
+        _check_spans(dev, b"[" + (b'"' + body + b'",') * 700 + b"0]", f"bodies across 4 KiB edges: {body[:12]!r}...")
+    _check_spans(dev, b"[" + b"1" * 40 + b"." + b"5" * 40 + b"e" + b"7" * 40 + b"," + b"-" + b"9" * 33 + b"x]", "long floats")
     # the closing quote is found from the NEXT structural: byte soups (valid or not) must agree with the forward scan
     rng = np.random.default_rng(9)
     alphabets = [b'{}[],: \n"\\ab1', b'""\\\\ a,', b'"abc\\" \t:1e5-', b'"\\" \r\n"x']
@@ -250,6 +257,40 @@ def test_token_spans(dev, lds_limit, monkeypatch):
         a = np.frombuffer(alphabets[k % len(alphabets)], dtype=np.uint8)
         n = int(rng.integers(1, 3000))
         _check_spans(dev, a[rng.integers(0, len(a), n)].tobytes(), f"soup {k}")
+
+
+@pytest.mark.gpu
+def test_token_spans_arrays_off_the_wide_grid(dev):
+    """The kernel writes a pair of tokens per access when the arrays allow it (8-byte aligned ends, 2-byte aligned
+    flags): off that grid, and for odd token counts, it must write the same values one by one."""
+    import torch
+    from mojo_simdjson_amd import synth
+    from mojo_simdjson_amd.device import _ptr
+
+    data = synth.workload("minified", 1 << 20).tobytes() + b' [1, "a\\"b", -2.5e3 ]'
+    d_buf = torch.from_numpy(np.frombuffer(data, dtype=np.uint8).copy()).to(dev.device)
+    d_idx = torch.empty(len(data) + 8, dtype=torch.int32, device=dev.device)
+    d_res = dev.new_carry()
+    dev.index(d_buf, d_idx, d_res)
+    n_all = int(dev.fetch(d_res).count)
+    for n in (n_all, n_all - 1, 513, 512, 2, 1):
+        # the oracle on the whole index array: a token's span does not depend on how many tokens follow it
+        full_e, full_f = helpers.oracle_token_spans(data, d_idx[:n_all].cpu().numpy().view(np.uint32))
+        for end_off, flag_off in ((1, 1), (0, 1), (1, 0), (0, 0)):
+            d_end = torch.full((n + 4,), -1, dtype=torch.int32, device=dev.device)
+            d_flags = torch.full((n + 4,), 0xEE, dtype=torch.uint8, device=dev.device)
+            rc = dev.lib.msj_token_spans_device(dev.ctx, _ptr(d_buf), len(data), _ptr(d_idx), n, _ptr(d_end[end_off:]),
+                                                _ptr(d_flags[flag_off:]), dev._stream())
+            assert rc == 0
+            e = d_end.cpu().numpy().view(np.uint32)
+            f = d_flags.cpu().numpy()
+            # tokens in front of the last one do not depend on n; the last one ends where the buffer ends when n < n_all
+            assert np.array_equal(e[end_off:end_off + n - 1], full_e[:n - 1]), (n, end_off, flag_off)
+            assert np.array_equal(f[flag_off:flag_off + n - 1], full_f[:n - 1]), (n, end_off, flag_off)
+            assert (e[end_off + n:] == 0xFFFFFFFF).all() and (f[flag_off + n:] == 0xEE).all(), "nothing behind the arrays"
+            assert (e[:end_off] == 0xFFFFFFFF).all() and (f[:flag_off] == 0xEE).all(), "nothing in front of the arrays"
+            if n == n_all:
+                assert e[end_off + n - 1] == full_e[n - 1] and f[flag_off + n - 1] == full_f[n - 1]
 
 
 def _check_prep(dev, data, where):
