@@ -13,13 +13,15 @@ INTEGRATION.md included) reaches it; this module only supplies the exchange:
     torch.distributed) handed to ``msj_exchange_rccl``: the library calls ncclAllGather itself, on the
     kernel's stream, over xGMI;
   * backend "gloo" (CPU tests, several ranks sharing one GPU): a callback that moves the 128 bytes
-    through torch.distributed.
+    through torch.distributed -- also what backend "nccl" falls back to (all ranks together, with a line on
+    stderr) when the communicator cannot be had, and what ``MSJ_SHARDED_EXCHANGE=torch`` selects.
 
 No bulk data ever crosses xGMI: input shards are placed on their GPU up front and the index arrays
 stay shard-local.
 """
 import ctypes
 import os
+import sys
 
 import torch
 import torch.distributed as dist
@@ -168,20 +170,24 @@ class ShardedStage1:
         self._tickets = {}
 
     # ---- the exchange
-    def _gloo_allgather(self):
+    def _torch_allgather(self):
+        """The exchange as a callback through torch.distributed: the 128 bytes go through host memory (and, when
+        the process group is RCCL, back through device tensors of torch's).  The CPU tests' and shared-GPU runs'
+        exchange, and the fallback when this module cannot get an RCCL communicator of its own."""
         L = self.dev.lib
         ctx = self.dev.ctx
         group, world = self.group, self.world
+        via = self.dev.device if dist.get_backend(group) == "nccl" else torch.device("cpu")
 
         def allgather(_comm, d_send, d_recv, nbytes, stream):
             try:
                 buf = (ctypes.c_uint8 * nbytes)()
                 if L.msj_copy_to_host(ctx, buf, ctypes.c_void_p(d_send), nbytes, ctypes.c_void_p(stream)) != 0:
                     return -3
-                mine = torch.frombuffer(bytearray(bytes(buf)), dtype=torch.uint8)
-                gathered = torch.empty(world * nbytes, dtype=torch.uint8)
+                mine = torch.frombuffer(bytearray(bytes(buf)), dtype=torch.uint8).to(via)
+                gathered = torch.empty(world * nbytes, dtype=torch.uint8, device=via)
                 dist.all_gather_into_tensor(gathered, mine, group=group)
-                blob = gathered.numpy().tobytes()
+                blob = gathered.cpu().numpy().tobytes()
                 if L.msj_copy_to_device(ctx, ctypes.c_void_p(d_recv), blob, len(blob), ctypes.c_void_p(stream)) != 0:
                     return -3
                 return 0
@@ -195,13 +201,26 @@ class ShardedStage1:
         L.msj_copy_to_host.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint64, ctypes.c_void_p]
         L.msj_copy_to_device.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_char_p, ctypes.c_uint64, ctypes.c_void_p]
         x = MsjExchange()
-        if dist.get_backend(self.group) == "nccl":
-            self._rccl = _rccl_communicator(self.rank, self.world, self.dev.device, self.group)
-            rc = L.msj_exchange_rccl(self._rccl[1], self.rank, self.world, self._rccl[2].encode(), ctypes.byref(x))
-            if rc != 0:
-                raise RuntimeError(f"msj_exchange_rccl failed: {rc}")
-        else:
-            self._cb = self._gloo_allgather()  # keep the callback object alive
+        native = dist.get_backend(self.group) == "nccl" and os.environ.get("MSJ_SHARDED_EXCHANGE", "rccl") != "torch"
+        if native:
+            # every rank must end up with the same kind of exchange: agree on the outcome before using it
+            ok = 1
+            try:
+                self._rccl = _rccl_communicator(self.rank, self.world, self.dev.device, self.group)
+                if L.msj_exchange_rccl(self._rccl[1], self.rank, self.world, self._rccl[2].encode(), ctypes.byref(x)) != 0:
+                    ok = 0
+            except Exception as e:  # noqa: BLE001 -- whatever went wrong, the fallback still stitches
+                print(f"mojo_simdjson_amd.sharded: no RCCL communicator of our own ({e!r})", file=sys.stderr)
+                ok = 0
+            t = torch.tensor([ok], dtype=torch.int32, device=self.dev.device)
+            dist.all_reduce(t, op=dist.ReduceOp.MIN, group=self.group)
+            if int(t.item()) == 0:
+                if self.rank == 0:
+                    print("mojo_simdjson_amd.sharded: falling back to the exchange through torch.distributed", file=sys.stderr)
+                native = False
+        if not native:
+            self._cb = self._torch_allgather()  # keep the callback object alive
+            x = MsjExchange()
             x.comm, x.allgather, x.rank, x.world = None, self._cb, self.rank, self.world
         h = ctypes.c_void_p()
         rc = L.msj_sharded_create(self.dev.ctx, ctypes.byref(x), None, ctypes.byref(h))

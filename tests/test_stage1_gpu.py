@@ -724,7 +724,7 @@ def test_multi_segment_over_4gib(torch_mod, dev, oracle):
     assert tail == [total & 0xFFFFFFFF, total & 0xFFFFFFFF, 0]
 
 
-def _rccl_single_rank_worker(port, q):
+def _rccl_single_rank_worker(port, q, exchange="rccl"):
     """world_size 1 over the real "nccl" (= RCCL) backend: the asynchronous all-gather, the side
     stream and the pinned read-back of ShardedStage1 on the one GPU this box has."""
     import torch
@@ -732,6 +732,7 @@ def _rccl_single_rank_worker(port, q):
 
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
+    os.environ["MSJ_SHARDED_EXCHANGE"] = exchange
     torch.cuda.set_device(0)
     dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
     try:
@@ -759,12 +760,15 @@ def _rccl_single_rank_worker(port, q):
         dist.destroy_process_group()
 
 
-def test_sharded_rccl_plumbing_single_rank(oracle):
+@pytest.mark.parametrize("exchange", ["rccl", "torch"])
+def test_sharded_rccl_plumbing_single_rank(oracle, exchange):
+    """exchange "rccl": the library's own ncclAllGather on a communicator of the module's own; "torch": the
+    fallback the module takes when it cannot get one -- the same 128 bytes through torch.distributed's RCCL group."""
     import multiprocessing as mp
 
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    p = ctx.Process(target=_rccl_single_rank_worker, args=(29500 + (os.getpid() % 400) + 411, q))
+    p = ctx.Process(target=_rccl_single_rank_worker, args=(29500 + (os.getpid() % 400) + 411 + (exchange == "torch"), q, exchange))
     p.start()
     res, got = q.get(timeout=240)
     p.join(timeout=60)
