@@ -73,13 +73,33 @@ struct DomParserImplementation {
         return code;
     }
 
-    void allocate(size_t amount) {  // :85-89
-        structural_indexes.reserve(amount + 3);
-        structural_indexes.assign(amount + 3, 0);
+    // :85-89 -- reserve(amount) + resize(amount, 0) on the list the parser keeps: memory moves only when a document
+    // is larger than any before, resize zero-fills only what it adds.  Where a large list moves it is pinned
+    // (msj_host_register): the indices then come down by DMA straight into it.
+    void allocate(size_t amount) {
+        const size_t want = amount + 3;
+        if (want > structural_indexes.capacity()) {
+            unregister();
+            structural_indexes.reserve(want);
+            if (structural_indexes.capacity() * sizeof(uint32_t) >= kRegisterFromBytes)
+                _registered = msj_host_register(nullptr, structural_indexes.data(), structural_indexes.capacity() * sizeof(uint32_t)) == 0;
+        }
+        structural_indexes.resize(want, 0);
         _capacity = amount;
     }
 
+    ~DomParserImplementation() { unregister(); }
+    DomParserImplementation() = default;
+    DomParserImplementation(const DomParserImplementation &) = delete;
+    DomParserImplementation &operator=(const DomParserImplementation &) = delete;
+
   private:
+    static constexpr size_t kRegisterFromBytes = size_t(64) << 20;
+    void unregister() {
+        if (_registered) (void)msj_host_unregister(nullptr, structural_indexes.data());
+        _registered = false;
+    }
+    bool _registered = false;
     size_t _capacity = 0;
     int _max_depth = 100;  // :39
 };

@@ -144,6 +144,19 @@ int32_t msj_stage1_ctx(msj_ctx *ctx, const uint8_t *buf, uint64_t len, uint32_t 
                        uint32_t flags);
 
 /*
+ * Optional: pin a caller-owned host range once (hipHostRegister) and remember it.  msj_stage1 / msj_stage1_ctx
+ * calls whose input and / or index array lie inside a registered range move that side by DMA straight from / into
+ * the caller's memory instead of staging it through the library's pinned rings (two host copies less per byte).
+ * For buffers the host reuses: the reference allocates structural_indexes once per parser, in allocate()
+ * (include/generic/dom_parser_implementation.mojo:85-89) -- the shim registers it there and unregisters it where the
+ * parser is destroyed.  Pinning costs ~50 us per MiB, once.  The range must stay allocated until
+ * msj_host_unregister (msj_ctx_destroy unregisters what is left).  ctx NULL: the default context of msj_stage1.
+ * Returns MSJ_SUCCESS, MSJ_ERR_BAD_ARGUMENT (null / empty / ptr not the start of a registered range), MSJ_ERR_HIP.
+ */
+int32_t msj_host_register(msj_ctx *ctx, void *ptr, uint64_t bytes);
+int32_t msj_host_unregister(msj_ctx *ctx, void *ptr);
+
+/*
  * msj_stage1_device -- device-resident form (what bench.py times).
  * d_buf: device pointer, 16-byte aligned, len < 2^32 bytes.
  * d_idx: device pointer (16-byte aligned) to idx_capacity uint32 slots.

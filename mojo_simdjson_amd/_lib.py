@@ -135,6 +135,10 @@ def load():
     lib.msj_carry_fetch.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.POINTER(MsjCarry), ctypes.c_void_p]
     lib.msj_debug_set_wait_ticks.restype = ctypes.c_int32
     lib.msj_debug_set_wait_ticks.argtypes = [ctypes.c_void_p, ctypes.c_uint32]
+    lib.msj_host_register.restype = ctypes.c_int32
+    lib.msj_host_register.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint64]
+    lib.msj_host_unregister.restype = ctypes.c_int32
+    lib.msj_host_unregister.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
     lib.msj_fallback_count.restype = ctypes.c_uint64
     lib.msj_fallback_count.argtypes = [ctypes.c_void_p]
     lib.msj_stage1_shard_device.restype = ctypes.c_int32

@@ -68,6 +68,14 @@ struct msj_ctx {
         const msj_carry *d_carry_in; msj_carry *d_carry_out; msj_segment *d_segments; uint32_t max_segments;
         bool has_prefix, is_final, no_emit; uint64_t trailer_len; hipStream_t stream; uint32_t flags;
     } last;
+    struct HostRange { const uint8_t *base; uint64_t bytes; };
+    std::vector<HostRange> pinned;  // msj_host_register: caller-owned host ranges the DMA engines can reach directly
+    bool is_pinned(const void *p, uint64_t n) const {
+        const uint8_t *q = static_cast<const uint8_t *>(p);
+        for (const HostRange &r : pinned)
+            if (q >= r.base && n <= r.bytes && (uint64_t)(q - r.base) <= r.bytes - n) return true;
+        return false;
+    }
     int32_t *tok_ws = nullptr;    // block aggregates of the token pre-pass
     uint64_t tok_ws_bytes = 0;
     uint64_t tok_doc_n = ~0ull;   // the token count whose document aggregates tok_ws holds (~0: none)
@@ -382,6 +390,9 @@ int32_t host_pipeline(msj_ctx *ctx, const uint8_t *buf, uint64_t len, uint32_t *
     auto now = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     const double t_begin = now();
     std::vector<double> t_chunk_done(nchunks, 0.0), t_piece;
+    // msj_host_register: a side whose caller memory is pinned needs no staging
+    const bool in_pinned = P.direct_upload || ctx->is_pinned(buf, len);
+    const bool out_pinned = ctx->is_pinned(idx_out, dev_cap * sizeof(uint32_t));
     // ---- the downloader: follows the chunks' cumulative counts, brings finished indices down in pieces
     int32_t down_rc = MSJ_SUCCESS;
     std::atomic<bool> abort{false};
@@ -402,6 +413,16 @@ int32_t host_pipeline(msj_ctx *ctx, const uint8_t *buf, uint64_t len, uint32_t *
             uint64_t avail = c.count;
             if (last && (c.code == MSJ_SUCCESS || c.code == MSJ_EMPTY || c.code == MSJ_UTF8_ERROR)) avail += 3;  // the trailer
             if (avail > dev_cap) avail = dev_cap;
+            if (out_pinned) {  // the caller's array is pinned: one DMA per chunk straight into it, nothing to wait for here
+                if (avail > sent &&
+                    !hip_ok(hipMemcpyAsync(idx_out + sent, ctx->d_idx + sent, (avail - sent) * sizeof(uint32_t), hipMemcpyDeviceToHost, P.s_down))) {
+                    down_rc = MSJ_ERR_HIP;
+                    break;
+                }
+                sent = avail;
+                if (trace) t_piece.push_back(now() - t_begin);
+                continue;
+            }
             const uint64_t piece = HostPipe::kPiece / sizeof(uint32_t);
             while (avail - sent >= piece || (last && sent < avail)) {
                 const uint64_t n = avail - sent < piece ? avail - sent : piece;
@@ -422,6 +443,7 @@ int32_t host_pipeline(msj_ctx *ctx, const uint8_t *buf, uint64_t len, uint32_t *
             if (down_rc != MSJ_SUCCESS) break;
         }
         for (auto &c : copying) CopyPool::wait(&c);
+        if (out_pinned && !hip_ok(hipStreamSynchronize(P.s_down))) down_rc = MSJ_ERR_HIP;
     });
 
     // ---- the uploader (this thread): pinned staging, H2D, one shard launch per chunk
@@ -431,8 +453,8 @@ int32_t host_pipeline(msj_ctx *ctx, const uint8_t *buf, uint64_t len, uint32_t *
         const uint64_t off = k * chunk, n = len - off < chunk ? len - off : chunk;
         const int slot = (int)(k % HostPipe::kInSlots);
         double t0 = now();
-        if (P.direct_upload) {
-            // the runtime's own pageable copy (it pins the pages in flight): no staging copy of ours
+        if (in_pinned) {
+            // the caller's pages are pinned (or MSJ_PIPE_DIRECT_UPLOAD: the runtime pins them in flight): no staging copy of ours
             if (!hip_ok(hipMemcpyAsync(ctx->d_in + off, buf + off, n, hipMemcpyHostToDevice, P.s_up))) rc = MSJ_ERR_HIP;
             t_copy += now() - t0;
         } else {
@@ -543,6 +565,7 @@ void msj_ctx_destroy(msj_ctx *ctx) {
     if (ctx->d_idx) (void)hipFree(ctx->d_idx);
     if (ctx->d_result) (void)hipFree(ctx->d_result);
     delete ctx->pipe;
+    for (const msj_ctx::HostRange &r : ctx->pinned) (void)hipHostUnregister(const_cast<uint8_t *>(r.base));
     if (ctx->h_pin) (void)hipHostFree(ctx->h_pin);
     if (ctx->d_small) (void)hipFree(ctx->d_small);
     delete ctx;
@@ -744,6 +767,46 @@ int32_t msj_debug_set_wait_ticks(msj_ctx *ctx, uint32_t ticks) {
     if (!ctx) return MSJ_ERR_BAD_ARGUMENT;
     ctx->wait_ticks = ticks;
     return MSJ_SUCCESS;
+}
+
+static msj_ctx *default_ctx_locked() {  // g_default_mutex held
+    if (!g_default_ctx && msj_ctx_create(0, &g_default_ctx) != MSJ_SUCCESS) return nullptr;
+    return g_default_ctx;
+}
+
+int32_t msj_host_register(msj_ctx *ctx, void *ptr, uint64_t bytes) {
+    if (!ptr || bytes == 0) return MSJ_ERR_BAD_ARGUMENT;
+    std::unique_lock<std::mutex> lock(g_default_mutex, std::defer_lock);
+    if (!ctx) {
+        lock.lock();
+        ctx = default_ctx_locked();
+        if (!ctx) return MSJ_ERR_NO_DEVICE;
+    }
+    if (!hip_ok(hipSetDevice(ctx->device))) return MSJ_ERR_HIP;
+    if (!hip_ok(hipHostRegister(ptr, bytes, hipHostRegisterDefault))) {
+        (void)hipGetLastError();
+        return MSJ_ERR_HIP;
+    }
+    ctx->pinned.push_back({static_cast<const uint8_t *>(ptr), bytes});
+    return MSJ_SUCCESS;
+}
+
+int32_t msj_host_unregister(msj_ctx *ctx, void *ptr) {
+    if (!ptr) return MSJ_ERR_BAD_ARGUMENT;
+    std::unique_lock<std::mutex> lock(g_default_mutex, std::defer_lock);
+    if (!ctx) {
+        lock.lock();
+        ctx = g_default_ctx;
+        if (!ctx) return MSJ_ERR_BAD_ARGUMENT;
+    }
+    for (size_t i = 0; i < ctx->pinned.size(); i++)
+        if (ctx->pinned[i].base == ptr) {
+            ctx->pinned.erase(ctx->pinned.begin() + (long)i);
+            (void)hipSetDevice(ctx->device);
+            (void)hipDeviceSynchronize();  // nothing of ours may still be moving bytes of the range
+            return hip_ok(hipHostUnregister(ptr)) ? MSJ_SUCCESS : MSJ_ERR_HIP;
+        }
+    return MSJ_ERR_BAD_ARGUMENT;
 }
 
 uint64_t msj_fallback_count(const msj_ctx *ctx) { return ctx ? ctx->fallbacks : 0; }

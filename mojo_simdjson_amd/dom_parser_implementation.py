@@ -26,6 +26,8 @@ class DomParserImplementation:
         self.length = 0
         self.n_structural_indexes = 0
         self.structural_indexes = np.zeros(0, dtype=np.uint32)
+        self._storage = np.zeros(0, dtype=np.uint32)  # the list's allocation (its capacity); structural_indexes views it
+        self._registered = False
         self.next_structural_index = 0
         self.utf8_verdict = errors.SUCCESS  # extra: the reference's checker is a stub
         self._capacity = 0
@@ -37,16 +39,42 @@ class DomParserImplementation:
     def capacity(self):
         return self._capacity
 
+    # from this size on the list's allocation is pinned where it grows (msj_host_register): the indices then come
+    # down by DMA straight into it
+    REGISTER_FROM_BYTES = 64 << 20
+
     def allocate(self, amount):
-        """dom_parser_implementation.mojo:85-89 -- ``resize(amount, 0)``.
+        """dom_parser_implementation.mojo:85-89 -- ``reserve(amount)`` + ``resize(amount, 0)`` on a list the parser
+        keeps: memory is allocated only when a document is larger than any before, and ``resize`` zero-fills only
+        the elements it adds.
 
         The reference sizes the list to exactly ``amount`` slots although the
         callee writes three trailer words after the last index
         (json_structural_indexer.mojo:167-173); the replacement ABI requires
         ``len + 3`` (include/msj_stage1.h), so three extra slots are reserved.
         """
-        self.structural_indexes = np.zeros(amount + 3, dtype=np.uint32)
+        want = amount + 3
+        if want > self._storage.size:  # reserve(): the list moves
+            self._unregister()
+            self._storage = np.zeros(want, dtype=np.uint32)
+            if self._storage.nbytes >= self.REGISTER_FROM_BYTES:
+                lib = _lib.load()
+                self._registered = lib.msj_host_register(None, self._storage.ctypes.data, self._storage.nbytes) == 0
+        elif want > self.structural_indexes.size:  # resize() upwards inside the capacity: the added elements are 0
+            self._storage[self.structural_indexes.size:want] = 0
+        self.structural_indexes = self._storage[:want]
         self._capacity = amount
+
+    def _unregister(self):
+        if self._registered:
+            _lib.load().msj_host_unregister(None, self._storage.ctypes.data)
+            self._registered = False
+
+    def __del__(self):
+        try:
+            self._unregister()
+        except Exception:  # interpreter shutdown
+            pass
 
     def stage1(self, buffer, flags=0):
         """``stage1(String | StringSlice | Span[UInt8]) -> ErrorType`` (:59-69)."""

@@ -855,6 +855,46 @@ def test_host_pointer_large_inputs(oracle):
     assert_matches_oracle(oracle, dense, "50 MiB of brackets")
 
 
+def test_host_pointer_registered_buffers(oracle):
+    """msj_host_register: the caller's index array (and input) pinned once, the pipeline then moves them by DMA
+    without its staging copies -- same bits as the oracle, also from the middle of a registered range, also after
+    unregistering; and what the two calls refuse."""
+    import ctypes
+
+    from mojo_simdjson_amd import _lib, synth
+
+    lib = _lib.load()
+    data = synth.workload("minified", 40 << 20).tobytes() + b" [1,2]"
+    code, n, want = helpers.run_oracle(oracle.msj_oracle_stage1, data)
+    assert code == 0
+    want = np.concatenate([want[:n], np.array([len(data), len(data), 0], dtype=np.uint32)])
+    arena = np.zeros(len(data) + 3 + 1024, dtype=np.uint32)
+    inbuf = np.frombuffer(data, dtype=np.uint8).copy()
+    vp = lambda a, off=0: ctypes.c_void_p(a.ctypes.data + off)  # noqa: E731
+
+    def run(idx_view, src):
+        idx_view[:] = 0xDEADBEEF
+        got_n, verdict = ctypes.c_uint64(0), ctypes.c_int32(-1)
+        rc = lib.msj_stage1(vp(src), len(data), vp(idx_view), idx_view.size,
+                            ctypes.byref(got_n), ctypes.byref(verdict), 0)
+        assert (rc, got_n.value, verdict.value) == (0, n, 0)
+        assert np.array_equal(idx_view[: n + 3], want)
+
+    assert lib.msj_host_register(None, None, 10) == -1
+    assert lib.msj_host_register(None, vp(arena), 0) == -1
+    assert lib.msj_host_unregister(None, vp(arena)) == -1  # not registered
+    assert lib.msj_host_register(None, vp(arena), arena.nbytes) == 0
+    run(arena[: len(data) + 3], inbuf)                    # indices by DMA into the caller's array, input staged
+    run(arena[512: 512 + len(data) + 3], inbuf)          # a view inside the registered range
+    assert lib.msj_host_register(None, vp(inbuf), inbuf.nbytes) == 0
+    run(arena[: len(data) + 3], inbuf)                    # both sides direct
+    assert lib.msj_host_unregister(None, vp(arena, 64)) == -1  # not the start of a range
+    assert lib.msj_host_unregister(None, vp(arena)) == 0
+    run(arena[: len(data) + 3], inbuf)                    # input direct, indices staged again
+    assert lib.msj_host_unregister(None, vp(inbuf)) == 0
+    run(arena[: len(data) + 3], inbuf)
+
+
 def test_shard_carry_out_at_any_length(torch_mod, dev, oracle):
     """A non-final shard may end anywhere, not only on a 4 KiB tile: its carry-out
     (next_is_escaped, prev_scalar, in_string, count) is the state after its LAST BYTE, and a
