@@ -595,8 +595,10 @@ int32_t msj_stage1_shard_device(msj_ctx *ctx, const uint8_t *d_buf, uint64_t len
 }
 
 extern "C" uint64_t msj_tokens_workspace_bytes(uint64_t n, int with_match);
-extern "C" int msj_launch_tokens(const uint8_t *d_buf, const uint32_t *d_idx, uint64_t n, uint8_t *d_type, int32_t *d_depth,
-                                 uint32_t *d_match, msj_tokens_result *d_result, int32_t *d_ws, void *stream);
+
+extern "C" int msj_launch_tokens(const uint8_t *d_buf, uint64_t len, const uint32_t *d_idx, uint64_t n, uint8_t *d_type,
+                                        int32_t *d_depth, uint32_t *d_match, msj_tokens_result *d_result, int32_t *d_ws, void *stream);
+extern "C" uint64_t msj_stage2_prep_workspace_bytes(uint64_t n, int with_match);
 
 int32_t msj_tokens_device(msj_ctx *ctx, const uint8_t *d_buf, uint64_t len, const uint32_t *d_idx, uint64_t n,
                           uint8_t *d_type, int32_t *d_depth, uint32_t *d_match, msj_tokens_result *d_result,
@@ -608,7 +610,7 @@ int32_t msj_tokens_device(msj_ctx *ctx, const uint8_t *d_buf, uint64_t len, cons
         (reinterpret_cast<uintptr_t>(d_type) & 7u))
         return MSJ_ERR_BAD_ARGUMENT;
     if (!hip_ok(hipSetDevice(ctx->device))) return MSJ_ERR_HIP;
-    const uint64_t need = msj_tokens_workspace_bytes(n, d_match != nullptr);
+    const uint64_t need = msj_stage2_prep_workspace_bytes(n, d_match != nullptr);  // incl. the span kernel's sub-aggregates
     if (need > ctx->tok_ws_bytes) {
         if (ctx->tok_ws) {
             (void)hipDeviceSynchronize();
@@ -620,7 +622,7 @@ int32_t msj_tokens_device(msj_ctx *ctx, const uint8_t *d_buf, uint64_t len, cons
         ctx->tok_ws_bytes = need + need / 4;
     }
     ctx->tok_doc_n = ~0ull;
-    if (msj_launch_tokens(d_buf, d_idx, n, d_type, d_depth, d_match, d_result, ctx->tok_ws, stream) != 0) return MSJ_ERR_HIP;
+    if (msj_launch_tokens(d_buf, len, d_idx, n, d_type, d_depth, d_match, d_result, ctx->tok_ws, stream) != 0) return MSJ_ERR_HIP;
     ctx->tok_doc_n = n;
     return MSJ_SUCCESS;
 }

@@ -13,11 +13,11 @@
 // DERIVED quantities: the reference has no array like this and no fixture for it; the CPU
 // definition used by the tests is a definition, not a pin against the reference's own outputs.
 //
-// Three small kernels over blocks of 2 048 structurals: (1) gather the type bytes and reduce each
-// block to (sum, min prefix, max prefix) of its depth deltas, (2) one workgroup scans the block
-// aggregates in order, (3) every block re-scans its type bytes from the exact depth at its
-// start.  HBM-bound: 4 B index + the gathered byte + 1 B type out, then 1 B type in + 4 B depth
-// out per structural.
+// Kernels: (1) the type bytes and, per 512 structurals, the (sum, min prefix, max prefix) of their depth deltas, from
+// the workgroup's stretch of the buffer staged in LDS (the span kernel further down, type-bytes-only instantiation),
+// merged to blocks of 2 048; (2) a two-level scan of the block aggregates; (3) every block re-scans its type bytes
+// from the exact depth at its start.  HBM-bound: the buffer + 4 B index in, 1 B type out, then 1 B type in + 4 B
+// depth out per structural.
 #include <hip/hip_runtime.h>
 #include <stdlib.h>
 #include <stdint.h>
@@ -57,74 +57,61 @@ __device__ __forceinline__ Agg shfl_up(const Agg &a, int off) {
     return r;
 }
 
-// (1) type bytes + per-block aggregate
-__global__ __launch_bounds__(kThreads) void gather_reduce(const uint8_t *__restrict__ buf, const uint32_t *__restrict__ idx,
-                                                          uint64_t n, uint8_t *__restrict__ type, int32_t *__restrict__ block_agg) {
-    __shared__ Agg wave_agg[kThreads / 64];
-    __shared__ int wave_opens[kThreads / 64];
-    const uint64_t base = (uint64_t)blockIdx.x * kBlock + (uint64_t)threadIdx.x * kPer;
-    uint32_t off[kPer];
-    if (base + kPer <= n) {  // 32 bytes of indices per thread, two 16-byte loads
-        const uint4 a = *reinterpret_cast<const uint4 *>(idx + base);
-        const uint4 b = *reinterpret_cast<const uint4 *>(idx + base + 4);
-        off[0] = a.x; off[1] = a.y; off[2] = a.z; off[3] = a.w;
-        off[4] = b.x; off[5] = b.y; off[6] = b.z; off[7] = b.w;
-    } else {
-#pragma unroll
-        for (int k = 0; k < kPer; k++) off[k] = (base + k < n) ? idx[base + k] : 0xFFFFFFFFu;
-    }
-    uint32_t c[kPer];
-#pragma unroll
-    for (int k = 0; k < kPer; k++) c[k] = (base + k < n) ? buf[off[k]] : (uint32_t)' ';
-    if (base + kPer <= n) {
-        *reinterpret_cast<uint2 *>(type + base) =
-            make_uint2(c[0] | (c[1] << 8) | (c[2] << 16) | (c[3] << 24), c[4] | (c[5] << 8) | (c[6] << 16) | (c[7] << 24));
-    } else {
-#pragma unroll
-        for (int k = 0; k < kPer; k++)
-            if (base + k < n) type[base + k] = (uint8_t)c[k];
-    }
-    Agg a = {0, kNone, -kNone};
-    int run = 0, opens = 0;
-#pragma unroll
-    for (int k = 0; k < kPer; k++) {
-        if (base + k < n) {
-            const int dk = delta_of(c[k]);
-            opens += dk > 0;
-            run += dk;
-            a.mn = min(a.mn, run);
-            a.mx = max(a.mx, run);
-        }
-    }
-    a.sum = run;
-    // ordered reduction: inclusive scan inside the wave, the last lane holds the wave's aggregate
-    const int lane = threadIdx.x & 63;
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-        const Agg p = shfl_up(a, o);
-        if (lane >= o) a = combine(p, a);
-    }
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) opens += __shfl_xor(opens, o);  // opening brackets in the wave
-    if (lane == 63) {
-        wave_agg[threadIdx.x >> 6] = a;
-        wave_opens[threadIdx.x >> 6] = opens;
-    }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        Agg t = wave_agg[0];
-        int no = wave_opens[0];
-#pragma unroll
-        for (int w = 1; w < kThreads / 64; w++) {
-            t = combine(t, wave_agg[w]);
-            no += wave_opens[w];
-        }
-        block_agg[4 * (uint64_t)blockIdx.x + 0] = t.sum;
-        block_agg[4 * (uint64_t)blockIdx.x + 1] = t.mn;
-        block_agg[4 * (uint64_t)blockIdx.x + 2] = t.mx;
-        block_agg[4 * (uint64_t)blockIdx.x + 3] = no;
-    }
+// minimum and maximum over the wave, by DPP: an inclusive scan inside each row of 16 lanes (row_shr 1, 2, 4, 8),
+// then the last lane of a row into the next row (row_bcast:15, rows 1 and 3) and lane 31 into rows 2 and 3
+// (row_bcast:31); lane 63 holds the result.  A lane without a source lane keeps its value (the instruction is
+// off for it).  One instruction per step and value; a DPP read needs two wait states after the write of its
+// source, which the other chain and an s_nop provide.
+__device__ __forceinline__ void wave_min_max(int lo, int hi, int &mn_out, int &mx_out) {  // min over lo, max over hi
+    int mn = lo, mx = hi;
+    asm volatile(
+        "s_nop 1\n\t"
+        "v_min_i32_dpp %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
+        "v_max_i32_dpp %1, %1, %1 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 0\n\t"
+        "v_min_i32_dpp %0, %0, %0 row_shr:2 row_mask:0xf bank_mask:0xf\n\t"
+        "v_max_i32_dpp %1, %1, %1 row_shr:2 row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 0\n\t"
+        "v_min_i32_dpp %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xf\n\t"
+        "v_max_i32_dpp %1, %1, %1 row_shr:4 row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 0\n\t"
+        "v_min_i32_dpp %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xf\n\t"
+        "v_max_i32_dpp %1, %1, %1 row_shr:8 row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 0\n\t"
+        "v_min_i32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+        "v_max_i32_dpp %1, %1, %1 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+        "s_nop 0\n\t"
+        "v_min_i32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"
+        "v_max_i32_dpp %1, %1, %1 row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"
+        "s_nop 1"
+        : "+v"(mn), "+v"(mx));
+    mn_out = __builtin_amdgcn_readlane(mn, 63);
+    mx_out = __builtin_amdgcn_readlane(mx, 63);
 }
+
+// inclusive prefix sum over the wave, the same six DPP steps
+__device__ __forceinline__ uint32_t wave_incl_sum(uint32_t x) {
+    asm volatile(
+        "s_nop 1\n\t"
+        "v_add_u32_dpp %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\t"
+        "v_add_u32_dpp %0, %0, %0 row_shr:2 row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\t"
+        "v_add_u32_dpp %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\t"
+        "v_add_u32_dpp %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\t"
+        "v_add_u32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+        "s_nop 1\n\t"
+        "v_add_u32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"
+        "s_nop 1"
+        : "+v"(x));
+    return x;
+}
+// (1) type bytes + per-block aggregate: the span kernel's type-bytes-only instantiation (token_spans<true, false>
+//     below: the workgroup's stretch of the buffer staged in LDS with coalesced loads, the bytes picked from there;
+//     a kernel that gathered buf[idx[i]] per token through L2 took 0.6 ms per GiB minified where this takes 0.5) and
+//     merge_sub_aggregates.
 
 // (2a) many workgroups: exclusive scan of the block aggregates INSIDE each run of kSuper blocks (relative
 //      start depth and start slot per block) and the aggregate of the run.  One workgroup scanning all
@@ -309,15 +296,7 @@ __global__ __launch_bounds__(kThreads) void apply_depth(const uint8_t *__restric
     }
     // exclusive prefix of the thread sums (depth deltas, opening brackets) inside the block
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    int incl = run, incl_no = no;
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-        const int p = __shfl_up(incl, o), q = __shfl_up(incl_no, o);
-        if (lane >= o) {
-            incl += p;
-            incl_no += q;
-        }
-    }
+    const int incl = (int)wave_incl_sum((uint32_t)run), incl_no = (int)wave_incl_sum((uint32_t)no);
     if (lane == 63) {
         wave_sum[wave] = incl;
         wave_no[wave] = incl_no;
@@ -361,13 +340,14 @@ __global__ __launch_bounds__(kThreads) void apply_depth(const uint8_t *__restric
                 }
             }
         }
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) {
-            cnt += (uint32_t)__shfl_xor((int)cnt, o);
-            ls = max(ls, (uint32_t)__shfl_xor((int)ls, o));
-            lc = max(lc, (uint32_t)__shfl_xor((int)lc, o));
+        {   // wave totals by DPP (token indices + 1 fit an int: n < 2^31); lane 63 holds the sum, every lane the maxima
+            cnt = wave_incl_sum(cnt);
+            int neg_lc, m_ls;  // one chain of minima, one of maxima: max(lc) = -min(-lc)
+            wave_min_max(-(int)lc, (int)ls, neg_lc, m_ls);
+            ls = (uint32_t)m_ls;
+            lc = (uint32_t)(-neg_lc);
         }
-        if (lane == 0) {
+        if (lane == 63) {
             doc_cnt[wave] = cnt;
             doc_start[wave] = ls;
             doc_close[wave] = lc;
@@ -528,16 +508,6 @@ extern "C" uint64_t msj_tokens_workspace_bytes(uint64_t n, int with_match) {
 // scan of the block aggregates (already in d_ws), depth of every token, bracket partners
 static int launch_depth_passes(const uint32_t *d_idx, uint64_t n, uint8_t *d_type, int32_t *d_depth, uint32_t *d_match,
                                msj_tokens_result *d_result, int32_t *d_ws, hipStream_t s);
-
-extern "C" int msj_launch_tokens(const uint8_t *d_buf, const uint32_t *d_idx, uint64_t n, uint8_t *d_type, int32_t *d_depth,
-                                 uint32_t *d_match, msj_tokens_result *d_result, int32_t *d_ws, void *stream) {
-    using namespace msj_tokens;
-    hipStream_t s = static_cast<hipStream_t>(stream);
-    const uint64_t nb64 = (n + kBlock - 1) / kBlock;
-    if (nb64 > 0x7FFFFFFFull) return (int)hipErrorInvalidValue;
-    if (nb64) hipLaunchKernelGGL(gather_reduce, dim3((uint32_t)nb64), dim3(kThreads), 0, s, d_buf, d_idx, n, d_type, d_ws);
-    return launch_depth_passes(d_idx, n, d_type, d_depth, d_match, d_result, d_ws, s);
-}
 
 static int launch_depth_passes(const uint32_t *d_idx, uint64_t n, uint8_t *d_type, int32_t *d_depth, uint32_t *d_match,
                                msj_tokens_result *d_result, int32_t *d_ws, hipStream_t s) {
@@ -902,60 +872,10 @@ __device__ __forceinline__ bool staged_token_fast(const uint8_t *stage, const ui
     return !(is_str ? (more_ink || more_bs || far) : (is_num && (more_num || more_flt)));
 }
 
-// inclusive prefix sum over the wave, the same six DPP steps
-__device__ __forceinline__ uint32_t wave_incl_sum(uint32_t x) {
-    asm volatile(
-        "s_nop 1\n\t"
-        "v_add_u32_dpp %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
-        "s_nop 1\n\t"
-        "v_add_u32_dpp %0, %0, %0 row_shr:2 row_mask:0xf bank_mask:0xf\n\t"
-        "s_nop 1\n\t"
-        "v_add_u32_dpp %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xf\n\t"
-        "s_nop 1\n\t"
-        "v_add_u32_dpp %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xf\n\t"
-        "s_nop 1\n\t"
-        "v_add_u32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
-        "s_nop 1\n\t"
-        "v_add_u32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"
-        "s_nop 1"
-        : "+v"(x));
-    return x;
-}
-// minimum and maximum over the wave, by DPP: an inclusive scan inside each row of 16 lanes (row_shr 1, 2, 4, 8),
-// then the last lane of a row into the next row (row_bcast:15, rows 1 and 3) and lane 31 into rows 2 and 3
-// (row_bcast:31); lane 63 holds the result.  A lane without a source lane keeps its value (the instruction is
-// off for it).  One instruction per step and value; a DPP read needs two wait states after the write of its
-// source, which the other chain and an s_nop provide.
-__device__ __forceinline__ void wave_min_max(int lo, int hi, int &mn_out, int &mx_out) {  // min over lo, max over hi
-    int mn = lo, mx = hi;
-    asm volatile(
-        "s_nop 1\n\t"
-        "v_min_i32_dpp %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
-        "v_max_i32_dpp %1, %1, %1 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
-        "s_nop 0\n\t"
-        "v_min_i32_dpp %0, %0, %0 row_shr:2 row_mask:0xf bank_mask:0xf\n\t"
-        "v_max_i32_dpp %1, %1, %1 row_shr:2 row_mask:0xf bank_mask:0xf\n\t"
-        "s_nop 0\n\t"
-        "v_min_i32_dpp %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xf\n\t"
-        "v_max_i32_dpp %1, %1, %1 row_shr:4 row_mask:0xf bank_mask:0xf\n\t"
-        "s_nop 0\n\t"
-        "v_min_i32_dpp %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xf\n\t"
-        "v_max_i32_dpp %1, %1, %1 row_shr:8 row_mask:0xf bank_mask:0xf\n\t"
-        "s_nop 0\n\t"
-        "v_min_i32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
-        "v_max_i32_dpp %1, %1, %1 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
-        "s_nop 0\n\t"
-        "v_min_i32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"
-        "v_max_i32_dpp %1, %1, %1 row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"
-        "s_nop 1"
-        : "+v"(mn), "+v"(mx));
-    mn_out = __builtin_amdgcn_readlane(mn, 63);
-    mx_out = __builtin_amdgcn_readlane(mx, 63);
-}
-
 // kFused: the kernel also writes the type byte of every token and the (sum, min, max, opening brackets)
-// aggregate of its kSpanTokens tokens -- what gather_reduce computes from a second pass over the buffer.
-template <bool kFused>
+// aggregate of its kSpanTokens tokens (what the token pre-pass scans); kSpans = false: those only -- no classes, no
+// bitmaps, no token evaluation, no ends and flags (msj_tokens_device).
+template <bool kFused, bool kSpans = true>
 __global__ __launch_bounds__(kSpanThreads) void token_spans(const uint8_t *__restrict__ buf, uint64_t len, const uint32_t *__restrict__ idx,
                                                            uint64_t n, uint32_t *__restrict__ end, uint8_t *__restrict__ flags, uint32_t lds_limit,
                                                            uint8_t *__restrict__ type, int4 *__restrict__ sub_agg) {
@@ -994,11 +914,11 @@ __global__ __launch_bounds__(kSpanThreads) void token_spans(const uint8_t *__res
     if (!staged) {
         MSJ_SPAN_ARRIVED();
         if (have0) {
-            span_of(FromGlobal{buf, len}, start0, next0, len, e0, f0);
+            if (kSpans) span_of(FromGlobal{buf, len}, start0, next0, len, e0, f0);
             if (kFused) c0 = buf[start0];
         }
         if (have1) {
-            span_of(FromGlobal{buf, len}, start1, next1, len, e1, f1);
+            if (kSpans) span_of(FromGlobal{buf, len}, start1, next1, len, e1, f1);
             if (kFused) c1 = buf[start1];
         }
     } else {
@@ -1031,6 +951,7 @@ __global__ __launch_bounds__(kSpanThreads) void token_spans(const uint8_t *__res
 #pragma unroll
             for (int q = 0; q < 4; q++)
                 *reinterpret_cast<uint4 *>(stage + 64u * j + 16 * q) = make_uint4(x[4 * q], x[4 * q + 1], x[4 * q + 2], x[4 * q + 3]);
+            if (kSpans) {
             uint64_t pl[8];
 #if MSJ_SPAN_ABLATE == 3
             for (int q = 0; q < 8; q++) pl[q] = x[q] | ((uint64_t)x[q + 8] << 32);
@@ -1046,14 +967,15 @@ __global__ __launch_bounds__(kSpanThreads) void token_spans(const uint8_t *__res
             has_bs = cl.backslash;
             bs_lo = __popc((uint32_t)cl.backslash);
             bs_all = bs_lo + __popc((uint32_t)(cl.backslash >> 32));
-        } else if (j < nblk + 2u) {  // zero words behind the maps
+            }
+        } else if (kSpans && j < nblk + 2u) {  // zero words behind the maps
             const uint32_t w = kSpanMapFront + 2u * j;
             *reinterpret_cast<uint2 *>(m_num + w) = make_uint2(0, 0);
             *reinterpret_cast<uint2 *>(m_flt + w) = make_uint2(0, 0);
             *reinterpret_cast<uint2 *>(m_bs + w) = make_uint2(0, 0);
             *reinterpret_cast<uint2 *>(m_ink + w) = make_uint2(0, 0);
         }
-        if (j == kSpanThreads - 1) {  // ... and in front of them
+        if (kSpans && j == kSpanThreads - 1) {  // ... and in front of them
             *reinterpret_cast<uint2 *>(m_num) = make_uint2(0, 0);
             *reinterpret_cast<uint2 *>(m_flt) = make_uint2(0, 0);
             *reinterpret_cast<uint2 *>(m_bs) = make_uint2(0, 0);
@@ -1061,26 +983,25 @@ __global__ __launch_bounds__(kSpanThreads) void token_spans(const uint8_t *__res
             bs_blocks[2 * (kSpanThreads / 64)] = 0;
             bs_blocks[2 * (kSpanThreads / 64) + 1] = 0;
         }
-        {   // all lanes: blocks in front of this lane's, within the wave
+        if (kSpans) {  // all lanes: blocks in front of this lane's, within the wave
             const uint32_t upto = wave_incl_sum(bs_all) - bs_all;
             if (j < nblk + 2u)
                 *reinterpret_cast<uint32_t *>(bs_cnt + kSpanMapFront + 2u * j) = upto | ((upto + bs_lo) << 16);
             if (j == kSpanThreads - 1) *reinterpret_cast<uint32_t *>(bs_cnt) = 0;
         }
         const uint64_t bsb = __ballot(has_bs != 0);
-        if ((j & 63u) == 0) {
+        if (kSpans && (j & 63u) == 0) {
             bs_blocks[2 * (j >> 6)] = (uint32_t)bsb;
             bs_blocks[2 * (j >> 6) + 1] = (uint32_t)(bsb >> 32);
         }
         MSJ_SPAN_ARRIVED();
         __syncthreads();
-#if MSJ_SPAN_ABLATE == 1
-        if (have0) {
-            c0 = stage[(uint32_t)(start0 - lo)];
-            c1 = have1 ? (uint32_t)stage[(uint32_t)(start1 - lo)] : 0u;
-        } else
-#endif
-        if (have0) {
+        if (!kSpans || MSJ_SPAN_ABLATE == 1) {  // the type bytes only
+            if (have0) {
+                c0 = stage[(uint32_t)(start0 - lo)];
+                c1 = have1 ? (uint32_t)stage[(uint32_t)(start1 - lo)] : 0u;
+            }
+        } else if (have0) {
             const uint32_t lo32 = (uint32_t)lo, len32 = (uint32_t)len;
             const uint32_t rs0 = (uint32_t)(start0 - lo), rn0 = (uint32_t)(next0 - lo);
             const uint32_t rs1 = have1 ? (uint32_t)(start1 - lo) : rs0, rn1 = have1 ? (uint32_t)(next1 - lo) : rn0;
@@ -1101,16 +1022,22 @@ __global__ __launch_bounds__(kSpanThreads) void token_spans(const uint8_t *__res
         }
     }
     if (full) {
-        *reinterpret_cast<uint2 *>(end + tok0) = make_uint2(e0, e1);
-        *reinterpret_cast<uint16_t *>(flags + tok0) = (uint16_t)(f0 | (f1 << 8));
+        if (kSpans) {
+            *reinterpret_cast<uint2 *>(end + tok0) = make_uint2(e0, e1);
+            *reinterpret_cast<uint16_t *>(flags + tok0) = (uint16_t)(f0 | (f1 << 8));
+        }
         if (kFused) *reinterpret_cast<uint16_t *>(type + tok0) = (uint16_t)(c0 | (c1 << 8));
     } else if (have0) {
-        end[tok0] = e0;
-        flags[tok0] = (uint8_t)f0;
+        if (kSpans) {
+            end[tok0] = e0;
+            flags[tok0] = (uint8_t)f0;
+        }
         if (kFused) type[tok0] = (uint8_t)c0;
         if (have1) {
-            end[tok0 + 1] = e1;
-            flags[tok0 + 1] = (uint8_t)f1;
+            if (kSpans) {
+                end[tok0 + 1] = e1;
+                flags[tok0 + 1] = (uint8_t)f1;
+            }
             if (kFused) type[tok0 + 1] = (uint8_t)c1;
         }
     }
@@ -1208,6 +1135,24 @@ extern "C" int msj_launch_stage2_prep(const uint8_t *d_buf, uint64_t len, const 
         const unsigned long lim = env ? strtoul(env, nullptr, 10) : kSpanLds;
         const uint32_t lds_limit = (uint32_t)(lim < kSpanLds ? lim : kSpanLds);
         hipLaunchKernelGGL(token_spans<true>, dim3(nsub), dim3(kSpanThreads), 0, s, d_buf, len, d_idx, n, d_end, d_flags, lds_limit, d_type, sub);
+        hipLaunchKernelGGL(merge_sub_aggregates, dim3((nb + 255u) / 256u), dim3(256), 0, s, sub, nsub, d_ws, nb);
+    }
+    return launch_depth_passes(d_idx, n, d_type, d_depth, d_match, d_result, d_ws, s);
+}
+
+extern "C" int msj_launch_tokens(const uint8_t *d_buf, uint64_t len, const uint32_t *d_idx, uint64_t n, uint8_t *d_type,
+                                        int32_t *d_depth, uint32_t *d_match, msj_tokens_result *d_result, int32_t *d_ws, void *stream) {
+    using namespace msj_tokens;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const uint64_t nb64 = (n + kBlock - 1) / kBlock;
+    if (nb64 > 0x7FFFFFFFull) return (int)hipErrorInvalidValue;
+    const uint32_t nb = (uint32_t)nb64;
+    const uint32_t nsub = (uint32_t)((n + kSpanTokens - 1) / kSpanTokens);
+    const uint64_t tok_bytes = (msj_tokens_workspace_bytes(n, d_match != nullptr) + 15u) & ~15ull;
+    int4 *sub = reinterpret_cast<int4 *>(reinterpret_cast<uint8_t *>(d_ws) + tok_bytes);
+    if (n) {
+        hipLaunchKernelGGL((token_spans<true, false>), dim3(nsub), dim3(kSpanThreads), 0, s, d_buf, len, d_idx, n, static_cast<uint32_t *>(nullptr),
+                           static_cast<uint8_t *>(nullptr), kSpanLds, d_type, sub);
         hipLaunchKernelGGL(merge_sub_aggregates, dim3((nb + 255u) / 256u), dim3(256), 0, s, sub, nsub, d_ws, nb);
     }
     return launch_depth_passes(d_idx, n, d_type, d_depth, d_match, d_result, d_ws, s);

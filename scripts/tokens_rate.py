@@ -32,9 +32,9 @@ for name in ("minified", "utf8", "pretty4"):
     e1.record()
     torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / 10
-    alg = 10 * n  # 4 B index + 1 gathered byte + 1 B type out, then 1 B type in... counted once: 4+1+1+4
+    alg = nbytes + 10 * n  # the buffer + 4 B index in, 1 B type out; then 1 B type in, 4 B depth out
     print(f"{name:9s}: {n} structurals, {ms:.3f} ms, {n / ms / 1e6:.1f} G structurals/s, "
-          f"{alg / ms / 1e6:.0f} GB/s of 10 B/structural ({alg / ms / 1e6 / 8000:.3f} of 8 TB/s), "
+          f"{alg / ms / 1e6:.0f} GB/s of buffer + 10 B/structural ({alg / ms / 1e6 / 8000:.3f} of 8 TB/s), "
           f"max depth {res.max_depth}, final {res.final_depth}; as input rate {nbytes / ms / 1e6:.0f} GB/s of JSON")
     dev.tokens(d_buf, nbytes, d_idx, n, d_type, d_depth, d_match)
     torch.cuda.synchronize()
