@@ -42,6 +42,20 @@ bool is_nonscalar(uint8_t c) {
     }
 }
 
+// a byte a valid document can hold outside of strings: blanks, operators, number characters, the letters of the
+// three literals
+bool plausible_outside(uint8_t c) {
+    switch (c) {
+        case 0x09: case 0x0A: case 0x0D: case 0x20: case ',': case ':': case '[': case ']': case '{': case '}':
+        case '0': case '1': case '2': case '3': case '4': case '5': case '6': case '7': case '8': case '9':
+        case '-': case '+': case '.': case 'e': case 'E':
+        case 't': case 'r': case 'u': case 'f': case 'a': case 'l': case 's': case 'n':
+            return true;
+        default:
+            return false;
+    }
+}
+
 // length of the backslash run ending just before position pos of p[0..), -1 if it reaches p[0]
 int64_t run_before(const uint8_t *p, uint64_t pos) {
     int64_t n = 0;
@@ -168,8 +182,34 @@ int32_t msj_shard_speculate(const uint8_t *halo, uint64_t halo_len, const uint8_
     }
     out->next_is_escaped = e;
     out->prev_scalar = ps;
-    // in_string: the first unescaped quote of the shard opens a string if one of `: , [ {` precedes it,
-    // closes one if one of `: , ] }` follows it (blanks skipped).  Only a guess.
+    // in_string, first try: follow the head under both hypotheses at once (they are each other's complement at
+    // every byte) until one of them meets a byte it cannot hold -- a control character inside a string, or outside
+    // strings anything but blanks, operators, number characters and the letters of true / false / null.  A valid
+    // document never contradicts the true hypothesis; text, keys and UTF-8 contradict the false one within a few
+    // bytes.  Only a guess all the same (both or neither may fail): the chain check decides.
+    {
+        uint32_t esc = e, in0 = 0;  // in0: inside a string if the shard starts outside of one
+        for (uint64_t i = 0; i < head_len; i++) {
+            const uint8_t c = head[i];
+            const uint32_t escaped = esc;
+            esc = (!escaped && c == 0x5C) ? 1u : 0u;
+            if (escaped) continue;  // whatever it is, it is taken literally
+            if (c == 0x22) {
+                in0 ^= 1u;
+                continue;
+            }
+            const bool bad_in = c < 0x20;
+            const bool bad_out = !plausible_outside(c);
+            const bool h0_bad = in0 ? bad_in : bad_out, h1_bad = in0 ? bad_out : bad_in;
+            if (h0_bad != h1_bad) {
+                out->in_string = h0_bad ? 1u : 0u;
+                return MSJ_SUCCESS;
+            }
+            if (h0_bad) break;  // neither holds: not a valid document, any guess
+        }
+    }
+    // second try: the first unescaped quote of the shard opens a string if one of `: , [ {` precedes it,
+    // closes one if one of `: , ] }` follows it (blanks skipped).
     uint32_t esc = e;
     int64_t q = -1;
     for (uint64_t i = 0; i < head_len; i++) {

@@ -61,7 +61,20 @@ def test_speculate_matches_serial():
         assert (ge, gps) == (e, ps), (cut, halo)
         right += g == s
         wrong += g != s
-    assert right > 450 and wrong > 0  # good but not perfect: the re-run path matters
+    assert wrong <= 3, (right, wrong)  # text and keys contradict the wrong hypothesis within a few bytes
+    # ... unless every string is made of characters a document also holds outside of strings: then the first quote's
+    # neighbours decide, which is good but not perfect -- the re-run path matters
+    doc = (b'{"a":"e l","s":[1,2,"e:1,",true],"u":"e:","f":", 1"}' * 40)
+    right = wrong = 0
+    for _ in range(600):
+        cut = rng.randint(70, len(doc) - 70)
+        halo, head = doc[cut - 64:cut], doc[cut:cut + 4096]
+        e, s, ps = serial_state(doc[:cut])
+        g, ge, gps = sharded.speculate_bytes(halo, head)
+        assert (ge, gps) == (e, ps), (cut, halo)
+        right += g == s
+        wrong += g != s
+    assert right > 450 and wrong > 0, (right, wrong)
     # short halos (shard near the start of the stream), no halo at all, undecidable halo
     assert sharded.speculate_bytes(b"", b'"abc') == (0, 0, 0)
     assert sharded.speculate_bytes(b'["a', b'b",1]')[1:] == (0, 1)
@@ -227,7 +240,7 @@ def test_gloo_world2_live_protocol():
         data = bytes(rng.choice(alpha) for _ in range(300))
         cases.append((data, [0, rng.randint(80, 220), len(data)]))
     # the cut falls inside a string whose closing quote follows a ':' -> rank 1's guess is refuted
-    wrong = b'["' + b"a" * 90 + b':",1,2,"zz"]'
+    wrong = b'["' + b"a" * 90 + b':",1,2,"ee"]'
     cases.append((wrong, [0, 40, len(wrong)]))
     # a long backslash run across the cut (the halo cannot decide the escape carry)
     bs = b'["' + b"\\" * 150 + b'\\"x"' + b",1]" * 10
