@@ -572,7 +572,9 @@ def test_sharded_world8_one_gpu(torch_mod, oracle):
 
     world = 8
     u = synth.workload("utf8", 1 << 20).tobytes()
-    parts = [u, b' ["' + b"a" * 3000 + b':",1,2,"zz"] ', synth.workload("minified", 1 << 20).tobytes()]
+    # (a string longer than the 4 KiB of its head a rank speculates from, made of a letter that also occurs outside of
+    # strings: nothing contradicts either hypothesis and the guess of the rank that starts inside it is wrong)
+    parts = [u, b' ["' + b"a" * 8000 + b':",1,2,"zz"] ', synth.workload("minified", 1 << 20).tobytes()]
     p1 = len(parts[0])
     p3 = sum(len(x) for x in parts)
     head3 = b' ["x' + b"\\" * 70 + b'","'
