@@ -712,8 +712,11 @@ __device__ __forceinline__ uint64_t block_bits(const uint32_t *map, uint32_t blk
     return ((uint64_t)v.y << 32) | v.x;
 }
 
-// one token from the staged stretch; offsets relative to lo (< kSpanLds)
-__device__ __forceinline__ void staged_token(const uint8_t *stage, const uint32_t *m_num, const uint32_t *m_flt, const uint32_t *m_bs,
+// one token from the staged stretch; offsets relative to lo (< kSpanLds).  Returns true when the staged bytes were not
+// enough: a float's scan runs `while not structural-or-blank`, and where the next structural is a scalar that follows
+// a quote (`1.5"a"b`: no blank or operator in front of it) that scan goes on past the next structural and may leave
+// the stretch -- the caller then takes span_of from global memory for this token.
+__device__ __forceinline__ bool staged_token(const uint8_t *stage, const uint32_t *m_num, const uint32_t *m_flt, const uint32_t *m_bs,
                                              const uint32_t *m_ink, const uint32_t *bs_blocks, uint64_t lo, uint32_t span, uint64_t len,
                                              uint32_t c, uint64_t start, uint64_t next, uint32_t &e_out, uint32_t &f_out) {
     const uint32_t rs = (uint32_t)(start - lo);
@@ -810,13 +813,16 @@ __device__ __forceinline__ void staged_token(const uint8_t *stage, const uint32_
                 f |= MSJ_SPAN_BAD;
             }
         }
-        if (p == stop && lo + stop < len)  // kSpanCap characters and still no end
-            f = (f & ~MSJ_SPAN_BAD) | MSJ_SPAN_LONG;
-        else
+        if (p == stop && lo + stop < len) {
+            if (stop < rs + 1 + kSpanCap) return true;  // not the cap: the stretch ended
+            f = (f & ~MSJ_SPAN_BAD) | MSJ_SPAN_LONG;      // kSpanCap characters and still no end
+        } else {
             e = (uint32_t)(lo + p);
+        }
     }
     e_out = e;
     f_out = f;
+    return false;
 }
 
 // bits of m_bs in front of position pos, counted from the start of the 4 KiB the wave that staged pos covers
@@ -865,11 +871,12 @@ __device__ __forceinline__ bool staged_token_fast(const uint8_t *stage, const ui
     const uint32_t pe = flt ? min(p + min((uint32_t)(__ffs(wf) - 1), 32u), stop) : p;
     const bool more_flt = flt && wf == 0 && p + 32u < stop;
     const bool lng_num = pe == stop && lo + stop < len;  // kSpanCap characters and still no end
+    const bool edge = lng_num && stop < rs + 1u + kSpanCap;  // ... or the stretch did (staged_token tells)
     const uint32_t f_num = MSJ_SPAN_NUMBER | (flt ? MSJ_SPAN_FLOAT : 0u) | (lng_num ? MSJ_SPAN_LONG : (bad ? MSJ_SPAN_BAD : 0u));
     const uint32_t e_num = lng_num ? 0u : lo + pe;
     e_out = is_str ? e_str : (is_num ? e_num : 0u);
     f_out = is_str ? f_str : (is_num ? f_num : 0u);
-    return !(is_str ? (more_ink || more_bs || far) : (is_num && (more_num || more_flt)));
+    return !(is_str ? (more_ink || more_bs || far) : (is_num && (more_num || more_flt || edge)));
 }
 
 // kFused: the kernel also writes the type byte of every token and the (sum, min, max, opening brackets)
@@ -1011,13 +1018,15 @@ __global__ __launch_bounds__(kSpanThreads) void token_spans(const uint8_t *__res
             const bool s1 = have1 && (c1 == '"' || c1 == '-' || c1 - '0' < 10u);
             const uint32_t cs = s0 ? c0 : c1, rs = s0 ? rs0 : rs1, rn = s0 ? rn0 : rn1;
             uint32_t e, f;
-            if (!staged_token_fast(stage, m_num, m_flt, m_bs, bs_cnt, m_ink, lo32, span, len32, cs, rs, rn, e, f))
-                staged_token(stage, m_num, m_flt, m_bs, m_ink, bs_blocks, lo, span, len, cs, lo + rs, lo + rn, e, f);
+            if (!staged_token_fast(stage, m_num, m_flt, m_bs, bs_cnt, m_ink, lo32, span, len32, cs, rs, rn, e, f) &&
+                staged_token(stage, m_num, m_flt, m_bs, m_ink, bs_blocks, lo, span, len, cs, lo + rs, lo + rn, e, f))
+                span_of(FromGlobal{buf, len}, lo + rs, lo + rn, len, e, f);
             e0 = s0 ? e : 0u, f0 = s0 ? f : 0u;
             e1 = s0 ? 0u : e, f1 = s0 ? 0u : f;
             if (s0 && s1) {  // two scalars in a row (not a valid document)
-                if (!staged_token_fast(stage, m_num, m_flt, m_bs, bs_cnt, m_ink, lo32, span, len32, c1, rs1, rn1, e1, f1))
-                    staged_token(stage, m_num, m_flt, m_bs, m_ink, bs_blocks, lo, span, len, c1, start1, next1, e1, f1);
+                if (!staged_token_fast(stage, m_num, m_flt, m_bs, bs_cnt, m_ink, lo32, span, len32, c1, rs1, rn1, e1, f1) &&
+                    staged_token(stage, m_num, m_flt, m_bs, m_ink, bs_blocks, lo, span, len, c1, start1, next1, e1, f1))
+                    span_of(FromGlobal{buf, len}, start1, next1, len, e1, f1);
             }
         }
     }

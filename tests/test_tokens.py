@@ -250,6 +250,11 @@ def test_token_spans(dev, lds_limit, monkeypatch):
     for body in (b"a" * 90 + b"\\n" + b"b" * 7, b"a" * 99, b"\\\\" * 17 + b"c" * 65, b"\\" * 33 + b"\\" + b"d"):
         _check_spans(dev, b"[" + (b'"' + body + b'",') * 700 + b"0]", f"bodies across 4 KiB edges: {body[:12]!r}...")
     _check_spans(dev, b"[" + b"1" * 40 + b"." + b"5" * 40 + b"e" + b"7" * 40 + b"," + b"-" + b"9" * 33 + b"x]", "long floats")
+    # a float's scan (`while not structural-or-blank`) goes on past the next structural where that is a scalar that
+    # follows a quote, and -- for the last token of a workgroup -- past the bytes the workgroup has staged
+    for fill in (253, 254, 255, 256, 257):
+        for tail in (300, 2000):
+            _check_spans(dev, b"[" + b"1," * fill + b'1.5"xx"' + b"y" * tail + b" ,7]", f"float scan leaves the stretch ({fill}, {tail})")
     # the closing quote is found from the NEXT structural: byte soups (valid or not) must agree with the forward scan
     rng = np.random.default_rng(9)
     alphabets = [b'{}[],: \n"\\ab1', b'""\\\\ a,', b'"abc\\" \t:1e5-', b'"\\" \r\n"x']
