@@ -76,6 +76,7 @@ struct msj_ctx {
             if (q >= r.base && n <= r.bytes && (uint64_t)(q - r.base) <= r.bytes - n) return true;
         return false;
     }
+    uint32_t *span_fix = nullptr; // work list of the span kernel's fix-up pass (tokens_kernel.hip), zeroed once
     int32_t *tok_ws = nullptr;    // block aggregates of the token pre-pass
     uint64_t tok_ws_bytes = 0;
     uint64_t tok_doc_n = ~0ull;   // the token count whose document aggregates tok_ws holds (~0: none)
@@ -559,6 +560,7 @@ void msj_ctx_destroy(msj_ctx *ctx) {
     if (ctx->ws) (void)hipFree(ctx->ws);
     if (ctx->tp) (void)hipFree(ctx->tp);
     if (ctx->tok_ws) (void)hipFree(ctx->tok_ws);
+    if (ctx->span_fix) (void)hipFree(ctx->span_fix);
     if (ctx->doc_ws) (void)hipFree(ctx->doc_ws);
     if (ctx->carries) (void)hipFree(ctx->carries);
     if (ctx->d_in) (void)hipFree(ctx->d_in);
@@ -628,7 +630,19 @@ int32_t msj_tokens_device(msj_ctx *ctx, const uint8_t *d_buf, uint64_t len, cons
 }
 
 extern "C" int msj_launch_token_spans(const uint8_t *d_buf, uint64_t len, const uint32_t *d_idx, uint64_t n, uint32_t *d_end,
-                                      uint8_t *d_flags, void *stream);
+                                      uint8_t *d_flags, uint32_t *d_fix, void *stream);
+extern "C" uint64_t msj_span_fix_bytes(void);
+
+static bool ensure_span_fix(msj_ctx *ctx) {
+    if (ctx->span_fix) return true;
+    if (!hip_ok(hipMalloc(reinterpret_cast<void **>(&ctx->span_fix), msj_span_fix_bytes()))) return false;
+    if (!hip_ok(hipMemset(ctx->span_fix, 0, msj_span_fix_bytes()))) {
+        (void)hipFree(ctx->span_fix);
+        ctx->span_fix = nullptr;
+        return false;
+    }
+    return true;
+}
 
 int32_t msj_token_spans_device(msj_ctx *ctx, const uint8_t *d_buf, uint64_t len, const uint32_t *d_idx, uint64_t n,
                                uint32_t *d_end, uint8_t *d_flags, void *stream) {
@@ -636,13 +650,14 @@ int32_t msj_token_spans_device(msj_ctx *ctx, const uint8_t *d_buf, uint64_t len,
     if (n > 0 && (!d_buf || !d_idx || !d_end || !d_flags)) return MSJ_ERR_BAD_ARGUMENT;
     if (len > MSJ_MAX_SEGMENT_BYTES || n >= (1ull << 31)) return MSJ_CAPACITY;
     if (!hip_ok(hipSetDevice(ctx->device))) return MSJ_ERR_HIP;
-    return msj_launch_token_spans(d_buf, len, d_idx, n, d_end, d_flags, stream) == 0 ? MSJ_SUCCESS : MSJ_ERR_HIP;
+    if (!ensure_span_fix(ctx)) return MSJ_MEMALLOC;
+    return msj_launch_token_spans(d_buf, len, d_idx, n, d_end, d_flags, ctx->span_fix, stream) == 0 ? MSJ_SUCCESS : MSJ_ERR_HIP;
 }
 
 extern "C" uint64_t msj_stage2_prep_workspace_bytes(uint64_t n, int with_match);
 extern "C" int msj_launch_stage2_prep(const uint8_t *d_buf, uint64_t len, const uint32_t *d_idx, uint64_t n, uint8_t *d_type,
                                       int32_t *d_depth, uint32_t *d_match, uint32_t *d_end, uint8_t *d_flags,
-                                      msj_tokens_result *d_result, int32_t *d_ws, void *stream);
+                                      msj_tokens_result *d_result, int32_t *d_ws, uint32_t *d_fix, void *stream);
 
 int32_t msj_stage2_prep_device(msj_ctx *ctx, const uint8_t *d_buf, uint64_t len, const uint32_t *d_idx, uint64_t n,
                                uint8_t *d_type, int32_t *d_depth, uint32_t *d_match, uint32_t *d_end, uint8_t *d_flags,
@@ -666,7 +681,8 @@ int32_t msj_stage2_prep_device(msj_ctx *ctx, const uint8_t *d_buf, uint64_t len,
         ctx->tok_ws_bytes = need + need / 4;
     }
     ctx->tok_doc_n = ~0ull;
-    if (msj_launch_stage2_prep(d_buf, len, d_idx, n, d_type, d_depth, d_match, d_end, d_flags, d_result, ctx->tok_ws, stream) != 0)
+    if (!ensure_span_fix(ctx)) return MSJ_MEMALLOC;
+    if (msj_launch_stage2_prep(d_buf, len, d_idx, n, d_type, d_depth, d_match, d_end, d_flags, d_result, ctx->tok_ws, ctx->span_fix, stream) != 0)
         return MSJ_ERR_HIP;
     ctx->tok_doc_n = n;
     return MSJ_SUCCESS;

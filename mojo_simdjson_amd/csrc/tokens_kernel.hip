@@ -697,6 +697,22 @@ constexpr uint32_t kSpanMapFront = 2;
 constexpr uint32_t kSpanMapWords = kSpanMapFront + 2 * kSpanBlocks + 4;
 static_assert(kSpanBlocks <= kSpanThreads, "one lane per staged block");
 
+// Tokens the span kernel could not finish from its staged bytes (staged_token returns true: see there) go on a
+// work list in global memory -- fix[0] counts them, fix[2 ..] holds their token indices, fix[1] counts the
+// workgroups of span_fixup that are done -- and get the sentinel 0xFF as their flags; span_fixup, launched behind
+// the span kernel, works them out from global memory.  Appending is one atomic and one store in a block that
+// almost no wave enters (a call or an inlined scan from global memory at that place cost the kernel 5 %).
+constexpr uint32_t kFixCap = 16382;        // entries; more than that: span_fixup looks for the sentinel itself (MSJ_SPANS_FIX_CAP: tests)
+constexpr uint32_t kFixWords = kFixCap + 2;
+constexpr uint32_t kFixSentinel = 0xFFu;   // no token has all eight flag bits
+constexpr uint32_t kFixGroups = 32;
+__device__ __forceinline__ void fix_later(uint32_t *fix, uint32_t cap, uint32_t token, uint32_t &e, uint32_t &f) {
+    const uint32_t slot = atomicAdd(&fix[0], 1u);
+    if (slot < cap) fix[2 + slot] = token;
+    e = 0;
+    f = kFixSentinel;
+}
+
 // 32 bits of a bitmap starting at bit `pos` (bit 0 of the result = position pos)
 __device__ __forceinline__ uint32_t bits_at(const uint32_t *map, uint32_t pos) {
     const uint32_t w = (pos >> 5) + kSpanMapFront;
@@ -715,7 +731,7 @@ __device__ __forceinline__ uint64_t block_bits(const uint32_t *map, uint32_t blk
 // one token from the staged stretch; offsets relative to lo (< kSpanLds).  Returns true when the staged bytes were not
 // enough: a float's scan runs `while not structural-or-blank`, and where the next structural is a scalar that follows
 // a quote (`1.5"a"b`: no blank or operator in front of it) that scan goes on past the next structural and may leave
-// the stretch -- the caller then takes span_of from global memory for this token.
+// the stretch -- the caller then puts the token on the work list of span_fixup.
 __device__ __forceinline__ bool staged_token(const uint8_t *stage, const uint32_t *m_num, const uint32_t *m_flt, const uint32_t *m_bs,
                                              const uint32_t *m_ink, const uint32_t *bs_blocks, uint64_t lo, uint32_t span, uint64_t len,
                                              uint32_t c, uint64_t start, uint64_t next, uint32_t &e_out, uint32_t &f_out) {
@@ -870,13 +886,12 @@ __device__ __forceinline__ bool staged_token_fast(const uint8_t *stage, const ui
     const bool bad = ends && !flt && p < rlen && !(wf & 1u);
     const uint32_t pe = flt ? min(p + min((uint32_t)(__ffs(wf) - 1), 32u), stop) : p;
     const bool more_flt = flt && wf == 0 && p + 32u < stop;
-    const bool lng_num = pe == stop && lo + stop < len;  // kSpanCap characters and still no end
-    const bool edge = lng_num && stop < rs + 1u + kSpanCap;  // ... or the stretch did (staged_token tells)
-    const uint32_t f_num = MSJ_SPAN_NUMBER | (flt ? MSJ_SPAN_FLOAT : 0u) | (lng_num ? MSJ_SPAN_LONG : (bad ? MSJ_SPAN_BAD : 0u));
-    const uint32_t e_num = lng_num ? 0u : lo + pe;
+    const bool no_end = pe == stop && lo + stop < len;  // kSpanCap characters and still no end, or the stretch ended: staged_token
+    const uint32_t f_num = MSJ_SPAN_NUMBER | (flt ? MSJ_SPAN_FLOAT : 0u) | (bad ? MSJ_SPAN_BAD : 0u);
+    const uint32_t e_num = lo + pe;
     e_out = is_str ? e_str : (is_num ? e_num : 0u);
     f_out = is_str ? f_str : (is_num ? f_num : 0u);
-    return !(is_str ? (more_ink || more_bs || far) : (is_num && (more_num || more_flt || edge)));
+    return !(is_str ? (more_ink || more_bs || far) : (is_num && (more_num || more_flt || no_end)));
 }
 
 // kFused: the kernel also writes the type byte of every token and the (sum, min, max, opening brackets)
@@ -885,7 +900,8 @@ __device__ __forceinline__ bool staged_token_fast(const uint8_t *stage, const ui
 template <bool kFused, bool kSpans = true>
 __global__ __launch_bounds__(kSpanThreads) void token_spans(const uint8_t *__restrict__ buf, uint64_t len, const uint32_t *__restrict__ idx,
                                                            uint64_t n, uint32_t *__restrict__ end, uint8_t *__restrict__ flags, uint32_t lds_limit,
-                                                           uint8_t *__restrict__ type, int4 *__restrict__ sub_agg) {
+                                                           uint8_t *__restrict__ type, int4 *__restrict__ sub_agg, uint32_t *__restrict__ fix,
+                                                           uint32_t fix_cap) {
     __shared__ __attribute__((aligned(16))) uint8_t stage[kSpanLds + 16];  // a number may be asked for the byte behind the stretch
     __shared__ __attribute__((aligned(8))) uint32_t m_num[kSpanMapWords], m_flt[kSpanMapWords], m_bs[kSpanMapWords], m_ink[kSpanMapWords];
     __shared__ __attribute__((aligned(4))) uint16_t bs_cnt[kSpanMapWords];  // set bits of m_bs in front of each word, from the wave's first block
@@ -1020,13 +1036,13 @@ __global__ __launch_bounds__(kSpanThreads) void token_spans(const uint8_t *__res
             uint32_t e, f;
             if (!staged_token_fast(stage, m_num, m_flt, m_bs, bs_cnt, m_ink, lo32, span, len32, cs, rs, rn, e, f) &&
                 staged_token(stage, m_num, m_flt, m_bs, m_ink, bs_blocks, lo, span, len, cs, lo + rs, lo + rn, e, f))
-                span_of(FromGlobal{buf, len}, lo + rs, lo + rn, len, e, f);
+                fix_later(fix, fix_cap, tok0 + (s0 ? 0u : 1u), e, f);
             e0 = s0 ? e : 0u, f0 = s0 ? f : 0u;
             e1 = s0 ? 0u : e, f1 = s0 ? 0u : f;
             if (s0 && s1) {  // two scalars in a row (not a valid document)
                 if (!staged_token_fast(stage, m_num, m_flt, m_bs, bs_cnt, m_ink, lo32, span, len32, c1, rs1, rn1, e1, f1) &&
                     staged_token(stage, m_num, m_flt, m_bs, m_ink, bs_blocks, lo, span, len, c1, start1, next1, e1, f1))
-                    span_of(FromGlobal{buf, len}, start1, next1, len, e1, f1);
+                    fix_later(fix, fix_cap, tok0 + 1u, e1, f1);
             }
         }
     }
@@ -1086,6 +1102,38 @@ __global__ __launch_bounds__(kSpanThreads) void token_spans(const uint8_t *__res
 
 #undef MSJ_SPAN_ARRIVED
 
+static uint32_t fix_cap() {  // host: the list's capacity for this launch
+    const char *env = getenv("MSJ_SPANS_FIX_CAP");
+    const unsigned long v = env ? strtoul(env, nullptr, 10) : kFixCap;
+    return (uint32_t)(v < kFixCap ? v : kFixCap);
+}
+
+// the tokens on the work list, from global memory; the last workgroup to finish clears the list for the next call
+__global__ __launch_bounds__(256) void span_fixup(const uint8_t *__restrict__ buf, uint64_t len, const uint32_t *__restrict__ idx, uint64_t n,
+                                                  uint32_t *__restrict__ end, uint8_t *__restrict__ flags, uint32_t *__restrict__ fix, uint32_t cap) {
+    const uint32_t count = __hip_atomic_load(&fix[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (count != 0) {
+        const uint32_t stride = gridDim.x * blockDim.x, me = blockIdx.x * blockDim.x + threadIdx.x;
+        const auto redo = [&](uint64_t tok) {
+            uint32_t e, f;
+            span_of(FromGlobal{buf, len}, (uint64_t)idx[tok], tok + 1 < n ? (uint64_t)idx[tok + 1] : len, len, e, f);
+            end[tok] = e;
+            flags[tok] = (uint8_t)f;
+        };
+        if (count <= cap) {
+            for (uint32_t k = me; k < count; k += stride) redo(fix[2 + k]);
+        } else {  // the list overflowed: every token that carries the sentinel
+            for (uint64_t tok = me; tok < n; tok += stride)
+                if (flags[tok] == kFixSentinel) redo(tok);
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0 && atomicAdd(&fix[1], 1u) == gridDim.x - 1u) {  // every workgroup has read the count
+        fix[1] = 0;
+        __hip_atomic_store(&fix[0], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+
 // block aggregates of the token pre-pass (kBlock tokens) from those of the fused kernel (kSpanTokens tokens)
 static_assert(kBlock % kSpanTokens == 0, "a block of the depth pass is a whole number of span workgroups");
 __global__ __launch_bounds__(256) void merge_sub_aggregates(const int4 *__restrict__ sub, uint32_t nsub, int32_t *__restrict__ block_agg,
@@ -1106,8 +1154,11 @@ __global__ __launch_bounds__(256) void merge_sub_aggregates(const int4 *__restri
 }
 }  // namespace msj_tokens
 
+// the work list of span_fixup: zeroed once by the owner (the kernels leave it zeroed)
+extern "C" uint64_t msj_span_fix_bytes(void) { return msj_tokens::kFixWords * sizeof(uint32_t); }
+
 extern "C" int msj_launch_token_spans(const uint8_t *d_buf, uint64_t len, const uint32_t *d_idx, uint64_t n, uint32_t *d_end,
-                                      uint8_t *d_flags, void *stream) {
+                                      uint8_t *d_flags, uint32_t *d_fix, void *stream) {
     if (n == 0) return 0;
     // MSJ_SPANS_LDS_LIMIT (tests): stretches over this many bytes take the global-memory path
     const char *env = getenv("MSJ_SPANS_LDS_LIMIT");
@@ -1115,7 +1166,9 @@ extern "C" int msj_launch_token_spans(const uint8_t *d_buf, uint64_t len, const 
     const uint32_t lds_limit = (uint32_t)(lim < msj_tokens::kSpanLds ? lim : msj_tokens::kSpanLds);
     hipLaunchKernelGGL(msj_tokens::token_spans<false>, dim3((uint32_t)((n + msj_tokens::kSpanTokens - 1) / msj_tokens::kSpanTokens)),
                        dim3(msj_tokens::kSpanThreads), 0, static_cast<hipStream_t>(stream), d_buf, len, d_idx, n, d_end, d_flags, lds_limit,
-                       static_cast<uint8_t *>(nullptr), static_cast<int4 *>(nullptr));
+                       static_cast<uint8_t *>(nullptr), static_cast<int4 *>(nullptr), d_fix, msj_tokens::fix_cap());
+    hipLaunchKernelGGL(msj_tokens::span_fixup, dim3(msj_tokens::kFixGroups), dim3(256), 0, static_cast<hipStream_t>(stream), d_buf, len, d_idx, n,
+                       d_end, d_flags, d_fix, msj_tokens::fix_cap());
     return (int)hipGetLastError();
 }
 
@@ -1129,7 +1182,7 @@ extern "C" uint64_t msj_stage2_prep_workspace_bytes(uint64_t n, int with_match) 
 
 extern "C" int msj_launch_stage2_prep(const uint8_t *d_buf, uint64_t len, const uint32_t *d_idx, uint64_t n, uint8_t *d_type,
                                       int32_t *d_depth, uint32_t *d_match, uint32_t *d_end, uint8_t *d_flags,
-                                      msj_tokens_result *d_result, int32_t *d_ws, void *stream) {
+                                      msj_tokens_result *d_result, int32_t *d_ws, uint32_t *d_fix, void *stream) {
     using namespace msj_tokens;
     hipStream_t s = static_cast<hipStream_t>(stream);
     const uint64_t nb64 = (n + kBlock - 1) / kBlock;
@@ -1143,7 +1196,8 @@ extern "C" int msj_launch_stage2_prep(const uint8_t *d_buf, uint64_t len, const 
         const char *env = getenv("MSJ_SPANS_LDS_LIMIT");
         const unsigned long lim = env ? strtoul(env, nullptr, 10) : kSpanLds;
         const uint32_t lds_limit = (uint32_t)(lim < kSpanLds ? lim : kSpanLds);
-        hipLaunchKernelGGL(token_spans<true>, dim3(nsub), dim3(kSpanThreads), 0, s, d_buf, len, d_idx, n, d_end, d_flags, lds_limit, d_type, sub);
+        hipLaunchKernelGGL(token_spans<true>, dim3(nsub), dim3(kSpanThreads), 0, s, d_buf, len, d_idx, n, d_end, d_flags, lds_limit, d_type, sub, d_fix, fix_cap());
+        hipLaunchKernelGGL(span_fixup, dim3(kFixGroups), dim3(256), 0, s, d_buf, len, d_idx, n, d_end, d_flags, d_fix, fix_cap());
         hipLaunchKernelGGL(merge_sub_aggregates, dim3((nb + 255u) / 256u), dim3(256), 0, s, sub, nsub, d_ws, nb);
     }
     return launch_depth_passes(d_idx, n, d_type, d_depth, d_match, d_result, d_ws, s);
@@ -1161,7 +1215,7 @@ extern "C" int msj_launch_tokens(const uint8_t *d_buf, uint64_t len, const uint3
     int4 *sub = reinterpret_cast<int4 *>(reinterpret_cast<uint8_t *>(d_ws) + tok_bytes);
     if (n) {
         hipLaunchKernelGGL((token_spans<true, false>), dim3(nsub), dim3(kSpanThreads), 0, s, d_buf, len, d_idx, n, static_cast<uint32_t *>(nullptr),
-                           static_cast<uint8_t *>(nullptr), kSpanLds, d_type, sub);
+                           static_cast<uint8_t *>(nullptr), kSpanLds, d_type, sub, static_cast<uint32_t *>(nullptr), 0u);
         hipLaunchKernelGGL(merge_sub_aggregates, dim3((nb + 255u) / 256u), dim3(256), 0, s, sub, nsub, d_ws, nb);
     }
     return launch_depth_passes(d_idx, n, d_type, d_depth, d_match, d_result, d_ws, s);

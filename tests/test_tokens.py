@@ -255,6 +255,13 @@ def test_token_spans(dev, lds_limit, monkeypatch):
     for fill in (253, 254, 255, 256, 257):
         for tail in (300, 2000):
             _check_spans(dev, b"[" + b"1," * fill + b'1.5"xx"' + b"y" * tail + b" ,7]", f"float scan leaves the stretch ({fill}, {tail})")
+    # ... many of them: the work list of the fix-up pass, and (capacity lowered to 3 entries) its overflow path
+    many = b"[" + (b"1," * 255 + b'1.5"xx"' + b"y" * 300 + b" ,") * 40 + b"7]"
+    _check_spans(dev, many, "forty tokens on the fix-up list")
+    monkeypatch.setenv("MSJ_SPANS_FIX_CAP", "3")
+    _check_spans(dev, many, "the fix-up list overflows")
+    monkeypatch.delenv("MSJ_SPANS_FIX_CAP")
+    _check_spans(dev, many, "the list is clean again")
     # the closing quote is found from the NEXT structural: byte soups (valid or not) must agree with the forward scan
     rng = np.random.default_rng(9)
     alphabets = [b'{}[],: \n"\\ab1', b'""\\\\ a,', b'"abc\\" \t:1e5-', b'"\\" \r\n"x']
