@@ -236,9 +236,11 @@ def test_gloo_world2_live_protocol():
     rng = random.Random(8)
     alpha = b'\\\\\\""a1 ,:[]{}'
     cases = []
-    for trial in range(3):
-        data = bytes(rng.choice(alpha) for _ in range(300))
-        cases.append((data, [0, rng.randint(80, 220), len(data)]))
+    alphabets = [alpha, b'{}[]:,"\\ abtrue1.5e\n', b'"xyz\\" \t:,', b'{"k":"v w","n":[1,2.5e3,true,null]} ']
+    for trial in range(48):
+        a = alphabets[trial % len(alphabets)]
+        data = bytes(rng.choice(a) for _ in range(rng.randint(150, 400)))
+        cases.append((data, [0, rng.randint(70, len(data) - 70), len(data)]))
     # the cut falls inside a string whose closing quote follows a ':' -> rank 1's guess is refuted
     wrong = b'["' + b"a" * 90 + b':",1,2,"ee"]'
     cases.append((wrong, [0, 40, len(wrong)]))
