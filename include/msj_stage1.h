@@ -228,7 +228,9 @@ typedef struct msj_shard_report {
 
 /* Carries a shard may assume from its own bytes: halo = the <= 64 stream bytes in front of it (halo_len 0 at the
  * start of the stream), head = its first <= 4096 bytes.  next_is_escaped / prev_scalar are exact unless a run of
- * backslashes reaches halo[0]; in_string is a guess from the context of the first unescaped quote. */
+ * backslashes reaches halo[0]; in_string is a guess: the head is followed under both hypotheses until one meets a byte
+ * it cannot hold (a control character inside a string; outside of strings anything but blanks, operators, number
+ * characters and the letters of true / false / null), else the neighbours of the first unescaped quote decide. */
 int32_t msj_shard_speculate(const uint8_t *halo, uint64_t halo_len, const uint8_t *head, uint64_t head_len,
                             msj_carry *out);
 /* Replays the chain of all ranks' reports.  exact_in[g] (world entries) receives the exact carry at the start of
