@@ -639,6 +639,7 @@ def test_sharded_world8_one_gpu(torch_mod, oracle):
             d_idx = torch.full((hi - lo + 3,), -1, dtype=torch.int32, device=dev.device)
             nseg = -(-(hi - lo) // (64 << 10))
             d_seg = torch.zeros(nseg * 32, dtype=torch.uint8, device=dev.device)
+            stream.wait_stream(torch.cuda.current_stream(dev.device))  # the fills above ran on this thread's current stream
             ticket = ctypes.c_uint32()
             rc = L.msj_stage1_sharded_submit(h, ctypes.c_void_p(d_shard.data_ptr()), hi - lo, ctypes.c_void_p(d_idx.data_ptr()),
                                              d_idx.numel(), total, int(rank > 0), None, ctypes.c_void_p(d_seg.data_ptr()), nseg,
