@@ -5,7 +5,7 @@ Byte soups over an alphabet chosen to hit every carry (quotes, long backslash ru
 operators, control characters, multi-byte UTF-8 incl. invalid sequences) at sizes from a few
 bytes to tens of MiB, with density changing along the stream; every index, the count, the
 trailer, the return code and the strict UTF-8 verdict are compared with the oracle.
-usage: tests/stress.py [seconds] [seed]
+usage: tests/stress.py [seconds] [seed]      (MSJ_STRESS_FLAGS=0x100: through the two-pass fallback kernels)
 """
 import os
 import sys
@@ -51,6 +51,7 @@ def main():
 
     budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
     seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+    flags = int(os.environ.get("MSJ_STRESS_FLAGS", "0"), 0)  # e.g. 0x100 = MSJ_FLAG_TWO_PASS: the fallback kernels
     rng = np.random.default_rng(seed)
     oracle = helpers.load_oracle()
     dev = Stage1Device(0)
@@ -70,7 +71,7 @@ def main():
         d_buf = torch.from_numpy(np.frombuffer(data, dtype=np.uint8).copy()).to(dev.device)
         d_idx = torch.full((n + 3 + 4,), -1, dtype=torch.int32, device=dev.device)
         d_res = dev.new_carry()
-        dev.index(d_buf, d_idx, d_res)
+        dev.index(d_buf, d_idx, d_res, flags=flags)
         r = dev.fetch(d_res)
         tag = f"case {cases} (seed {seed}, len {n})"
         assert r.internal_error == 0, tag
