@@ -293,6 +293,9 @@ int32_t msj_stage1_sharded_submit(msj_sharded *sh, const uint8_t *d_shard, uint6
  * msj_carry (count = its own structurals); *used_out: the exact carry at its first byte. */
 int32_t msj_stage1_sharded_result(msj_sharded *sh, uint32_t ticket, int32_t *code_out, uint64_t *total_count_out,
                                   msj_carry *local_out, msj_carry *used_out);
+/* Test hook: host-pointer inputs of at least this many bytes go through the chunked pinned pipeline of msj_stage1
+ * (default 64 MiB; 0 restores it).  ctx NULL: the default context. */
+int32_t msj_debug_set_pipeline_min_bytes(msj_ctx *ctx, uint64_t bytes);
 /* Test hook: longest segment (bytes, multiple of 4096) one launch indexes; default MSJ_MAX_SEGMENT_BYTES rounded
  * down to the tile. */
 int32_t msj_debug_set_segment_bytes(msj_ctx *ctx, uint64_t bytes);

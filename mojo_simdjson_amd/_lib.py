@@ -139,6 +139,8 @@ def load():
     lib.msj_host_register.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint64]
     lib.msj_host_unregister.restype = ctypes.c_int32
     lib.msj_host_unregister.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
+    lib.msj_debug_set_pipeline_min_bytes.restype = ctypes.c_int32
+    lib.msj_debug_set_pipeline_min_bytes.argtypes = [ctypes.c_void_p, ctypes.c_uint64]
     lib.msj_fallback_count.restype = ctypes.c_uint64
     lib.msj_fallback_count.argtypes = [ctypes.c_void_p]
     lib.msj_stage1_shard_device.restype = ctypes.c_int32

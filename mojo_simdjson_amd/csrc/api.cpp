@@ -26,7 +26,7 @@
 // small-input path of msj_stage1: input, result and len + 3 indices fit the pinned staging buffer
 constexpr uint64_t kSmallInput = 64u << 10;
 // from here on msj_stage1 stages through pinned rings in chunks (host_pipeline)
-constexpr uint64_t kPipelineMin = 24u << 20;
+constexpr uint64_t kPipelineMinDefault = 64u << 20;  // (below that plain staging is as fast or faster; test hook: msj_debug_set_pipeline_min_bytes)
 constexpr uint64_t kPinBytes = kSmallInput + 64 + (kSmallInput + 3) * sizeof(uint32_t) + 64;
 
 static_assert(sizeof(msj_carry) == 64, "the small-input staging layout assumes a 64-byte carry");
@@ -58,6 +58,7 @@ struct msj_ctx {
     uint32_t grid = 0;            // persistent workgroups per launch (CUs x resident blocks per CU)
     uint32_t wait_ticks = msj::kWaitTicksDefault;  // bound of the kernel's waits (10 ns ticks)
     uint64_t seg_bytes = msj::kSegmentBytes;  // longest segment of one launch (test hook: msj_debug_set_segment_bytes)
+    uint64_t pipeline_min = kPipelineMinDefault;  // host-pointer inputs from this size on take the chunked pipeline
     uint64_t *tp = nullptr;       // workspace of the two-pass path (2 words per tile), allocated on first use
     uint64_t tp_words = 0;
     uint64_t fallbacks = 0;       // calls re-issued through the two-pass path after an expired wait
@@ -425,18 +426,21 @@ int32_t host_pipeline(msj_ctx *ctx, const uint8_t *buf, uint64_t len, uint32_t *
                 continue;
             }
             const uint64_t piece = HostPipe::kPiece / sizeof(uint32_t);
-            while (avail - sent >= piece || (last && sent < avail)) {
-                const uint64_t n = avail - sent < piece ? avail - sent : piece;
+            while (sent < avail) {  // whatever this chunk added, in pieces of at most one slot
+                // source and slot keep the same offset inside a 256-byte line: a DMA between differently aligned
+                // ends runs at half the rate
+                const uint64_t mis = sent & 63u;
+                const uint64_t n = avail - sent < piece - mis ? avail - sent : piece - mis;
                 const int slot = (int)(pieces % HostPipe::kOutSlots);
                 CopyPool::wait(&copying[slot]);  // the piece that used this slot has been copied out
                 // the DMA into the pinned slot (this call returns when it is done), then the copy into the
                 // caller's memory by the pool while the next piece's DMA runs
-                if (!hip_ok(hipMemcpyAsync(P.pin_out[slot], ctx->d_idx + sent, n * sizeof(uint32_t), hipMemcpyDeviceToHost, P.s_down)) ||
+                if (!hip_ok(hipMemcpyAsync(P.pin_out[slot], ctx->d_idx + (sent - mis), (n + mis) * sizeof(uint32_t), hipMemcpyDeviceToHost, P.s_down)) ||
                     !hip_ok(hipStreamSynchronize(P.s_down))) {
                     down_rc = MSJ_ERR_HIP;
                     break;
                 }
-                P.pool.copy_async(idx_out + sent, P.pin_out[slot], n * sizeof(uint32_t), P.kParts, &copying[slot]);
+                P.pool.copy_async(idx_out + sent, P.pin_out[slot] + mis * sizeof(uint32_t), n * sizeof(uint32_t), P.kParts, &copying[slot]);
                 sent += n;
                 pieces++;
                 if (trace) t_piece.push_back(now() - t_begin);
@@ -829,6 +833,17 @@ int32_t msj_host_unregister(msj_ctx *ctx, void *ptr) {
 
 uint64_t msj_fallback_count(const msj_ctx *ctx) { return ctx ? ctx->fallbacks : 0; }
 
+int32_t msj_debug_set_pipeline_min_bytes(msj_ctx *ctx, uint64_t bytes) {
+    std::unique_lock<std::mutex> lock(g_default_mutex, std::defer_lock);
+    if (!ctx) {
+        lock.lock();
+        ctx = default_ctx_locked();
+        if (!ctx) return MSJ_ERR_NO_DEVICE;
+    }
+    ctx->pipeline_min = bytes ? bytes : kPipelineMinDefault;
+    return MSJ_SUCCESS;
+}
+
 int32_t msj_debug_set_segment_bytes(msj_ctx *ctx, uint64_t bytes) {
     if (!ctx || bytes == 0 || bytes % msj::kTileBytes != 0 || bytes > msj::kSegmentBytes) return MSJ_ERR_BAD_ARGUMENT;
     ctx->seg_bytes = bytes;
@@ -898,7 +913,7 @@ int32_t msj_stage1_ctx(msj_ctx *ctx, const uint8_t *buf, uint64_t len, uint32_t 
     msj_carry res;
     int32_t rc;
     static const bool pipe_off = std::getenv("MSJ_PIPE_DISABLE") != nullptr;  // measurement aid: the plain staging path
-    const bool piped = len >= kPipelineMin && !(flags & MSJ_FLAG_TWO_PASS) && !pipe_off;
+    const bool piped = len >= ctx->pipeline_min && !(flags & MSJ_FLAG_TWO_PASS) && !pipe_off;
     if (piped) {
         // large inputs: pinned rings, chunks, both PCIe directions and the kernel at once
         rc = host_pipeline(ctx, buf, len, idx_out, dev_cap, flags, &res);

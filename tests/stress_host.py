@@ -28,6 +28,7 @@ def main():
     rng = np.random.default_rng(seed)
     oracle = helpers.load_oracle()
     lib = _lib.load()
+    lib.msj_debug_set_pipeline_min_bytes(None, 24 << 20)  # (default 64 MiB) both paths within the sizes below
     parser = DomParserImplementation()
     mib = 1 << 20
     sizes = [1, 63, 4097, 65535, 65536, 65537, 3 * mib + 5, 16 * mib - 1, 24 * mib - 1, 24 * mib, 24 * mib + 1,

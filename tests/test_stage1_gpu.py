@@ -840,8 +840,10 @@ def test_random_byte_soups():
 def test_host_pointer_large_inputs(oracle):
     """The host-pointer entry point on inputs of 50-64 MiB: same bits as the oracle, also for the
     error codes and the reference's capacity quirk."""
-    from mojo_simdjson_amd import synth
+    from mojo_simdjson_amd import _lib, synth
 
+    # from 24 MiB on through the chunked pipeline (the default threshold is 64 MiB: the largest input here is just over)
+    assert _lib.load().msj_debug_set_pipeline_min_bytes(None, 24 << 20) == 0
     base = synth.workload("minified", 52 << 20).tobytes()
     assert len(base) > 48 << 20
     assert_matches_oracle(oracle, base, "52 MiB minified")
@@ -856,6 +858,8 @@ def test_host_pointer_large_inputs(oracle):
     # the reference's capacity quirk: all structural, n + 3 > len
     dense = b"[" * (50 << 20)
     assert_matches_oracle(oracle, dense, "50 MiB of brackets")
+    assert _lib.load().msj_debug_set_pipeline_min_bytes(None, 0) == 0
+    assert_matches_oracle(oracle, base, "52 MiB minified, plain staging")
 
 
 def test_host_pointer_registered_buffers(oracle):
@@ -867,6 +871,7 @@ def test_host_pointer_registered_buffers(oracle):
     from mojo_simdjson_amd import _lib, synth
 
     lib = _lib.load()
+    assert lib.msj_debug_set_pipeline_min_bytes(None, 24 << 20) == 0  # 40 MiB: through the chunked pipeline
     data = synth.workload("minified", 40 << 20).tobytes() + b" [1,2]"
     code, n, want = helpers.run_oracle(oracle.msj_oracle_stage1, data)
     assert code == 0
@@ -896,6 +901,7 @@ def test_host_pointer_registered_buffers(oracle):
     run(arena[: len(data) + 3], inbuf)                    # input direct, indices staged again
     assert lib.msj_host_unregister(None, vp(inbuf)) == 0
     run(arena[: len(data) + 3], inbuf)
+    assert lib.msj_debug_set_pipeline_min_bytes(None, 0) == 0
 
 
 def test_shard_carry_out_at_any_length(torch_mod, dev, oracle):
