@@ -397,6 +397,10 @@ def main():
                 "measured_read_peak": measured.get("read_4gib"),
                 "frac_of_measured_read": (round(achieved / measured["read_4gib"], 4)
                                           if measured.get("read_4gib") else None),
+                # ... and the stricter reading of the same target: input bytes only over the measured read bandwidth
+                # (at density d it cannot exceed the same-mix ceiling / (1 + 4 d))
+                "ingest_frac_of_measured_read": (round(value / world / measured["read_4gib"], 4)
+                                                 if measured.get("read_4gib") else None),
                 "measured_same_mix_peak": measured.get("mix_r1_w0775_1gib"),
             },
             "cpu_baseline": cpu,
