@@ -23,8 +23,10 @@
 #include "../../include/msj_stage1.h"
 #include "stage1_kernel.h"
 
-// small-input path of msj_stage1: input, result and len + 3 indices fit the pinned staging buffer
-constexpr uint64_t kSmallInput = 64u << 10;
+// small-input path of msj_stage1: input, result and len + 3 indices fit the pinned staging buffer, which the kernel
+// reads and writes itself over PCIe (no DMA calls; measured against staged copies: 77 B 24 -> 22 us, 13 KB 33 -> 23,
+// 62 KB 45 -> 30, 258 KB 76 -> 42, 1 MB 136 -> 104; 4 MB 242 -> 371, hence the limit)
+constexpr uint64_t kSmallInput = 1u << 20;
 // from here on msj_stage1 stages through pinned rings in chunks (host_pipeline)
 constexpr uint64_t kPipelineMinDefault = 64u << 20;  // (below that plain staging is as fast or faster; test hook: msj_debug_set_pipeline_min_bytes)
 constexpr uint64_t kPinBytes = kSmallInput + 64 + (kSmallInput + 3) * sizeof(uint32_t) + 64;
@@ -54,7 +56,7 @@ struct msj_ctx {
     uint64_t d_idx_words = 0;
     msj_carry *d_result = nullptr;
     uint8_t *h_pin = nullptr;     // pinned host staging of the small-input path of msj_stage1 (kPinBytes)
-    uint8_t *d_small = nullptr;   // ... and its device side: [input][msj_carry][indices], same layout
+    uint8_t *d_small = nullptr;   // ... and the msj_carry of that path (device memory: the kernel updates it with atomics)
     uint32_t grid = 0;            // persistent workgroups per launch (CUs x resident blocks per CU)
     uint32_t wait_ticks = msj::kWaitTicksDefault;  // bound of the kernel's waits (10 ns ticks)
     uint64_t seg_bytes = msj::kSegmentBytes;  // longest segment of one launch (test hook: msj_debug_set_segment_bytes)
@@ -864,17 +866,18 @@ int32_t msj_stage1_ctx(msj_ctx *ctx, const uint8_t *buf, uint64_t len, uint32_t 
     // is cheap at this size) -- and the host waits once instead of three times (pageable copies are synchronous).
     if (len <= kSmallInput && idx_capacity >= len + 3) {
         if (!ctx->h_pin && !hip_ok(hipHostMalloc(reinterpret_cast<void **>(&ctx->h_pin), kPinBytes, hipHostMallocDefault))) ctx->h_pin = nullptr;
-        if (!ctx->d_small && !hip_ok(hipMalloc(reinterpret_cast<void **>(&ctx->d_small), kPinBytes))) ctx->d_small = nullptr;
+        if (!ctx->d_small && !hip_ok(hipMalloc(reinterpret_cast<void **>(&ctx->d_small), sizeof(msj_carry)))) ctx->d_small = nullptr;
     }
     if (len <= kSmallInput && idx_capacity >= len + 3 && ctx->h_pin && ctx->d_small) {
-        // [0, kSmallInput): input | [kSmallInput, +64): msj_carry | then len + 3 indices
+        // pinned: [0, kSmallInput): input | [kSmallInput, +64): msj_carry | then len + 3 indices.  The kernel reads the
+        // input from there and writes the indices there; the 64-byte result lives in device memory (the kernel
+        // updates it with atomics) and comes down by the one copy of the call
         std::memcpy(ctx->h_pin, buf, len);
-        if (!hip_ok(hipMemcpyAsync(ctx->d_small, ctx->h_pin, len, hipMemcpyHostToDevice, nullptr))) return MSJ_ERR_HIP;
-        msj_carry *d_res = reinterpret_cast<msj_carry *>(ctx->d_small + kSmallInput);
-        uint32_t *d_ix = reinterpret_cast<uint32_t *>(ctx->d_small + kSmallInput + 64);
-        int32_t rc = msj_stage1_device(ctx, ctx->d_small, len, d_ix, len + 3, d_res, nullptr, flags);
+        msj_carry *d_res = reinterpret_cast<msj_carry *>(ctx->d_small);
+        uint32_t *h_ix = reinterpret_cast<uint32_t *>(ctx->h_pin + kSmallInput + 64);
+        int32_t rc = msj_stage1_device(ctx, ctx->h_pin, len, h_ix, len + 3, d_res, nullptr, flags);
         if (rc != MSJ_SUCCESS) return rc;
-        if (!hip_ok(hipMemcpyAsync(ctx->h_pin + kSmallInput, d_res, 64 + (len + 3) * sizeof(uint32_t), hipMemcpyDeviceToHost, nullptr)) ||
+        if (!hip_ok(hipMemcpyAsync(ctx->h_pin + kSmallInput, d_res, sizeof(msj_carry), hipMemcpyDeviceToHost, nullptr)) ||
             !hip_ok(hipStreamSynchronize(nullptr)))
             return MSJ_ERR_HIP;
         const msj_carry res = *reinterpret_cast<const msj_carry *>(ctx->h_pin + kSmallInput);

@@ -1,8 +1,8 @@
 #!/usr/bin/env python3
 """Randomised parity stress of the host-pointer entry point on the GPU box (not part of pytest: runs for minutes).
 
-Byte soups of tests/stress.py at sizes on both sides of every switch of msj_stage1 (the 64 KiB pinned round trip,
-plain staging, the 24 MiB chunked pipeline and its 16 MiB chunks), through ONE reused DomParserImplementation -- its
+Byte soups of tests/stress.py at sizes on both sides of every switch of msj_stage1 (the zero-copy pinned path up to 1 MiB,
+plain staging, the chunked pipeline -- set to start at 24 MiB here -- and its 16 MiB chunks), through ONE reused DomParserImplementation -- its
 index array grows, gets pinned (msj_host_register) and is reused, like the reference's list -- and through the C entry
 point with fresh pageable arrays.  Code, count, every index and the trailer against the oracle.
 usage: tests/stress_host.py [seconds] [seed]
@@ -31,7 +31,7 @@ def main():
     lib.msj_debug_set_pipeline_min_bytes(None, 24 << 20)  # (default 64 MiB) both paths within the sizes below
     parser = DomParserImplementation()
     mib = 1 << 20
-    sizes = [1, 63, 4097, 65535, 65536, 65537, 3 * mib + 5, 16 * mib - 1, 24 * mib - 1, 24 * mib, 24 * mib + 1,
+    sizes = [1, 63, 4097, 65535, 65536, 65537, mib - 1, mib, mib + 1, 3 * mib + 5, 16 * mib - 1, 24 * mib - 1, 24 * mib, 24 * mib + 1,
              32 * mib, 32 * mib + 4099, 40 * mib + 17, 48 * mib]
     t0 = time.time()
     cases = nbytes = 0
