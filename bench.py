@@ -416,6 +416,9 @@ def main():
                 "note": "rank 0's clock; the first ~100 ms after idle run 10-15 % slower than the sustained rate",
             }
         print(json.dumps(out), flush=True)
+    if world > 1:
+        barrier()
+        sh.close()  # the RCCL communicator of the stitch goes before torch's process group does
     dev.close()
     if dist is not None:
         dist.destroy_process_group()
