@@ -6,8 +6,21 @@ rank's device-resident shard of the synthetic stream:
 
   N = 1 : BASELINE.json configs[1], 1 GiB minified ASCII twitter-like JSON
           (a ~64 MiB generated unit repeated; exact size printed in `config`).
-  N > 1 : the same stream grown to N x 1 GiB, cut into N byte-range shards
-          (weak scaling); every step includes the RCCL stitch (sharded.py).
+  N > 1 : BASELINE.json configs[4]'s per-rank share: the same stream grown to
+          N x 8 GiB (64 GiB at N = 8), cut into N byte-range shards that start
+          and end anywhere inside a unit (weak scaling; `--gib-per-gpu` overrides);
+          every step includes the RCCL stitch (sharded.py: one all-gather of 128
+          bytes per rank, the library calls ncclAllGather itself).
+
+`python bench.py --gpus N` without a launcher environment starts the N ranks itself
+(torch.distributed.run as a CHILD process, before anything here touches a GPU) and
+relays their output and exit code; under the driver's launcher (WORLD_SIZE set) it
+is one of the ranks.
+
+After the timed window every rank verifies its own index array ON THE DEVICE against
+the replication property (tests/replication.py: every index, placed with the offsets
+the stitch returned) and contributes a 64-bit hash to one all-gather; rank 0 compares
+the sum with the closed form of the oracle's unit indices: `config.verified`.
 
 Output: ONE JSON line on rank 0 (contract in the task statement), with
 `roofline` for the dominant kernel (stage1_kernel) and `cpu_baseline` (the
@@ -16,6 +29,8 @@ oracle's block-for-block restatement of the reference, 1 thread, bounded sample)
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -33,39 +48,29 @@ UNIT_BYTES = 64 << 20
 SHARD_ALIGN = 16384  # shard bases are multiples of this (four of the kernel's 4 KiB tiles: 16-byte aligned bases)
 
 
-def build_stream_shard(d_unit, unit_len, start, length, device):
-    """Bytes [start, start+length) of the infinite repetition of the unit."""
-    parts = []
-    off = start % unit_len
-    remaining = length
-    first = min(unit_len - off, remaining)
-    parts.append(d_unit[off:off + first])
-    remaining -= first
-    full = remaining // unit_len
-    if full:
-        parts.append(d_unit.repeat(full))
-    remaining -= full * unit_len
-    if remaining:
-        parts.append(d_unit[:remaining])
-    return torch.cat(parts)
-
-
-def cpu_baseline(unit, budget_s=10.0, timed=True):
-    """Reference-faithful CPU port (oracle/stage1_oracle.c, 1 thread) on a bounded sample.
-
-    The only place bench.py touches oracle/: the timed baseline, and the expected structural count
-    of the unit that the GPU result is checked against (timed=False: only that count)."""
+def unit_indices(unit):
+    """The oracle's structural indices of one unit (checker only: what the GPU result is verified against after
+    the timed window).  oracle/stage1_fast.c gives the port's results bit for bit (tests/test_oracle_fast.py) in a
+    fraction of its time, and every rank needs them."""
     import ctypes
 
     from tests import helpers
 
-    if not timed:
-        f = helpers.load_oracle_fast()
-        data = unit.tobytes()
-        idx = np.zeros(len(data) + 3, dtype=np.uint32)
-        nn = ctypes.c_uint64(0)
-        rc = f.msj_fast_stage1(data, len(data), idx.ctypes.data, idx.size, ctypes.byref(nn))
-        return None, (int(nn.value) if rc == 0 else None)
+    f = helpers.load_oracle_fast()
+    data = unit.tobytes()
+    idx = np.zeros(len(data) + 3, dtype=np.uint32)
+    nn = ctypes.c_uint64(0)
+    rc = f.msj_fast_stage1(data, len(data), idx.ctypes.data, idx.size, ctypes.byref(nn))
+    assert rc == 0, f"the oracle rejects the synthetic unit: {rc}"
+    return idx[: int(nn.value)].copy()
+
+
+def cpu_baseline(unit, budget_s=10.0):
+    """Reference-faithful CPU port (oracle/stage1_oracle.c, 1 thread) on a bounded sample: the timed baseline.
+    (bench.py touches oracle/ here and in unit_indices(), nowhere else, and never inside a timed window.)"""
+    import ctypes
+
+    from tests import helpers
 
     o = helpers.load_oracle()
     o.msj_oracle_stage1_repeat.restype = ctypes.c_int32
@@ -144,7 +149,22 @@ def cpu_baseline(unit, budget_s=10.0, timed=True):
         }
     except Exception as exc:  # measurement extra: never fails the bench
         out["not_the_reference"] = {"error": repr(exc)}
-    return out, int(n.value)
+    return out
+
+
+def self_launch(args):
+    """`python bench.py --gpus N` from a plain command line: start the N ranks as a child process tree
+    (torch.distributed.run, one process per GPU) BEFORE anything in this process touches a GPU, relay their
+    output (rank 0 prints the JSON line) and leave with their exit code.  Never an exec: a process that has
+    initialised the GPU must not be replaced, and this one has not even done that."""
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    return subprocess.run(cmd, env=env).returncode
 
 
 def main():
@@ -154,7 +174,12 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="minified",
                     choices=["minified", "utf8", "pretty2", "pretty4", "pretty8", "pretty_tab_crlf"])
-    ap.add_argument("--gib-per-gpu", type=float, default=1.0)
+    ap.add_argument("--gib-per-gpu", type=float, default=None,
+                    help="stream bytes per GPU; default 1 (BASELINE config 2) at N = 1, 8 (config 5: 64 GiB over 8 GPUs) at N > 1")
+    ap.add_argument("--lib", default=None,
+                    help="measurement aid: load this build of libmsj_stage1.so instead of the package's (A/B of kernel "
+                         "variants in one GPU session); reported as config.library")
+    ap.add_argument("--no-verify", action="store_true", help="skip the index-by-index verification after the timed window")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-utf8", action="store_true", help="skip UTF-8 validation (not the headline config)")
     ap.add_argument("--settle-ms", type=float, default=400.0,
@@ -165,11 +190,19 @@ def main():
     ap.add_argument("--no-emit", action="store_true",
                     help="diagnostic: summary pass only, no index writes (never a reported number)")
     args = ap.parse_args()
+    if args.gib_per_gpu is None:
+        args.gib_per_gpu = 1.0 if args.gpus == 1 else 8.0
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(args))  # nothing above or in the imports has touched a GPU
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    if args.lib:
+        from mojo_simdjson_amd import _lib
+
+        _lib.LIB_PATH = os.path.abspath(args.lib)
     # one process per GPU; MSJ_BENCH_BACKEND=gloo lets several ranks share one GPU to
     # rehearse the N>1 path on a one-GPU box (never used for reported numbers)
     backend = os.environ.get("MSJ_BENCH_BACKEND", "nccl")
@@ -205,20 +238,23 @@ def main():
     shard_len = max(0, min(total_len, start + shard_len_nominal) - start)
     assert shard_len > 0
     halo = 64 if rank > 0 else 0
-    d_alloc = build_stream_shard(d_unit, unit_len, start - halo, shard_len + halo, device)
+    d_alloc = synth.stream_shard(d_unit, unit_len, start - halo, shard_len + halo)
     d_shard = d_alloc[halo:]
     assert d_shard.data_ptr() % 16 == 0
 
-    # ---- expected result (rank 0 computes the unit's count with the oracle: checker only)
+    # ---- expected result: the oracle's indices of ONE unit (checker only, outside every timed window)
+    u_idx = unit_indices(unit)
+    unit_n = int(u_idx.size)
     cpu = None
-    unit_n = None
-    if rank == 0:
-        # timed CPU baseline at N = 1 only; otherwise just the expected count (checker)
-        cpu, unit_n = cpu_baseline(unit, timed=(world == 1 and not args.no_cpu_baseline))
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        cpu = cpu_baseline(unit)  # timed CPU baseline on rank 0 at N = 1 only
 
     cap = int(shard_len * 0.75) + 1024  # index slots for this shard (density < 0.75 for every workload here)
     d_idx = torch.empty(cap, dtype=torch.int32, device=device)
     d_res = dev.new_carry()
+    n_seg_max = 8
+    d_seg = torch.zeros(n_seg_max * 32, dtype=torch.uint8, device=device)  # msj_segment table of the shard
+    sh = None
 
     if world == 1 and args.no_emit:
         d_zero = dev.new_carry()
@@ -236,7 +272,8 @@ def main():
         d_zero = dev.new_carry()
 
         def step():
-            dev.shard(d_shard, shard_len, d_idx, d_zero, d_res, is_final=True, trailer_len=total_len, flags=flags)
+            dev.shard(d_shard, shard_len, d_idx, d_zero, d_res, segments=d_seg, is_final=True, trailer_len=total_len,
+                      flags=flags)
             return None
     else:
         from mojo_simdjson_amd.sharded import ShardedStage1
@@ -254,7 +291,7 @@ def main():
             # after the first verified run the exact carry-in of this (unchanged) shard is known: a
             # refuted guess costs one re-run once, not one per step
             return sh.submit(d_shard, shard_len, d_idx, total_len, has_prefix=(rank > 0), flags=flags,
-                             speculation=sh.last_spec or spec)
+                             segments=d_seg, speculation=sh.last_spec or spec)
 
         def step():
             return sh.result(submit())
@@ -313,7 +350,9 @@ def main():
                 dist.all_reduce(flag, op=dist.ReduceOp.MIN)  # every rank leaves in the same round
             if float(flag.item()) == 0.0:
                 break
+    stats0 = sh.stats() if sh is not None else None
     dt, ev_ms, last_timed = timed_window()
+    stats1 = sh.stats() if sh is not None else None
     if last_timed is not None:
         last = last_timed
 
@@ -323,21 +362,80 @@ def main():
         code, total_count = int(res.code), int(res.count)
         assert res.internal_error == 0
         assert int(res.bytes) == shard_len and total_count > 0, (int(res.bytes), shard_len, total_count)
+        placement = (0, 0, total_count, shard_len)
     else:
         code, total_count, res = last
+        placement = sh.last_placement
     assert code == 0, f"stage 1 returned {code}"
-    if unit_n is not None:
-        assert total_count == unit_n * (total_len // unit_len), (total_count, unit_n)
+    reps = total_len // unit_len
+    assert total_count == unit_n * reps, (total_count, unit_n, reps)
+    local_count = int(res.count) if world > 1 else total_count
+
+    # ---- every index of this rank's shard, on the device, placed with the offsets the stitch returned
+    #      (tests/replication.py; SURVEY.md section 8d config 5: device-side checker + 64-bit hash)
+    verified, verify_detail = "count", None
+    if not (args.no_verify or args.no_emit):
+        from tests import replication
+
+        torch.cuda.synchronize()
+        index_begin, byte_base, cnt, nbytes = placement
+        assert (byte_base, cnt, nbytes) == (start, local_count, shard_len), (placement, start, local_count, shard_len)
+        segs = None
+        if world > 1 or shard_len > 0xFFFFFFFF:
+            nseg = -(-shard_len // 0xFFFF0000)
+            table = np.frombuffer(d_seg.cpu().numpy().tobytes(), dtype=np.uint64).reshape(n_seg_max, 4)[:nseg]
+            segs = [(int(r[0]), int(r[2]), int(r[3])) for r in table]
+            assert sum(sg[2] for sg in segs) == local_count, (segs, local_count)
+        d_uidx = torch.from_numpy(u_idx.astype(np.int64)).to(device)
+        bad, h = replication.check_shard(torch, d_idx, local_count, d_uidx, unit_len, byte_base, index_begin, segs)
+        want_begin = replication.expected_index_begin(u_idx, unit_len, start)
+        tail_ok = True
+        if rank == world - 1:
+            tail = (d_idx[local_count:local_count + 3].to(torch.int64) & 0xFFFFFFFF).tolist()
+            tail_ok = tail == [total_len & 0xFFFFFFFF, total_len & 0xFFFFFFFF, 0]
+        # one all-gather of (mismatches, hash, index_begin ok, trailer ok) per rank
+        mine = torch.tensor([bad, h - (1 << 64) if h >= (1 << 63) else h, int(index_begin == want_begin), int(tail_ok)],
+                            dtype=torch.int64, device=device if backend == "nccl" else "cpu")
+        if dist is not None:
+            allv = [torch.empty_like(mine) for _ in range(world)]
+            dist.all_gather(allv, mine)
+        else:
+            allv = [mine]
+        rows = [[int(x) for x in v.tolist()] for v in allv]
+        h_sum = sum(r[1] for r in rows) & replication.MASK64
+        h_want = replication.stream_hash(u_idx, unit_len, reps)
+        ok = all(r[0] == 0 and r[2] == 1 and r[3] == 1 for r in rows) and h_sum == h_want
+        verify_detail = {"mismatches": sum(r[0] for r in rows), "hash": f"{h_sum:016x}", "hash_expected": f"{h_want:016x}",
+                         "index_begin_ok": all(r[2] == 1 for r in rows), "trailer_ok": all(r[3] == 1 for r in rows)}
+        assert ok, f"index verification failed: {verify_detail} (per rank: {rows})"
+        verified = "indices"
+        del d_uidx
 
     t = torch.tensor([dt], dtype=torch.float64, device=device if backend == "nccl" else "cpu")
     if dist is not None:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     dt_max = float(t.item())
+    stitch = None
+    if sh is not None:
+        # the stitch over the timed window, max over ranks where it is a latency
+        st = {k: stats1[k] - stats0[k] for k in stats1}
+        v = torch.tensor([st["reruns"], st["rounds"], st["stitch_device_ns"] / max(1, st["rounds"]),
+                          st["result_wait_ns"] / max(1, st["results"])], dtype=torch.float64,
+                         device=device if backend == "nccl" else "cpu")
+        vmax = v.clone()
+        dist.all_reduce(v, op=dist.ReduceOp.SUM)
+        dist.all_reduce(vmax, op=dist.ReduceOp.MAX)
+        stitch = {"exchange": sh.exchange_used, "rccl_ranks": sh.rccl_ranks, "reruns": int(v[0].item()),
+                  "allgather_rounds": int(vmax[1].item()),
+                  "stitch_us_per_round": round(float(vmax[2].item()) / 1e3, 2),
+                  "result_wait_us_per_step": round(float(vmax[3].item()) / 1e3, 2),
+                  "note": "timed window only; reruns summed over ranks; stitch = HIP-event time from the end of a round's "
+                          "kernel to the gathered reports' arrival in pinned host memory (max over ranks); result_wait = host "
+                          "time blocked in msj_stage1_sharded_result per step (max over ranks, with up to 3 steps in flight)"}
 
     if rank == 0:
         ms_per_step = dt_max / args.steps * 1e3
         value = total_len * args.steps / dt_max / 1e9
-        local_count = int(res.count) if world > 1 else total_count
         # dominant kernel: stage1_kernel, one launch per step on this rank's stream
         # (N>1: one launch per shard unless a speculation was refuted); HIP-event time
         # over the timed region / steps, which also covers the small per-launch
@@ -346,14 +444,23 @@ def main():
         alg_bytes = shard_len + 4 * local_count
         k_ms = ev_ms / args.steps / launches
         achieved = alg_bytes / (k_ms * 1e-3) / 1e9
-        traffic, measured = None, {}
+        # HBM bytes per launch from the PMC passes kept in profiles/traffic.json -- only if they were taken with
+        # THIS kernel (the source hash in msj_version()) on this workload and size; otherwise null
+        traffic, traffic_note, measured = None, None, {}
+        version = dev.lib.msj_version().decode()
+        src_hash = version.rsplit("src:", 1)[-1] if "src:" in version else None
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tpath):
             try:
                 tj = json.load(open(tpath))
-                # measured for the 1 GiB-per-launch configuration only
-                traffic = tj.get(args.workload) if args.gib_per_gpu == 1.0 else None
                 measured = tj.get("_measured_peaks_gbps", {})
+                ent = tj.get(args.workload)
+                if isinstance(ent, dict) and world == 1 and ent.get("bytes_total") == total_len:
+                    if ent.get("kernel_src") == src_hash:
+                        traffic = ent.get("hbm_bytes_per_launch")
+                    else:
+                        traffic_note = (f"profiles/traffic.json holds {ent.get('hbm_bytes_per_launch')} B for kernel "
+                                        f"src:{ent.get('kernel_src')}, this is src:{src_hash}: not reported")
             except Exception:
                 traffic = None
         out = {
@@ -379,7 +486,16 @@ def main():
                 "dvfs_settle": (f"{settle_steps} untimed passes ({args.settle_ms:g} ms) between the {args.warmup} warm-up "
                                 f"steps and the {args.steps} timed ones; see 'unsettled'") if args.settle_ms > 0 else "none",
                 **({"diagnostic": "no-emit summary pass: not a stage-1 result"} if args.no_emit else {}),
-                "sharding": "single GPU" if world == 1 else f"{world} byte-range shards, RCCL stitch",
+                "sharding": "single GPU" if world == 1 else f"{world} byte-range shards of {shard_len_nominal} B "
+                                                             f"({-(-shard_len_nominal // 0xFFFF0000)} uint32 segments each), cut inside units; "
+                                                             f"one all-gather of 128 B per rank and step",
+                # after the timed window: "indices" = every index of every rank compared on the device with the
+                # oracle's unit indices + k * unit_len, placed with the stitched offsets, trailer included, and the
+                # ranks' 64-bit hashes sum to the closed form; "count" = only the total was checked
+                "verified": verified,
+                **({"verify": verify_detail} if verify_detail else {}),
+                **({"stitch": stitch} if stitch else {}),
+                "library": version + (f" [--lib {args.lib}]" if args.lib else ""),
             },
             "roofline": {
                 "bound": "hbm",
@@ -388,6 +504,7 @@ def main():
                 "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBPS, 4),
                 "traffic": traffic,
+                **({"traffic_note": traffic_note} if traffic_note else {}),
                 "kernel": "stage1_kernel",
                 "algorithmic_bytes_per_launch": alg_bytes,
                 "kernel_ms": round(k_ms, 4),
@@ -408,6 +525,8 @@ def main():
         if unsettled is not None:
             # the same K steps timed right after the W warm-up steps, before the clocks have settled
             u_k_ms = unsettled[1] / args.steps
+            # the cold figure beside the sustained one: what a caller who parses one document after idle sees
+            out["roofline"]["frac_unsettled"] = round(alg_bytes / (u_k_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4)
             out["unsettled"] = {
                 "ms_per_step": round(unsettled[0] / args.steps * 1e3, 4),
                 "value": round(total_len * args.steps / unsettled[0] / 1e9, 2),

@@ -99,9 +99,12 @@ typedef struct msj_carry {
     uint32_t prev_scalar;     /* 1 = previous byte was a non-quote scalar */
     uint32_t unescaped_error; /* sticky: control char seen inside a string */
     uint32_t utf8_error;      /* sticky: invalid UTF-8 seen */
-    uint32_t internal_error;  /* sticky: look-back timeout / capacity clip */
+    uint32_t internal_error;  /* sticky: a wait inside the single-pass kernel ran into its bound */
     int32_t code;             /* reference return code, valid after a FINAL segment */
-    uint32_t reserved[5];
+    uint32_t capacity_error;  /* sticky: the index buffer could not hold every index so far (+ the 3 trailer words
+                                 on a FINAL segment); writes were clipped.  A FINAL segment also reports it as
+                                 code = MSJ_CAPACITY, a non-final shard only here (msj_shard_global_code reads it) */
+    uint32_t reserved[4];
 } msj_carry;
 
 /* One <= 4 GiB piece of a larger input: offsets in
@@ -118,6 +121,8 @@ typedef struct msj_ctx msj_ctx;
 /* Library / device probes.  msj_device_count() returns the number of HIP
  * devices (0 when none or no runtime); never initialises a context. */
 int32_t msj_device_count(void);
+/* "mojo-simdjson_amd stage1 <version> (gfx950) src:<12 hex digits>": the digits are a hash of the stage-1 kernel's
+ * sources; measurements kept beside the code (profiles/traffic.json) name the kernel they were taken with. */
 const char *msj_version(void);
 
 /* Context: owns the per-device workspace (tile descriptors, carry structs,
@@ -234,12 +239,19 @@ typedef struct msj_shard_report {
 int32_t msj_shard_speculate(const uint8_t *halo, uint64_t halo_len, const uint8_t *head, uint64_t head_len,
                             msj_carry *out);
 /* Replays the chain of all ranks' reports.  exact_in[g] (world entries) receives the exact carry at the start of
- * shard g for every g < return value; *rerun_mask gets bit g set for every rank that has to index again with
- * exact_in[g] (wrong in_string guess, wrong escape carries, or a poisoned launch -- the chain cannot be followed
- * past the latter two).  Returns world and mask 0 when every report stands; < 0 on bad arguments. */
+ * shard g for every g < return value -- in_string / next_is_escaped / prev_scalar, and the STITCHED OFFSETS:
+ * exact_in[g].count = structurals of the stream in front of shard g (the position of its first index in the
+ * stream-wide array that the reference's BitIndexer.tail / n_structural_indexes define,
+ * json_structural_indexer.mojo:34-37,160-165), exact_in[g].bytes = stream bytes in front of it.  The counts of
+ * ranks named in *rerun_mask are not final yet (they index again), so the offsets are final when the mask is 0.
+ * *rerun_mask gets bit g set for every rank that has to index again with exact_in[g] (wrong in_string guess,
+ * wrong escape carries, or a poisoned launch -- the chain cannot be followed past the latter two).  Returns world
+ * and mask 0 when every report stands; < 0 on bad arguments. */
 int32_t msj_shard_verify(const msj_shard_report *reports, uint32_t world, msj_carry *exact_in, uint64_t *rerun_mask);
 /* The reference's return code for the whole stream (finish(), json_structural_indexer.mojo:147-186) and the
- * total structural count, from reports that msj_shard_verify accepted. */
+ * total structural count, from reports that msj_shard_verify accepted.  MSJ_CAPACITY when any rank's index
+ * buffer was too small for its shard (out.capacity_error), in the place the single-GPU path gives it (after
+ * 15 and 14, before 13 and 11). */
 int32_t msj_shard_global_code(const msj_shard_report *reports, uint32_t world, uint32_t flags, uint64_t *total_count);
 
 /* The one collective: all-gather of `bytes_per_rank` bytes per rank, device memory, enqueued on `stream`
@@ -278,6 +290,18 @@ int32_t msj_sharded_create(msj_ctx *ctx, const msj_exchange *xchg, const msj_sha
 void msj_sharded_destroy(msj_sharded *sh);
 uint64_t msj_sharded_reruns(const msj_sharded *sh); /* shard launches repeated by this rank (refuted guesses) */
 uint64_t msj_sharded_rounds(const msj_sharded *sh); /* all-gathers so far */
+/* Where the time of the stitch goes (cumulative since msj_sharded_create; device figures only with the default HIP
+ * operations, 0 otherwise): results = msj_stage1_sharded_result calls completed; stitch_device_ns = HIP-event time
+ * from the end of a round's kernel to the arrival of the gathered reports in pinned host memory (the all-gather
+ * and the read-back, per round); result_wait_ns = host time spent blocked inside msj_stage1_sharded_result. */
+typedef struct msj_sharded_stats {
+    uint64_t results, rounds, reruns;
+    uint64_t stitch_device_ns, result_wait_ns;
+    uint64_t reserved[3];
+} msj_sharded_stats;
+int32_t msj_sharded_get_stats(const msj_sharded *sh, msj_sharded_stats *out);
+/* Gives back what msj_exchange_rccl allocated when the exchange is NOT handed to msj_sharded_create after all. */
+void msj_exchange_release(msj_exchange *x);
 
 /* Enqueue this rank's shard: kernel, all-gather of the reports, pinned read-back; returns at once with a ticket
  * (up to 3 submissions may be in flight).  d_shard: 16-byte aligned device pointer; with has_prefix the 64 bytes
@@ -288,14 +312,31 @@ int32_t msj_stage1_sharded_submit(msj_sharded *sh, const uint8_t *d_shard, uint6
                                   uint64_t idx_capacity, uint64_t total_len, int32_t has_prefix,
                                   const msj_carry *speculation, msj_segment *d_segments, uint32_t max_segments,
                                   void *stream, uint32_t flags, uint32_t *ticket_out);
+/* Where a shard's results sit in the stream: the stitch's offsets (every rank folds the
+ * ranks below it).  Local index k of this shard is index (index_begin + k) of the stream-wide array; a local
+ * offset (plus its segment's byte_base, msj_segment) + byte_base is the offset in the stream. */
+typedef struct msj_shard_placement {
+    uint64_t index_begin; /* structurals of the stream in front of this shard: BitIndexer.tail - base at its first byte
+                             (json_structural_indexer.mojo:34-37); the exclusive sum of the lower ranks' counts */
+    uint64_t byte_base;   /* stream bytes in front of this shard */
+    uint64_t count;       /* this shard's structurals */
+    uint64_t bytes;       /* this shard's bytes */
+} msj_shard_placement;
 /* Wait for a submission; collective (every rank calls it for its matching ticket).  *code_out: the reference's
- * return code for the whole stream; *total_count_out: structurals of the whole stream; *local_out: this shard's
- * msj_carry (count = its own structurals); *used_out: the exact carry at its first byte. */
+ * return code for the whole stream; *total_count_out: structurals of the whole stream (n_structural_indexes,
+ * json_structural_indexer.mojo:160-165); *local_out: this shard's msj_carry (count = its own structurals);
+ * *used_out: the exact carry at its first byte; *placement_out: the stitched offsets.  Any out pointer may be NULL.
+ * A failure of the exchange or of a launch while ranks index again is returned as is and frees the ticket; the
+ * collective is then broken for that submission on every rank (they fail or time out in their own exchange). */
 int32_t msj_stage1_sharded_result(msj_sharded *sh, uint32_t ticket, int32_t *code_out, uint64_t *total_count_out,
-                                  msj_carry *local_out, msj_carry *used_out);
+                                  msj_carry *local_out, msj_carry *used_out, msj_shard_placement *placement_out);
 /* Test hook: host-pointer inputs of at least this many bytes go through the chunked pinned pipeline of msj_stage1
  * (default 64 MiB; 0 restores it).  ctx NULL: the default context. */
 int32_t msj_debug_set_pipeline_min_bytes(msj_ctx *ctx, uint64_t bytes);
+/* Test hook: on != 0 makes the pipeline's set-up fail as it does on a host that cannot give it pinned memory; the
+ * call (and every later one) then goes through the plain staging path.  on == 0 clears that state.  Returns 1 while
+ * the context has given the pipeline up, 0 otherwise, < 0 on error.  ctx NULL: the default context. */
+int32_t msj_debug_fail_pipeline_setup(msj_ctx *ctx, int32_t on);
 /* Test hook: longest segment (bytes, multiple of 4096) one launch indexes; default MSJ_MAX_SEGMENT_BYTES rounded
  * down to the tile. */
 int32_t msj_debug_set_segment_bytes(msj_ctx *ctx, uint64_t bytes);
@@ -354,6 +395,10 @@ int32_t msj_tokens_device(msj_ctx *ctx, const uint8_t *d_buf, uint64_t len, cons
 #define MSJ_SPAN_LONG 128u   /* string body over 1024 bytes: backslash flag not computed; number over 1024: not scanned */
 int32_t msj_token_spans_device(msj_ctx *ctx, const uint8_t *d_buf, uint64_t len, const uint32_t *d_idx, uint64_t n,
                                uint32_t *d_end, uint8_t *d_flags, void *stream);
+
+/* Test hook (process-wide): stretches of more than lds_limit_bytes take the span kernels' global-memory path, the
+ * fix-up list holds fix_capacity entries; 0xFFFFFFFF = the built-in value of either. */
+void msj_debug_set_span_limits(uint32_t lds_limit_bytes, uint32_t fix_capacity);
 
 /*
  * msj_stage2_prep_device -- msj_tokens_device and msj_token_spans_device in one go (rows f1 + f2 + f4), with

@@ -8,8 +8,9 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-# MSJ_STAGE1_LIB: tuning aid (A/B of differently built kernels in one GPU session)
-LIB_PATH = os.environ.get("MSJ_STAGE1_LIB") or os.path.join(_HERE, "libmsj_stage1.so")
+# The one library this package loads.  No environment variable can substitute it; measurement scripts that compare
+# differently built kernels set this attribute explicitly before the first load() (bench.py --lib, which reports it).
+LIB_PATH = os.path.join(_HERE, "libmsj_stage1.so")
 GEN_LIB_PATH = os.path.join(_HERE, "libmsj_gen.so")
 
 
@@ -26,7 +27,8 @@ class MsjCarry(ctypes.Structure):
         ("utf8_error", ctypes.c_uint32),
         ("internal_error", ctypes.c_uint32),
         ("code", ctypes.c_int32),
-        ("reserved", ctypes.c_uint32 * 5),
+        ("capacity_error", ctypes.c_uint32),
+        ("reserved", ctypes.c_uint32 * 4),
     ]
 
 
@@ -141,6 +143,10 @@ def load():
     lib.msj_host_unregister.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
     lib.msj_debug_set_pipeline_min_bytes.restype = ctypes.c_int32
     lib.msj_debug_set_pipeline_min_bytes.argtypes = [ctypes.c_void_p, ctypes.c_uint64]
+    lib.msj_debug_fail_pipeline_setup.restype = ctypes.c_int32
+    lib.msj_debug_fail_pipeline_setup.argtypes = [ctypes.c_void_p, ctypes.c_int32]
+    lib.msj_debug_set_span_limits.restype = None
+    lib.msj_debug_set_span_limits.argtypes = [ctypes.c_uint32, ctypes.c_uint32]
     lib.msj_fallback_count.restype = ctypes.c_uint64
     lib.msj_fallback_count.argtypes = [ctypes.c_void_p]
     lib.msj_stage1_shard_device.restype = ctypes.c_int32

@@ -61,6 +61,8 @@ struct msj_ctx {
     uint32_t wait_ticks = msj::kWaitTicksDefault;  // bound of the kernel's waits (10 ns ticks)
     uint64_t seg_bytes = msj::kSegmentBytes;  // longest segment of one launch (test hook: msj_debug_set_segment_bytes)
     uint64_t pipeline_min = kPipelineMinDefault;  // host-pointer inputs from this size on take the chunked pipeline
+    bool pipe_unavailable = false;  // the pipeline's pinned memory / streams could not be had: plain staging from then on
+    bool pipe_fail_setup = false;   // test hook: msj_debug_fail_pipeline_setup
     uint64_t *tp = nullptr;       // workspace of the two-pass path (2 words per tile), allocated on first use
     uint64_t tp_words = 0;
     uint64_t fallbacks = 0;       // calls re-issued through the two-pass path after an expired wait
@@ -176,7 +178,9 @@ int32_t enqueue_shard(msj_ctx *ctx, const uint8_t *d_buf, uint64_t len, uint32_t
         if (s == 0) a.flags |= flags & (15u << msj::kFlagSkipShift);
         a.stamps = g_stamps;
         a.wait_ticks = ctx->wait_ticks;
-        a.index_bias = index_bias;
+        // without a segment table nothing tells the caller where a later segment's offsets start: they stay
+        // relative to the call's buffer (wrapping like the reference's UInt32 would, json_structural_indexer.mojo:138)
+        a.index_bias = index_bias + (d_segments ? 0u : (uint32_t)base);
         a.tp = nullptr;
         if (flags & MSJ_FLAG_DEBUG_STALL) a.flags |= msj::kFlagDebugStall;
         if (flags & MSJ_FLAG_TWO_PASS) {
@@ -305,15 +309,26 @@ struct CopyPool {
     }
 };
 
+// Tuning knobs of the host pipeline exist in the measurement build only (make -C csrc knobs: -DMSJ_DEBUG_KNOBS,
+// scripts/libmsj_stage1_knobs.so); the product library has the measured defaults compiled in and reads no
+// environment variable at all.
+#ifdef MSJ_DEBUG_KNOBS
+static int knob_int(const char *name, int dflt, int lo) {
+    const char *v = std::getenv(name);
+    const int x = v && *v ? std::atoi(v) : dflt;
+    return x < lo ? lo : x;  // a pool without workers would block its callers for ever
+}
+static bool knob_set(const char *name) { return std::getenv(name) != nullptr; }
+#else
+static int knob_int(const char *, int dflt, int) { return dflt; }
+static bool knob_set(const char *) { return false; }
+#endif
+
 struct HostPipe {
     static constexpr int kInSlots = 3, kOutSlots = 2;
-    static int env_int(const char *name, int dflt) {
-        const char *v = std::getenv(name);
-        return v && *v ? std::atoi(v) : dflt;
-    }
-    // copy workers and slices per staging copy (tuning knobs; defaults measured on the MI355X box's host)
-    const int kCopyThreads = env_int("MSJ_PIPE_THREADS", 8), kParts = env_int("MSJ_PIPE_PARTS", 4);
-    const bool direct_upload = env_int("MSJ_PIPE_DIRECT_UPLOAD", 0) != 0;
+    // copy workers and slices per staging copy (defaults measured on the MI355X box's host)
+    const int kCopyThreads = knob_int("MSJ_PIPE_THREADS", 8, 1), kParts = knob_int("MSJ_PIPE_PARTS", 4, 1);
+    const bool direct_upload = knob_int("MSJ_PIPE_DIRECT_UPLOAD", 0, 0) != 0;
     static constexpr uint64_t kChunk = 16ull << 20;  // input bytes per chunk (a multiple of the tile)
     static constexpr uint64_t kPiece = 16ull << 20;  // index bytes per download piece
     uint8_t *pin_in[kInSlots] = {nullptr, nullptr, nullptr};
@@ -375,22 +390,26 @@ struct HostPipe {
     }
 };
 
-// The pipelined form of msj_stage1_ctx's device staging.  Returns MSJ_ERR_HIP when anything of the machinery
-// fails (the caller then takes the plain path); otherwise fills *res with the final carry.
+// The pipelined form of msj_stage1_ctx's device staging.  Returns kPipeUnavailable when the machinery cannot be
+// set up (pinned memory, streams, events: e.g. a memlock limit in a container) -- nothing has been enqueued then
+// and the caller takes the plain path, for this call and every later one; any other failure is the call's
+// result.  Otherwise fills *res with the final carry.
+constexpr int32_t kPipeUnavailable = -100;
 int32_t host_pipeline(msj_ctx *ctx, const uint8_t *buf, uint64_t len, uint32_t *idx_out, uint64_t dev_cap, uint32_t flags,
                       msj_carry *res) {
+    if (ctx->pipe_fail_setup) return kPipeUnavailable;  // test hook (msj_debug_fail_pipeline_setup)
     if (!ctx->pipe) {
         ctx->pipe = new (std::nothrow) HostPipe();
-        if (!ctx->pipe) return MSJ_MEMALLOC;
+        if (!ctx->pipe) return kPipeUnavailable;
     }
     HostPipe &P = *ctx->pipe;
-    if (!P.ok) return MSJ_ERR_HIP;
+    if (!P.ok) return kPipeUnavailable;
     const uint64_t chunk = HostPipe::kChunk;
     const uint64_t nchunks = (len + chunk - 1) / chunk;
-    if (!P.reserve(nchunks)) return MSJ_MEMALLOC;
-    if (!hip_ok(hipMemsetAsync(&P.d_carries[0], 0, sizeof(msj_carry), P.s_k))) return MSJ_ERR_HIP;
+    if (!P.reserve(nchunks)) return kPipeUnavailable;
+    if (!hip_ok(hipMemsetAsync(&P.d_carries[0], 0, sizeof(msj_carry), P.s_k))) return kPipeUnavailable;
 
-    static const bool trace = std::getenv("MSJ_PIPE_TRACE") != nullptr;  // diagnostics: where the call's time goes
+    static const bool trace = knob_set("MSJ_PIPE_TRACE");  // measurement build: where the call's time goes
     auto now = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     const double t_begin = now();
     std::vector<double> t_chunk_done(nchunks, 0.0), t_piece;
@@ -518,7 +537,12 @@ msj_ctx *g_default_ctx = nullptr;
 
 extern "C" {
 
-const char *msj_version(void) { return "mojo-simdjson_amd stage1 0.1 (gfx950)"; }
+#ifndef MSJ_SOURCE_HASH
+#define MSJ_SOURCE_HASH "unknown"
+#endif
+// "... src:<hash>": the first 12 hex digits of the SHA-256 of the stage-1 kernel's sources (csrc/Makefile), so that
+// measurements kept beside the code (profiles/traffic.json) can say which kernel they were taken with
+const char *msj_version(void) { return "mojo-simdjson_amd stage1 0.3 (gfx950) src:" MSJ_SOURCE_HASH; }
 
 uint32_t msj_tile_bytes(void) { return msj::kTileBytes; }
 
@@ -846,6 +870,18 @@ int32_t msj_debug_set_pipeline_min_bytes(msj_ctx *ctx, uint64_t bytes) {
     return MSJ_SUCCESS;
 }
 
+int32_t msj_debug_fail_pipeline_setup(msj_ctx *ctx, int32_t on) {
+    std::unique_lock<std::mutex> lock(g_default_mutex, std::defer_lock);
+    if (!ctx) {
+        lock.lock();
+        ctx = default_ctx_locked();
+        if (!ctx) return MSJ_ERR_NO_DEVICE;
+    }
+    ctx->pipe_fail_setup = on != 0;
+    if (!on) ctx->pipe_unavailable = false;
+    return ctx->pipe_unavailable ? 1 : 0;
+}
+
 int32_t msj_debug_set_segment_bytes(msj_ctx *ctx, uint64_t bytes) {
     if (!ctx || bytes == 0 || bytes % msj::kTileBytes != 0 || bytes > msj::kSegmentBytes) return MSJ_ERR_BAD_ARGUMENT;
     ctx->seg_bytes = bytes;
@@ -915,12 +951,25 @@ int32_t msj_stage1_ctx(msj_ctx *ctx, const uint8_t *buf, uint64_t len, uint32_t 
     }
     msj_carry res;
     int32_t rc;
-    static const bool pipe_off = std::getenv("MSJ_PIPE_DISABLE") != nullptr;  // measurement aid: the plain staging path
-    const bool piped = len >= ctx->pipeline_min && !(flags & MSJ_FLAG_TWO_PASS) && !pipe_off;
+    static const bool pipe_off = knob_set("MSJ_PIPE_DISABLE");  // measurement build: the plain staging path
+    bool piped = len >= ctx->pipeline_min && !(flags & MSJ_FLAG_TWO_PASS) && !pipe_off && !ctx->pipe_unavailable;
     if (piped) {
         // large inputs: pinned rings, chunks, both PCIe directions and the kernel at once
-        rc = host_pipeline(ctx, buf, len, idx_out, dev_cap, flags, &res);
-        if (rc != MSJ_SUCCESS) return rc;
+        try {
+            rc = host_pipeline(ctx, buf, len, idx_out, dev_cap, flags, &res);
+        } catch (...) {  // std::thread / std::vector could not get what they need: nothing of ours crosses the C boundary
+            rc = MSJ_MEMALLOC;
+        }
+        if (rc == kPipeUnavailable) {
+            // the machinery cannot be had on this host: the plain staging path below, now and from now on
+            (void)hipGetLastError();
+            ctx->pipe_unavailable = true;
+            piped = false;
+        } else if (rc != MSJ_SUCCESS) {
+            return rc;
+        }
+    }
+    if (piped) {
         if (res.internal_error) {  // an expired wait somewhere in the chain: once more, two-pass, plain staging
             ctx->fallbacks++;
             ctx->ws_dirty[0] = ctx->ws_dirty[1] = kAllDirty;

@@ -22,6 +22,7 @@
 #include <dlfcn.h>
 #include <hip/hip_runtime.h>
 
+#include <chrono>
 #include <cstring>
 #include <new>
 
@@ -112,6 +113,9 @@ struct Slot {
     msj_shard_report *h_gathered = nullptr;  // pinned host copy of d_gathered
     msj_carry *h_spec = nullptr;             // pinned host: the carry this rank's launch used
     bool busy = false;
+    // default HIP operations only: the end of the round's kernel / the arrival of the gathered reports (stats)
+    hipEvent_t ev_kernel = nullptr, ev_stitch = nullptr;
+    bool timed = false;
     // the call, for re-runs
     const uint8_t *d_shard;
     uint64_t shard_len, idx_capacity, total_len;
@@ -129,7 +133,9 @@ struct msj_sharded {
     msj_exchange x;
     Slot slots[kDepth];
     uint32_t next = 0;
-    uint64_t reruns = 0, rounds = 0;
+    uint64_t reruns = 0, rounds = 0, results = 0;
+    uint64_t stitch_device_ns = 0, result_wait_ns = 0;
+    bool hip_ops = false;  // the default operations: HIP events time the stitch
     RcclExchange *owned_rccl = nullptr;
 };
 
@@ -249,7 +255,7 @@ int32_t msj_shard_verify(const msj_shard_report *reports, uint32_t world, msj_ca
     // reliable, so nothing behind it can be judged yet.
     uint64_t mask = 0;
     uint32_t s = 0, e = 0, ps = 0;
-    uint64_t count = 0;
+    uint64_t count = 0, bytes = 0;
     uint32_t g = 0;
     for (; g < world; g++) {
         const msj_carry &u = reports[g].used, &o = reports[g].out;
@@ -257,8 +263,13 @@ int32_t msj_shard_verify(const msj_shard_report *reports, uint32_t world, msj_ca
         exact_in[g].in_string = s;
         exact_in[g].next_is_escaped = e;
         exact_in[g].prev_scalar = ps;
-        exact_in[g].count = 0;  // index arrays stay shard-local: every shard counts from 0
-        (void)count;
+        // the stitched offsets: where shard g's first index and first byte sit in the
+        // stream.  Index arrays themselves stay shard-local -- a launch counts from the carry it is given, and
+        // the sharded entry points give it 0 -- so these are what a consumer adds (msj_shard_placement).
+        exact_in[g].count = count;
+        exact_in[g].bytes = bytes;
+        count += o.count - u.count;
+        bytes += o.bytes - u.bytes;
         if ((u.next_is_escaped & 1u) != e || (u.prev_scalar & 1u) != ps || o.internal_error) {
             mask |= 1ull << g;
             g++;
@@ -277,18 +288,22 @@ int32_t msj_shard_verify(const msj_shard_report *reports, uint32_t world, msj_ca
 int32_t msj_shard_global_code(const msj_shard_report *reports, uint32_t world, uint32_t flags, uint64_t *total_count) {
     if (!reports || world == 0) return MSJ_ERR_BAD_ARGUMENT;
     uint64_t total = 0;
-    uint32_t unescaped = 0, utf8 = 0, internal = 0;
+    uint32_t unescaped = 0, utf8 = 0, internal = 0, clipped = 0;
     for (uint32_t g = 0; g < world; g++) {
-        total += reports[g].out.count;
+        total += reports[g].out.count - reports[g].used.count;
         unescaped |= reports[g].out.unescaped_error;
         utf8 |= reports[g].out.utf8_error;
         internal |= reports[g].out.internal_error;
+        clipped |= reports[g].out.capacity_error;
     }
     if (total_count) *total_count = total;
-    // finish(), json_structural_indexer.mojo:147-186: 15, then 14, then 13, then (strict) 11
+    // finish(), json_structural_indexer.mojo:147-186: 15, then 14, then 13, then (strict) 11; CAPACITY where
+    // the single-GPU path has it (stage1_kernel.hip finish_launch): a rank whose index buffer was too small
+    // clipped its writes, wherever in the stream it sits
     if (internal) return MSJ_UNEXPECTED_ERROR;
     if (reports[world - 1].out.in_string) return MSJ_UNCLOSED_STRING;
     if (unescaped) return MSJ_UNESCAPED_CHARS;
+    if (clipped) return MSJ_CAPACITY;
     if (total == 0) return MSJ_EMPTY;
     if ((flags & MSJ_FLAG_STRICT_UTF8) && utf8) return MSJ_UTF8_ERROR;
     return MSJ_SUCCESS;
@@ -310,6 +325,14 @@ int32_t msj_exchange_rccl(void *nccl_comm, uint32_t rank, uint32_t world, const 
     return MSJ_SUCCESS;
 }
 
+void msj_exchange_release(msj_exchange *x) {
+    if (!x || !x->owns_comm) return;
+    delete static_cast<RcclExchange *>(x->comm);
+    x->comm = nullptr;
+    x->allgather = nullptr;
+    x->owns_comm = 0;
+}
+
 int32_t msj_sharded_create(msj_ctx *ctx, const msj_exchange *xchg, const msj_sharded_ops *ops, msj_sharded **out) {
     if (!xchg || !out || !xchg->allgather || xchg->world == 0 || xchg->world > 64 || xchg->rank >= xchg->world)
         return MSJ_ERR_BAD_ARGUMENT;
@@ -326,6 +349,7 @@ int32_t msj_sharded_create(msj_ctx *ctx, const msj_exchange *xchg, const msj_sha
         sh->ops.copy = hip_copy;
         sh->ops.sync = hip_sync;
         sh->ops.run_shard = hip_run_shard;
+        sh->hip_ops = true;
     }
     sh->x = *xchg;
     if (xchg->owns_comm) sh->owned_rccl = static_cast<RcclExchange *>(xchg->comm);
@@ -340,6 +364,8 @@ int32_t msj_sharded_create(msj_ctx *ctx, const msj_exchange *xchg, const msj_sha
         if (ok) sl.h_gathered = static_cast<msj_shard_report *>(p);
         ok = ok && sh->ops.alloc(sh->ops.user, sizeof(msj_carry), 1, &p) == MSJ_SUCCESS;
         if (ok) sl.h_spec = static_cast<msj_carry *>(p);
+        if (ok && sh->hip_ops)  // without the events the stitch is simply not timed
+            sl.timed = hipEventCreate(&sl.ev_kernel) == hipSuccess && hipEventCreate(&sl.ev_stitch) == hipSuccess;
         if (!ok) {
             msj_sharded_destroy(sh);
             return MSJ_MEMALLOC;
@@ -356,6 +382,8 @@ void msj_sharded_destroy(msj_sharded *sh) {
         sh->ops.free(sh->ops.user, sl.d_gathered, 0);
         sh->ops.free(sh->ops.user, sl.h_gathered, 1);
         sh->ops.free(sh->ops.user, sl.h_spec, 1);
+        if (sl.ev_kernel) (void)hipEventDestroy(sl.ev_kernel);
+        if (sl.ev_stitch) (void)hipEventDestroy(sl.ev_stitch);
     }
     delete sh->owned_rccl;
     delete sh;
@@ -363,6 +391,16 @@ void msj_sharded_destroy(msj_sharded *sh) {
 
 uint64_t msj_sharded_reruns(const msj_sharded *sh) { return sh ? sh->reruns : 0; }
 uint64_t msj_sharded_rounds(const msj_sharded *sh) { return sh ? sh->rounds : 0; }
+int32_t msj_sharded_get_stats(const msj_sharded *sh, msj_sharded_stats *out) {
+    if (!sh || !out) return MSJ_ERR_BAD_ARGUMENT;
+    std::memset(out, 0, sizeof *out);
+    out->results = sh->results;
+    out->rounds = sh->rounds;
+    out->reruns = sh->reruns;
+    out->stitch_device_ns = sh->stitch_device_ns;
+    out->result_wait_ns = sh->result_wait_ns;
+    return MSJ_SUCCESS;
+}
 
 // kernel (with the carry in sl.h_spec) -> all-gather of the reports -> pinned host copy; nothing waits here
 static int32_t launch_round(msj_sharded *sh, Slot &sl, bool run_kernel, uint32_t extra_flags) {
@@ -377,10 +415,13 @@ static int32_t launch_round(msj_sharded *sh, Slot &sl, bool run_kernel, uint32_t
                          sl.flags | extra_flags);
         if (rc != MSJ_SUCCESS) return rc;
     }
+    if (sl.timed) (void)hipEventRecord(sl.ev_kernel, static_cast<hipStream_t>(sl.stream));
     rc = sh->x.allgather(sh->x.comm, sl.d_mine, sl.d_gathered, sizeof(msj_shard_report), sl.stream);
     if (rc != MSJ_SUCCESS) return rc;
     sh->rounds++;
-    return o.copy(o.user, sl.h_gathered, sl.d_gathered, (uint64_t)sh->x.world * sizeof(msj_shard_report), 1, sl.stream);
+    rc = o.copy(o.user, sl.h_gathered, sl.d_gathered, (uint64_t)sh->x.world * sizeof(msj_shard_report), 1, sl.stream);
+    if (rc == MSJ_SUCCESS && sl.timed) (void)hipEventRecord(sl.ev_stitch, static_cast<hipStream_t>(sl.stream));
+    return rc;
 }
 
 int32_t msj_stage1_sharded_submit(msj_sharded *sh, const uint8_t *d_shard, uint64_t shard_len, uint32_t *d_idx,
@@ -392,7 +433,11 @@ int32_t msj_stage1_sharded_submit(msj_sharded *sh, const uint8_t *d_shard, uint6
     if (sl.busy) return MSJ_CAPACITY;  // more than kDepth submissions without a result
     const msj_sharded_ops &o = sh->ops;
     if (speculation) {
-        *sl.h_spec = *speculation;
+        // only the three carry bits are the caller's to assume: counts, bytes and sticky flags start at zero
+        std::memset(sl.h_spec, 0, sizeof(msj_carry));
+        sl.h_spec->in_string = speculation->in_string & 1u;
+        sl.h_spec->next_is_escaped = speculation->next_is_escaped & 1u;
+        sl.h_spec->prev_scalar = speculation->prev_scalar & 1u;
     } else if (!has_prefix) {
         std::memset(sl.h_spec, 0, sizeof(msj_carry));
     } else {
@@ -424,15 +469,27 @@ int32_t msj_stage1_sharded_submit(msj_sharded *sh, const uint8_t *d_shard, uint6
 }
 
 int32_t msj_stage1_sharded_result(msj_sharded *sh, uint32_t ticket, int32_t *code_out, uint64_t *total_count_out,
-                                  msj_carry *local_out, msj_carry *used_out) {
+                                  msj_carry *local_out, msj_carry *used_out, msj_shard_placement *placement_out) {
     if (!sh || ticket >= kDepth || !sh->slots[ticket].busy) return MSJ_ERR_BAD_ARGUMENT;
     Slot &sl = sh->slots[ticket];
     const msj_sharded_ops &o = sh->ops;
     const uint32_t world = sh->x.world, rank = sh->x.rank;
     msj_carry exact[64];
+    // whatever goes wrong below, the ticket is free again afterwards (the submission is lost, not the slot)
+    struct Release {
+        Slot &sl;
+        ~Release() { sl.busy = false; }
+    } release{sl};
     for (;;) {
+        const auto t0 = std::chrono::steady_clock::now();
         int32_t rc = o.sync(o.user, sl.stream);
+        sh->result_wait_ns += (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count();
         if (rc != MSJ_SUCCESS) return rc;
+        if (sl.timed) {
+            float ms = 0.f;
+            if (hipEventElapsedTime(&ms, sl.ev_kernel, sl.ev_stitch) == hipSuccess && ms > 0.f)
+                sh->stitch_device_ns += (uint64_t)((double)ms * 1e6);
+        }
         uint64_t mask = 0;
         const int32_t known = msj_shard_verify(sl.h_gathered, world, exact, &mask);
         if (known < 0) return known;
@@ -444,21 +501,29 @@ int32_t msj_stage1_sharded_result(msj_sharded *sh, uint32_t ticket, int32_t *cod
         if (mine) {
             // poisoned launch (an expired wait): through the two-pass kernels this time
             if (sl.h_gathered[rank].out.internal_error) extra = MSJ_FLAG_TWO_PASS;
-            const uint64_t keep_count = 0;
             *sl.h_spec = exact[rank];
-            sl.h_spec->count = keep_count;
+            sl.h_spec->count = 0;  // index arrays stay shard-local: every shard counts from 0 ...
+            sl.h_spec->bytes = 0;  // ... its own bytes (the stitched offsets come back as msj_shard_placement)
             sh->reruns++;
         }
         rc = launch_round(sh, sl, mine, extra);
         if (rc != MSJ_SUCCESS) return rc;
     }
-    sl.busy = false;
+    sh->results++;
     uint64_t total = 0;
     const int32_t code = msj_shard_global_code(sl.h_gathered, world, sl.flags, &total);
     if (code_out) *code_out = code;
     if (total_count_out) *total_count_out = total;
     if (local_out) *local_out = sl.h_gathered[rank].out;
     if (used_out) *used_out = sl.h_gathered[rank].used;
+    if (placement_out) {
+        // every report stands: the exclusive sums of the replay are final (json_structural_indexer.mojo:34-37,
+        // 160-165: BitIndexer.tail / n_structural_indexes of the one stream the shards are cut from)
+        placement_out->index_begin = exact[rank].count;
+        placement_out->byte_base = exact[rank].bytes;
+        placement_out->count = sl.h_gathered[rank].out.count - sl.h_gathered[rank].used.count;
+        placement_out->bytes = sl.h_gathered[rank].out.bytes - sl.h_gathered[rank].used.bytes;
+    }
     return MSJ_SUCCESS;
 }
 

@@ -1053,6 +1053,11 @@ __device__ __forceinline__ void finish_launch(const KernelArgs &a, const uint32_
     if ((a.flags & kFlagFinal) && do_utf8 && (a.len % kTileBytes) == 0 && ((last >> 55) & 1u)) u8e = 1;
     out.utf8_error = u8e ? 1u : 0u;
     out.internal_error = (cin.internal_error | cx) ? 1u : 0u;
+    // an index buffer too small for the indices so far (+ the trailer on the stream's last segment): the
+    // emission clipped its writes (emit_general).  Sticky, and reported by non-final shards too: the ranks of a
+    // sharded stream learn it from each other's reports (msj_shard_global_code)
+    const bool clipped = !(a.flags & kFlagNoEmit) && n + ((a.flags & kFlagFinal) ? 3u : 0u) > a.capacity;
+    out.capacity_error = (cin.capacity_error | (clipped ? 1u : 0u)) ? 1u : 0u;
     int32_t code = MSJ_SUCCESS;
     if (a.flags & kFlagFinal) {
         if (out.internal_error) {
@@ -1061,7 +1066,7 @@ __device__ __forceinline__ void finish_launch(const KernelArgs &a, const uint32_
             code = MSJ_UNCLOSED_STRING;  // :151-155
         } else if (out.unescaped_error) {
             code = MSJ_UNESCAPED_CHARS;  // :157-158
-        } else if (n + 3 > a.capacity) {
+        } else if (out.capacity_error) {
             code = MSJ_CAPACITY;
         } else {
             if (!(a.flags & kFlagNoEmit)) {
@@ -1076,7 +1081,7 @@ __device__ __forceinline__ void finish_launch(const KernelArgs &a, const uint32_
         }
     }
     out.code = code;
-    for (int k = 0; k < 5; k++) out.reserved[k] = 0;
+    for (int k = 0; k < 4; k++) out.reserved[k] = 0;
     if (late_poison) {
         // single-pass kernel: workers may still OR a late timeout into internal_error (worker_wave), before
         // or after this store: every other field is stored, this one is ORed
@@ -1089,7 +1094,8 @@ __device__ __forceinline__ void finish_launch(const KernelArgs &a, const uint32_
         o->unescaped_error = out.unescaped_error;
         o->utf8_error = out.utf8_error;
         o->code = out.code;
-        for (int k = 0; k < 5; k++) o->reserved[k] = 0;
+        o->capacity_error = out.capacity_error;
+        for (int k = 0; k < 4; k++) o->reserved[k] = 0;
         if (out.internal_error) atomicOr(&o->internal_error, 1u);
     } else {
         *a.carry_out = out;

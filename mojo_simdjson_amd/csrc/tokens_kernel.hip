@@ -1102,11 +1102,13 @@ __global__ __launch_bounds__(kSpanThreads) void token_spans(const uint8_t *__res
 
 #undef MSJ_SPAN_ARRIVED
 
+// Test hooks (msj_debug_set_span_limits; 0xFFFFFFFF = the built-in value): stretches over g_lds_limit bytes take
+// the global-memory path, the fix-up list holds g_fix_cap entries.  No environment variable is read.
+static uint32_t g_lds_limit = 0xFFFFFFFFu, g_fix_cap = 0xFFFFFFFFu;
 static uint32_t fix_cap() {  // host: the list's capacity for this launch
-    const char *env = getenv("MSJ_SPANS_FIX_CAP");
-    const unsigned long v = env ? strtoul(env, nullptr, 10) : kFixCap;
-    return (uint32_t)(v < kFixCap ? v : kFixCap);
+    return g_fix_cap < kFixCap ? g_fix_cap : kFixCap;
 }
+static uint32_t span_lds_limit() { return g_lds_limit < kSpanLds ? g_lds_limit : kSpanLds; }
 
 // the tokens on the work list, from global memory; the last workgroup to finish clears the list for the next call
 __global__ __launch_bounds__(256) void span_fixup(const uint8_t *__restrict__ buf, uint64_t len, const uint32_t *__restrict__ idx, uint64_t n,
@@ -1154,16 +1156,18 @@ __global__ __launch_bounds__(256) void merge_sub_aggregates(const int4 *__restri
 }
 }  // namespace msj_tokens
 
+extern "C" void msj_debug_set_span_limits(uint32_t lds_limit_bytes, uint32_t fix_capacity) {
+    msj_tokens::g_lds_limit = lds_limit_bytes;
+    msj_tokens::g_fix_cap = fix_capacity;
+}
+
 // the work list of span_fixup: zeroed once by the owner (the kernels leave it zeroed)
 extern "C" uint64_t msj_span_fix_bytes(void) { return msj_tokens::kFixWords * sizeof(uint32_t); }
 
 extern "C" int msj_launch_token_spans(const uint8_t *d_buf, uint64_t len, const uint32_t *d_idx, uint64_t n, uint32_t *d_end,
                                       uint8_t *d_flags, uint32_t *d_fix, void *stream) {
     if (n == 0) return 0;
-    // MSJ_SPANS_LDS_LIMIT (tests): stretches over this many bytes take the global-memory path
-    const char *env = getenv("MSJ_SPANS_LDS_LIMIT");
-    const unsigned long lim = env ? strtoul(env, nullptr, 10) : msj_tokens::kSpanLds;
-    const uint32_t lds_limit = (uint32_t)(lim < msj_tokens::kSpanLds ? lim : msj_tokens::kSpanLds);
+    const uint32_t lds_limit = msj_tokens::span_lds_limit();  // stretches over this many bytes take the global-memory path
     hipLaunchKernelGGL(msj_tokens::token_spans<false>, dim3((uint32_t)((n + msj_tokens::kSpanTokens - 1) / msj_tokens::kSpanTokens)),
                        dim3(msj_tokens::kSpanThreads), 0, static_cast<hipStream_t>(stream), d_buf, len, d_idx, n, d_end, d_flags, lds_limit,
                        static_cast<uint8_t *>(nullptr), static_cast<int4 *>(nullptr), d_fix, msj_tokens::fix_cap());
@@ -1193,9 +1197,7 @@ extern "C" int msj_launch_stage2_prep(const uint8_t *d_buf, uint64_t len, const 
     const uint64_t tok_bytes = (msj_tokens_workspace_bytes(n, d_match != nullptr) + 15u) & ~15ull;
     int4 *sub = reinterpret_cast<int4 *>(reinterpret_cast<uint8_t *>(d_ws) + tok_bytes);
     if (n) {
-        const char *env = getenv("MSJ_SPANS_LDS_LIMIT");
-        const unsigned long lim = env ? strtoul(env, nullptr, 10) : kSpanLds;
-        const uint32_t lds_limit = (uint32_t)(lim < kSpanLds ? lim : kSpanLds);
+        const uint32_t lds_limit = span_lds_limit();
         hipLaunchKernelGGL(token_spans<true>, dim3(nsub), dim3(kSpanThreads), 0, s, d_buf, len, d_idx, n, d_end, d_flags, lds_limit, d_type, sub, d_fix, fix_cap());
         hipLaunchKernelGGL(span_fixup, dim3(kFixGroups), dim3(256), 0, s, d_buf, len, d_idx, n, d_end, d_flags, d_fix, fix_cap());
         hipLaunchKernelGGL(merge_sub_aggregates, dim3((nb + 255u) / 256u), dim3(256), 0, s, sub, nsub, d_ws, nb);

@@ -14,7 +14,7 @@ INTEGRATION.md included) reaches it; this module only supplies the exchange:
     kernel's stream, over xGMI;
   * backend "gloo" (CPU tests, several ranks sharing one GPU): a callback that moves the 128 bytes
     through torch.distributed -- also what backend "nccl" falls back to (all ranks together, with a line on
-    stderr) when the communicator cannot be had, and what ``MSJ_SHARDED_EXCHANGE=torch`` selects.
+    stderr) when the communicator cannot be had, and what ``ShardedStage1(exchange="torch")`` selects.
 
 No bulk data ever crosses xGMI: input shards are placed on their GPU up front and the index arrays
 stay shard-local.
@@ -43,6 +43,19 @@ ALLGATHER_FN = ctypes.CFUNCTYPE(ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p
 class MsjExchange(ctypes.Structure):
     _fields_ = [("comm", ctypes.c_void_p), ("allgather", ALLGATHER_FN), ("rank", ctypes.c_uint32),
                 ("world", ctypes.c_uint32), ("owns_comm", ctypes.c_uint32), ("reserved", ctypes.c_uint32)]
+
+
+class MsjShardPlacement(ctypes.Structure):
+    """``msj_shard_placement``: where a shard's indices and bytes sit in the stream (the stitched offsets)."""
+
+    _fields_ = [("index_begin", ctypes.c_uint64), ("byte_base", ctypes.c_uint64), ("count", ctypes.c_uint64),
+                ("bytes", ctypes.c_uint64)]
+
+
+class MsjShardedStats(ctypes.Structure):
+    _fields_ = [("results", ctypes.c_uint64), ("rounds", ctypes.c_uint64), ("reruns", ctypes.c_uint64),
+                ("stitch_device_ns", ctypes.c_uint64), ("result_wait_ns", ctypes.c_uint64),
+                ("reserved", ctypes.c_uint64 * 3)]
 
 
 class MsjShardedOps(ctypes.Structure):
@@ -89,7 +102,11 @@ def lib():
                                                 ctypes.POINTER(u32)]
         L.msj_stage1_sharded_result.restype = i32
         L.msj_stage1_sharded_result.argtypes = [vp, u32, ctypes.POINTER(i32), ctypes.POINTER(u64), ctypes.POINTER(MsjCarry),
-                                                ctypes.POINTER(MsjCarry)]
+                                                ctypes.POINTER(MsjCarry), ctypes.POINTER(MsjShardPlacement)]
+        L.msj_sharded_get_stats.restype = i32
+        L.msj_sharded_get_stats.argtypes = [vp, ctypes.POINTER(MsjShardedStats)]
+        L.msj_exchange_release.restype = None
+        L.msj_exchange_release.argtypes = [ctypes.POINTER(MsjExchange)]
         L.msj_debug_set_segment_bytes.restype = i32
         L.msj_debug_set_segment_bytes.argtypes = [vp, u64]
         _bound = True
@@ -105,9 +122,10 @@ def speculate_bytes(halo, head):
     return (int(c.in_string), int(c.next_is_escaped), int(c.prev_scalar))
 
 
-def verify_reports(reports):
+def verify_reports(reports, counts=None, offsets=False):
     """``msj_shard_verify`` on a list of (used, out) pairs of (in_string, next_is_escaped, prev_scalar[, internal_error])
-    tuples.  Returns (known, rerun_mask, exact_in) with exact_in[g] = (s, e, ps) for g < known."""
+    tuples; counts: optional per-rank (structurals, bytes) of the launches.  Returns (known, rerun_mask, exact_in) with
+    exact_in[g] = (s, e, ps) for g < known -- with offsets=True (s, e, ps, index_begin, byte_base)."""
     world = len(reports)
     arr = (MsjShardReport * world)()
     for g, (used, out) in enumerate(reports):
@@ -115,11 +133,14 @@ def verify_reports(reports):
         arr[g].out.in_string, arr[g].out.next_is_escaped, arr[g].out.prev_scalar = out[:3]
         if len(out) > 3:
             arr[g].out.internal_error = out[3]
+        if counts is not None:
+            arr[g].out.count, arr[g].out.bytes = counts[g]
     exact = (MsjCarry * world)()
     mask = ctypes.c_uint64(0)
     known = lib().msj_shard_verify(arr, world, exact, ctypes.byref(mask))
     assert known >= 0, known
-    return known, int(mask.value), [(int(exact[g].in_string), int(exact[g].next_is_escaped), int(exact[g].prev_scalar))
+    return known, int(mask.value), [(int(exact[g].in_string), int(exact[g].next_is_escaped), int(exact[g].prev_scalar)) +
+                                    ((int(exact[g].count), int(exact[g].bytes)) if offsets else ())
                                     for g in range(known)]
 
 
@@ -131,23 +152,51 @@ class _NcclUniqueId(ctypes.Structure):
     _fields_ = [("internal", ctypes.c_char * 128)]
 
 
+def _all_ok(ok, device, group):
+    """True iff `ok` holds on every rank (one small all-reduce): the ranks take every turn together."""
+    t = torch.tensor([1 if ok else 0], dtype=torch.int32, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MIN, group=group)
+    return int(t.item()) == 1
+
+
 def _rccl_communicator(rank, world, device, group):
     """An RCCL communicator of this module's own (the one inside torch's process group is not reachable):
-    ncclGetUniqueId on rank 0, the 128-byte id broadcast through torch.distributed, ncclCommInitRank."""
+    ncclGetUniqueId on rank 0, the 128-byte id broadcast through torch.distributed, ncclCommInitRank.
+
+    Every step that can fail on one rank alone (loading the library, ncclGetUniqueId, ncclCommInitRank) is followed
+    by an agreement of all ranks, so that nobody enters a collective the others have left.  Returns
+    (rccl, comm, path, ncclCommCount) or None -- the same on every rank."""
     path = _torch_rccl_path()
-    rccl = ctypes.CDLL(path, mode=ctypes.RTLD_GLOBAL)
-    uid = _NcclUniqueId()
-    if rank == 0:
-        rc = rccl.ncclGetUniqueId(ctypes.byref(uid))
-        assert rc == 0, f"ncclGetUniqueId: {rc}"
+    rccl, uid, why = None, _NcclUniqueId(), None
+    try:
+        rccl = ctypes.CDLL(path, mode=ctypes.RTLD_GLOBAL)
+        if rank == 0:
+            rc = rccl.ncclGetUniqueId(ctypes.byref(uid))
+            if rc != 0:
+                why = f"ncclGetUniqueId: {rc}"
+    except OSError as e:
+        why = repr(e)
+    if not _all_ok(why is None, device, group):
+        if why:
+            print(f"mojo_simdjson_amd.sharded: no RCCL communicator of our own ({why})", file=sys.stderr)
+        return None
     t = torch.frombuffer(bytearray(bytes(uid)), dtype=torch.uint8).to(device)
     dist.broadcast(t, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
     ctypes.memmove(ctypes.byref(uid), t.cpu().numpy().tobytes(), 128)
     comm = ctypes.c_void_p()
     rccl.ncclCommInitRank.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_int, _NcclUniqueId, ctypes.c_int]
     rc = rccl.ncclCommInitRank(ctypes.byref(comm), world, uid, rank)
-    assert rc == 0, f"ncclCommInitRank: {rc}"
-    return rccl, comm, path
+    count = ctypes.c_int(0)
+    if rc == 0:
+        rccl.ncclCommCount.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_int)]
+        rc = rccl.ncclCommCount(comm, ctypes.byref(count))
+    if rc != 0:
+        print(f"mojo_simdjson_amd.sharded: ncclCommInitRank / ncclCommCount: {rc}", file=sys.stderr)
+    if not _all_ok(rc == 0 and count.value == world, device, group):
+        if comm:
+            rccl.ncclCommDestroy(comm)
+        return None
+    return rccl, comm, path, int(count.value)
 
 
 class ShardedStage1:
@@ -159,12 +208,18 @@ class ShardedStage1:
 
     DEPTH = 3
 
-    def __init__(self, dev, rank, world, group=None, always_gather=False):
+    def __init__(self, dev, rank, world, group=None, always_gather=False, exchange="rccl"):
         """always_gather: take the collective path even for world == 1 (lets a one-GPU box exercise the RCCL
-        plumbing)."""
+        plumbing).  exchange: "rccl" = the library calls ncclAllGather on a communicator of this object's own when
+        the process group's backend is "nccl"; "torch" = the 128 bytes go through torch.distributed (what a "gloo"
+        group always does)."""
         self.dev, self.rank, self.world, self.group = dev, rank, world, group
         self.always_gather = always_gather
+        self.exchange = exchange
+        self.exchange_used = None  # "rccl" or "torch", known after the first submission
+        self.rccl_ranks = 0        # ncclCommCount of the stitch's communicator (0: no communicator of our own)
         self.last_spec = None  # the exact carry-in of the last verified run: pass it when re-submitting the same shard
+        self.last_placement = None  # (index_begin, byte_base, count, bytes) of the last verified run
         self._h = None
         self._rccl = None
         self._tickets = {}
@@ -201,20 +256,22 @@ class ShardedStage1:
         L.msj_copy_to_host.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint64, ctypes.c_void_p]
         L.msj_copy_to_device.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_char_p, ctypes.c_uint64, ctypes.c_void_p]
         x = MsjExchange()
-        native = dist.get_backend(self.group) == "nccl" and os.environ.get("MSJ_SHARDED_EXCHANGE", "rccl") != "torch"
+        native = dist.get_backend(self.group) == "nccl" and self.exchange == "rccl"
         if native:
-            # every rank must end up with the same kind of exchange: agree on the outcome before using it
-            ok = 1
-            try:
-                self._rccl = _rccl_communicator(self.rank, self.world, self.dev.device, self.group)
-                if L.msj_exchange_rccl(self._rccl[1], self.rank, self.world, self._rccl[2].encode(), ctypes.byref(x)) != 0:
-                    ok = 0
-            except Exception as e:  # noqa: BLE001 -- whatever went wrong, the fallback still stitches
-                print(f"mojo_simdjson_amd.sharded: no RCCL communicator of our own ({e!r})", file=sys.stderr)
-                ok = 0
-            t = torch.tensor([ok], dtype=torch.int32, device=self.dev.device)
-            dist.all_reduce(t, op=dist.ReduceOp.MIN, group=self.group)
-            if int(t.item()) == 0:
+            # every rank must end up with the same kind of exchange: each step is agreed on before the next one
+            self._rccl = _rccl_communicator(self.rank, self.world, self.dev.device, self.group)
+            ok = self._rccl is not None
+            if ok:
+                ok = L.msj_exchange_rccl(self._rccl[1], self.rank, self.world, self._rccl[2].encode(), ctypes.byref(x)) == 0
+                if not _all_ok(ok, self.dev.device, self.group):
+                    if ok:
+                        L.msj_exchange_release(ctypes.byref(x))  # it worked here but not everywhere: give it back
+                    self._rccl[0].ncclCommDestroy(self._rccl[1])
+                    self._rccl = None
+                    ok = False
+            if ok:
+                self.rccl_ranks = self._rccl[3]
+            else:
                 if self.rank == 0:
                     print("mojo_simdjson_amd.sharded: falling back to the exchange through torch.distributed", file=sys.stderr)
                 native = False
@@ -222,6 +279,7 @@ class ShardedStage1:
             self._cb = self._torch_allgather()  # keep the callback object alive
             x = MsjExchange()
             x.comm, x.allgather, x.rank, x.world = None, self._cb, self.rank, self.world
+        self.exchange_used = "rccl" if native else "torch"
         h = ctypes.c_void_p()
         rc = L.msj_sharded_create(self.dev.ctx, ctypes.byref(x), None, ctypes.byref(h))
         if rc != 0:
@@ -249,6 +307,13 @@ class ShardedStage1:
     @property
     def rounds(self):
         return int(lib().msj_sharded_rounds(self._h)) if self._h else 0
+
+    def stats(self):
+        """``msj_sharded_get_stats`` as a dict (cumulative): results, rounds, reruns, stitch_device_ns, result_wait_ns."""
+        st = MsjShardedStats()
+        if self._h:
+            lib().msj_sharded_get_stats(self._h, ctypes.byref(st))
+        return {k: int(getattr(st, k)) for k in ("results", "rounds", "reruns", "stitch_device_ns", "result_wait_ns")}
 
     # ---- speculation from local bytes only (host logic; compute once per placed shard)
     def speculate(self, has_prefix, d_shard=None, shard_len=0, d_halo=None, host_halo=None, host_head=None):
@@ -297,17 +362,20 @@ class ShardedStage1:
         return dict(ticket=int(ticket.value), keep=(d_shard, d_idx, segments))
 
     def result(self, ticket, flags=None):
-        """Wait for a submission; returns (code, total_count, local msj_carry)."""
+        """Wait for a submission; returns (code, total_count, local msj_carry).  The stitched offsets of this
+        shard -- (index_begin, byte_base, count, bytes), ``msj_shard_placement`` -- are in ``last_placement``."""
         if "single" in ticket:
             c = self.dev.fetch(ticket["single"])
+            self.last_placement = (0, 0, int(c.count), int(c.bytes))
             return int(c.code), int(c.count), c
         code, total = ctypes.c_int32(0), ctypes.c_uint64(0)
-        local, used = MsjCarry(), MsjCarry()
+        local, used, place = MsjCarry(), MsjCarry(), MsjShardPlacement()
         rc = lib().msj_stage1_sharded_result(self._h, ticket["ticket"], ctypes.byref(code), ctypes.byref(total),
-                                             ctypes.byref(local), ctypes.byref(used))
+                                             ctypes.byref(local), ctypes.byref(used), ctypes.byref(place))
         if rc != 0:
             raise RuntimeError(f"msj_stage1_sharded_result failed: {rc}")
         self.last_spec = (int(used.in_string), int(used.next_is_escaped), int(used.prev_scalar))
+        self.last_placement = (int(place.index_begin), int(place.byte_base), int(place.count), int(place.bytes))
         return int(code.value), int(total.value), local
 
     def run(self, d_shard, shard_len, d_idx, total_len, has_prefix, flags=0, segments=None,

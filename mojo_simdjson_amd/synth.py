@@ -47,3 +47,24 @@ def extreme(n, kind):
     out = np.empty(int(n), dtype=np.uint8)
     m = g.msj_gen_extreme(out.ctypes.data, int(n), kind)
     return out[:m]
+
+
+def stream_shard(d_unit, unit_len, start, length):
+    """Bytes [start, start + length) of the endless repetition of a device-resident unit (a torch uint8 tensor):
+    how bench.py and the full-size tests place a byte-range shard of BASELINE config 5's stream on its GPU
+    (start may be negative by up to one unit: the 64-byte halo in front of a shard)."""
+    import torch
+
+    parts = []
+    off = start % unit_len
+    remaining = length
+    first = min(unit_len - off, remaining)
+    parts.append(d_unit[off:off + first])
+    remaining -= first
+    full = remaining // unit_len
+    if full:
+        parts.append(d_unit.repeat(full))
+    remaining -= full * unit_len
+    if remaining:
+        parts.append(d_unit[:remaining])
+    return torch.cat(parts)

@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """msj_stage1 (host pointers, pageable buffers) on valid documents of 8 .. 256 MiB: ms and GB/s.  Run once as is and
-once with MSJ_PIPE_DISABLE=1 (plain staging) to see where the chunked pipeline starts to pay."""
+once with MSJ_PIPE_DISABLE=1 (plain staging) to see where the chunked pipeline starts to pay.  The knob exists in the
+measurement build only (make -C mojo_simdjson_amd/csrc knobs), which this script loads."""
 import ctypes
 import os
 import sys
@@ -11,6 +12,7 @@ import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from mojo_simdjson_amd import _lib, synth  # noqa: E402
 
+_lib.LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libmsj_stage1_knobs.so")
 lib = _lib.load()
 lib.msj_debug_set_pipeline_min_bytes(None, 24 << 20)
 mode = "plain staging" if os.environ.get("MSJ_PIPE_DISABLE") else "pipeline from 24 MiB"

@@ -7,7 +7,7 @@ export TMPDIR=/tmp
 i=0
 for G in "$@"; do
   i=$((i+1))
-  rocprofv3 --pmc $G --kernel-trace -d $OUT/g$i -o g --output-format csv -- python3 bench.py --steps 3 --warmup 1 --workload $W --no-cpu-baseline > $OUT/g$i.log 2>&1 || { echo "group $i failed: $G"; tail -3 $OUT/g$i.log; }
+  rocprofv3 --pmc $G --kernel-trace -d $OUT/g$i -o g --output-format csv -- python3 bench.py ${MSJ_LIB:+--lib $MSJ_LIB} --steps 3 --warmup 1 --workload $W --no-cpu-baseline > $OUT/g$i.log 2>&1 || { echo "group $i failed: $G"; tail -3 $OUT/g$i.log; }
 done
 python3 - <<'PY'
 import csv, glob, collections

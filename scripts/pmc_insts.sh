@@ -1,10 +1,10 @@
 #!/bin/bash
-# Dynamic instruction counts per tile for one build: scripts/pmc_insts.sh [workload] (honours MSJ_STAGE1_LIB)
+# Dynamic instruction counts per tile for one build: scripts/pmc_insts.sh [workload] (MSJ_LIB=path selects the build: passed to bench.py as --lib)
 cd "$(dirname "$0")/.."
 W=${1:-minified}
 OUT=gpurun_out/pmc_insts; rm -rf $OUT; mkdir -p $OUT
 export TMPDIR=/tmp
-rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_BRANCH SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU SQ_INSTS_SMEM --kernel-trace -d $OUT/g -o g --output-format csv -- python3 bench.py --steps 3 --warmup 1 --settle-ms 0 --workload $W --no-cpu-baseline > $OUT/g.log 2>&1 || echo "failed"
+rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_BRANCH SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU SQ_INSTS_SMEM --kernel-trace -d $OUT/g -o g --output-format csv -- python3 bench.py ${MSJ_LIB:+--lib $MSJ_LIB} --steps 3 --warmup 1 --settle-ms 0 --workload $W --no-cpu-baseline > $OUT/g.log 2>&1 || echo "failed"
 python3 - <<'PY'
 import csv, glob, collections
 agg = collections.defaultdict(list)

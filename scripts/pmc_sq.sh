@@ -15,7 +15,7 @@ for G in "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU" \
          "SQ_INSTS_SMEM SQ_INSTS_VMEM_WR SQ_ACTIVE_INST_MISC SQ_INSTS_BRANCH" \
          "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_LDS_ADDR_CONFLICT SQ_INSTS_WAVE32_LDS"; do
   i=$((i+1))
-  rocprofv3 --pmc $G --kernel-trace -d $OUT/g$i -o g$i --output-format csv -- python3 bench.py --steps 3 --warmup 1 --workload $W --no-cpu-baseline > $OUT/g$i.log 2>&1 || echo "group $i failed"
+  rocprofv3 --pmc $G --kernel-trace -d $OUT/g$i -o g$i --output-format csv -- python3 bench.py ${MSJ_LIB:+--lib $MSJ_LIB} --steps 3 --warmup 1 --workload $W --no-cpu-baseline > $OUT/g$i.log 2>&1 || echo "group $i failed"
 done
 python3 - <<'PY'
 import csv, glob, collections

@@ -1,5 +1,5 @@
 #!/bin/bash
-# Short form of valu_probe.sh: the three BASELINE workloads only (honours MSJ_STAGE1_LIB).
+# Short form of valu_probe.sh: the three BASELINE workloads only (MSJ_LIB=path selects the build: passed to bench.py as --lib).
 cd "$(dirname "$0")/.."
 TAG=${1:-quick}
 OUT=gpurun_out/valu_probe/$TAG; rm -rf $OUT; mkdir -p $OUT
@@ -7,7 +7,7 @@ export TMPDIR=/tmp
 run() {
   name=$1; shift
   timeout -k 10 150 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY \
-      --kernel-trace -d $OUT/$name -o g --output-format csv -- python3 bench.py --steps 6 --warmup 2 --settle-ms 0 --no-cpu-baseline "$@" > $OUT/$name.log 2>&1 || echo "$name failed"
+      --kernel-trace -d $OUT/$name -o g --output-format csv -- python3 bench.py ${MSJ_LIB:+--lib $MSJ_LIB} --steps 6 --warmup 2 --settle-ms 0 --no-cpu-baseline "$@" > $OUT/$name.log 2>&1 || echo "$name failed"
   python3 - "$OUT/$name" "$name" <<'PY'
 import csv, glob, collections, sys
 agg = collections.defaultdict(list)

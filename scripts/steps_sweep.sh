@@ -1,6 +1,6 @@
 cd /root/repo
 for st in 20 100 500 2500; do
-  MSJ_STAGE1_LIB=$PWD/variants/v15g.so timeout -k 10 200 python bench.py --steps $st --warmup 3 --no-cpu-baseline 2>/dev/null | python3 -c "import sys,json; d=json.loads(sys.stdin.readline()); print('steps $st', d['ms_per_step'], 'ms', d['value'], 'GB/s frac', d['roofline']['frac'])"
+  timeout -k 10 200 python bench.py --lib $PWD/variants/v15g.so --steps $st --warmup 3 --no-cpu-baseline 2>/dev/null | python3 -c "import sys,json; d=json.loads(sys.stdin.readline()); print('steps $st', d['ms_per_step'], 'ms', d['value'], 'GB/s frac', d['roofline']['frac'])"
 done
-MSJ_STAGE1_LIB=$PWD/variants/v15g.so timeout -k 10 200 python bench.py --steps 600 --warmup 3 --no-cpu-baseline --gib-per-gpu 3.9 2>/dev/null | python3 -c "import sys,json; d=json.loads(sys.stdin.readline()); print('3.9 GiB steps 600', d['ms_per_step'], 'ms', d['value'], 'GB/s frac', d['roofline']['frac'])"
-MSJ_STAGE1_LIB=$PWD/variants/v15g.so timeout -k 10 200 python bench.py --steps 20 --warmup 3 --no-cpu-baseline --gib-per-gpu 3.9 2>/dev/null | python3 -c "import sys,json; d=json.loads(sys.stdin.readline()); print('3.9 GiB steps 20', d['ms_per_step'], 'ms', d['value'], 'GB/s frac', d['roofline']['frac'])"
+timeout -k 10 200 python bench.py --lib $PWD/variants/v15g.so --steps 600 --warmup 3 --no-cpu-baseline --gib-per-gpu 3.9 2>/dev/null | python3 -c "import sys,json; d=json.loads(sys.stdin.readline()); print('3.9 GiB steps 600', d['ms_per_step'], 'ms', d['value'], 'GB/s frac', d['roofline']['frac'])"
+timeout -k 10 200 python bench.py --lib $PWD/variants/v15g.so --steps 20 --warmup 3 --no-cpu-baseline --gib-per-gpu 3.9 2>/dev/null | python3 -c "import sys,json; d=json.loads(sys.stdin.readline()); print('3.9 GiB steps 20', d['ms_per_step'], 'ms', d['value'], 'GB/s frac', d['roofline']['frac'])"

@@ -1,6 +1,6 @@
 #!/bin/bash
 # Dynamic instruction counts per 4 KiB tile for several workloads / diagnostic modes of one build
-# (honours MSJ_STAGE1_LIB):  scripts/valu_probe.sh [tag]
+# (MSJ_LIB=path selects the build: passed to bench.py as --lib):  scripts/valu_probe.sh [tag]
 # One rocprofv3 --pmc pass per configuration; prints per-tile means and the kernel's average duration.
 cd "$(dirname "$0")/.."
 TAG=${1:-probe}
@@ -9,7 +9,7 @@ export TMPDIR=/tmp
 run() {
   name=$1; shift
   timeout -k 10 150 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY \
-      --kernel-trace -d $OUT/$name -o g --output-format csv -- python3 bench.py --steps 6 --warmup 2 --settle-ms 0 --no-cpu-baseline "$@" > $OUT/$name.log 2>&1 || echo "$name failed"
+      --kernel-trace -d $OUT/$name -o g --output-format csv -- python3 bench.py ${MSJ_LIB:+--lib $MSJ_LIB} --steps 6 --warmup 2 --settle-ms 0 --no-cpu-baseline "$@" > $OUT/$name.log 2>&1 || echo "$name failed"
   python3 - "$OUT/$name" "$name" <<'PY'
 import csv, glob, collections, sys
 agg = collections.defaultdict(list)

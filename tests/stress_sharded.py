@@ -69,18 +69,19 @@ def run_case(torch, L, sharded, MsjCarry, devs, data, cuts, seg_bytes):
                                              sp, 0, ctypes.byref(ticket))
             assert rc == 0, rc
             rcode, rtotal = ctypes.c_int32(), ctypes.c_uint64()
-            local, used = MsjCarry(), MsjCarry()
+            local, used, place = MsjCarry(), MsjCarry(), sharded.MsjShardPlacement()
             rc = L.msj_stage1_sharded_result(h, ticket.value, ctypes.byref(rcode), ctypes.byref(rtotal), ctypes.byref(local),
-                                             ctypes.byref(used))
+                                             ctypes.byref(used), ctypes.byref(place))
             assert rc == 0, rc
             stream.synchronize()
             cnt = int(local.count)
             segs = np.frombuffer(d_seg.cpu().numpy().tobytes(), dtype=np.uint64).reshape(nseg, 4)
             vals = d_idx[: cnt + 3].cpu().numpy().view(np.uint32).astype(np.int64)
             out = vals[:cnt].copy()
+            assert (int(place.byte_base), int(place.count), int(place.bytes)) == (lo, cnt, hi - lo), (rank, lo, cnt)
             for base, blen, ibeg, c in segs:
-                out[int(ibeg):int(ibeg) + int(c)] += int(base) + lo
-            results[rank] = (rcode.value, int(rtotal.value), out, vals[cnt:], int(L.msj_sharded_reruns(h)))
+                out[int(ibeg):int(ibeg) + int(c)] += int(base) + int(place.byte_base)
+            results[rank] = (rcode.value, int(rtotal.value), out, vals[cnt:], int(L.msj_sharded_reruns(h)), int(place.index_begin))
             L.msj_sharded_destroy(h)
         except BaseException as exc:  # surface failures of worker threads
             with lock:
@@ -149,6 +150,9 @@ def main():
             owner = int(np.searchsorted(np.cumsum(counts), bad, side="right"))
             raise AssertionError(f"{tag}: code {code}, index {bad} of {k} (rank {owner}, counts {counts}, re-runs {[r[4] for r in res]}): "
                                  f"got {merged[bad - 2:bad + 3].tolist()} want {want[bad - 2:bad + 3].tolist()}; bytes there {data[max(0, int(want[min(bad, k - 1)]) - 20):int(want[min(bad, k - 1)]) + 20]!r}")
+        # the stitched offsets: every shard's first index sits at index_begin of the stream-wide array
+        begins = np.concatenate([[0], np.cumsum([r[2].size for r in res])[:-1]])
+        assert [r[5] for r in res] == begins.tolist(), f"{tag}: index_begin {[r[5] for r in res]} != {begins.tolist()}"
         if code in (0, 13):
             assert list(res[-1][3]) == [n, n, 0], f"{tag}: trailer {list(res[-1][3])}"
         cases += 1

@@ -37,8 +37,31 @@ def test_struct_layouts():
 
     assert ctypes.sizeof(_lib.MsjCarry) == 64
     assert _lib.MsjCarry.count.offset == 0 and _lib.MsjCarry.in_string.offset == 16
-    assert _lib.MsjCarry.code.offset == 40
+    assert _lib.MsjCarry.code.offset == 40 and _lib.MsjCarry.capacity_error.offset == 44
     assert ctypes.sizeof(_lib.MsjSegment) == 32
+    from mojo_simdjson_amd import sharded
+
+    assert ctypes.sizeof(sharded.MsjShardPlacement) == 32 and ctypes.sizeof(sharded.MsjShardedStats) == 64
+    assert ctypes.sizeof(sharded.MsjShardReport) == 128  # what one rank contributes to the all-gather
+
+
+def test_no_environment_switches():
+    """the shipped package must not be able to load another kernel, or change its data path,
+    because of an environment variable.  The library imports no getenv at all (the host pipeline's tuning knobs
+    exist only in the -DMSJ_DEBUG_KNOBS measurement build) and the Python side never looks at os.environ."""
+    import subprocess
+
+    from mojo_simdjson_amd import _lib
+
+    und = subprocess.check_output(["nm", "-D", "--undefined-only", _lib.LIB_PATH], text=True)
+    assert "getenv" not in und, [l for l in und.splitlines() if "getenv" in l]
+    for root, _, files in os.walk(PKG):
+        for f in files:
+            if f.endswith(".py"):
+                text = open(os.path.join(root, f)).read()
+                assert "os.environ" not in text and "getenv(" not in text, os.path.join(root, f)
+    assert _lib.LIB_PATH == os.path.join(PKG, "libmsj_stage1.so")
+    assert re.search(rb"src:[0-9a-f]{12}$", _lib.load().msj_version())
 
 
 def test_product_never_touches_oracle():

@@ -126,6 +126,12 @@ def test_verify_chain():
         for g in range(known):
             e, s, ps = true_in[g]
             assert exact[g] == (s, e, ps)
+        # the stitched offsets: exclusive sums of the counts / bytes the launches reported
+        counts = [(rng.randint(0, 1000), cuts[g + 1] - cuts[g]) for g in range(world)]
+        known2, mask2, exact2 = sharded.verify_reports(reports, counts=counts, offsets=True)
+        assert (known2, mask2) == (known, mask)
+        for g in range(known):
+            assert exact2[g][3:] == (sum(c for c, _ in counts[:g]), cuts[g])
 
 
 def _free_port():
@@ -140,6 +146,7 @@ class _HostOps:
     def __init__(self):
         self.bufs = {}
         self.launches = 0
+        self.fail_at = None  # launch number (1-based) whose run_shard fails
         O = sharded.MsjShardedOps
         f = dict(O._fields_)
         self.alloc = f["alloc"](self._alloc)
@@ -165,17 +172,22 @@ class _HostOps:
     def _run(self, user, d_shard, length, d_idx, cap, d_in, d_out, d_seg, max_seg, has_prefix, is_final, trailer_len,
              stream, flags):
         self.launches += 1
+        if self.fail_at == self.launches:
+            return -3
         data = ctypes.string_at(d_shard, length)
         cin = MsjCarry.from_address(d_in)
         idx, bad, esc, instr, pnq = serial_run(data, cin.next_is_escaped, cin.in_string, cin.prev_scalar)
         out = MsjCarry.from_address(d_out)
         ctypes.memset(d_out, 0, ctypes.sizeof(MsjCarry))
-        out.count, out.bytes = len(idx), length
+        out.count, out.bytes = cin.count + len(idx), cin.bytes + length
         out.in_string, out.next_is_escaped, out.prev_scalar, out.unescaped_error = instr, esc, pnq, bad
-        arr = (ctypes.c_uint32 * (len(idx) + 3)).from_address(d_idx)
-        for k, v in enumerate(idx):
+        # like the kernel (finish_launch): clipped writes and a sticky flag when the index buffer is too small
+        need = len(idx) + (3 if is_final else 0)
+        out.capacity_error = int(need > cap)
+        arr = (ctypes.c_uint32 * max(1, min(need, cap))).from_address(d_idx)
+        for k, v in enumerate(idx[:cap]):
             arr[k] = v
-        if is_final:
+        if is_final and need <= cap:
             arr[len(idx)], arr[len(idx) + 1], arr[len(idx) + 2] = trailer_len & 0xFFFFFFFF, trailer_len & 0xFFFFFFFF, 0
         return 0
 
@@ -201,7 +213,9 @@ def _live_worker(rank, world, port, cases, q):
         h = ctypes.c_void_p()
         assert L.msj_sharded_create(None, ctypes.byref(x), ctypes.byref(host.ops), ctypes.byref(h)) == 0
         results = []
-        for data_hex, cuts in cases:
+        for case in cases:
+            data_hex, cuts = case[0], case[1]
+            short = case[2] if len(case) > 2 else None  # (rank, capacity): that rank's index buffer is too small
             data = bytes.fromhex(data_hex)
             lo, hi = cuts[rank], cuts[rank + 1]
             # the "device" holds the 64-byte halo in front of the shard, like a placed shard does
@@ -210,23 +224,86 @@ def _live_worker(rank, world, port, cases, q):
             alloc = ctypes.create_string_buffer(pad + data[max(0, lo - 64):hi], len(pad) + hi - max(0, lo - 64))
             d_shard = ctypes.addressof(alloc) + (len(pad) + min(64, lo) if rank > 0 else 0)
             idx = (ctypes.c_uint32 * (hi - lo + 3))()
+            cap = short[1] if short and short[0] == rank else hi - lo + 3
             ticket = ctypes.c_uint32()
             before = host.launches
-            rc = L.msj_stage1_sharded_submit(h, d_shard, hi - lo, ctypes.addressof(idx), hi - lo + 3, len(data), int(rank > 0),
+            rc = L.msj_stage1_sharded_submit(h, d_shard, hi - lo, ctypes.addressof(idx), cap, len(data), int(rank > 0),
                                              None, None, 0, None, 0, ctypes.byref(ticket))
             assert rc == 0 and halo in (0, 64)
             code, total = ctypes.c_int32(), ctypes.c_uint64()
-            local, used = MsjCarry(), MsjCarry()
+            local, used, place = MsjCarry(), MsjCarry(), sharded.MsjShardPlacement()
             assert L.msj_stage1_sharded_result(h, ticket.value, ctypes.byref(code), ctypes.byref(total), ctypes.byref(local),
-                                               ctypes.byref(used)) == 0
+                                               ctypes.byref(used), ctypes.byref(place)) == 0
             n = int(local.count)
-            results.append((code.value, int(total.value), [int(idx[k]) + lo for k in range(n)],
+            assert (int(place.byte_base), int(place.count), int(place.bytes)) == (lo, n, hi - lo)
+            results.append((code.value, int(total.value), [int(idx[k]) + lo for k in range(min(n, cap))],
                             (used.next_is_escaped, used.in_string, used.prev_scalar), host.launches - before,
-                            [int(idx[n + k]) for k in range(3)] if rank == world - 1 else None))
+                            [int(idx[n + k]) for k in range(3)] if rank == world - 1 and n + 3 <= cap else None,
+                            int(place.index_begin)))
+        st = sharded.MsjShardedStats()
+        assert L.msj_sharded_get_stats(h, ctypes.byref(st)) == 0
+        assert (st.results, st.rounds, st.reruns) == (len(cases), L.msj_sharded_rounds(h), L.msj_sharded_reruns(h))
+        assert st.stitch_device_ns == 0  # host operations: nothing times the device side
+        # a launch that fails at submission leaves no slot busy behind it (both ranks fail their own launch, so
+        # nobody is left alone in the all-gather)
+        data = b'["' + b"a" * 200 + b'"]'
+        alloc = ctypes.create_string_buffer(bytes(64) + data, 64 + len(data))
+        idx = (ctypes.c_uint32 * (len(data) + 3))()
+        for _ in range(4):  # more often than there are slots
+            host.fail_at = host.launches + 1
+            ticket = ctypes.c_uint32()
+            rc = L.msj_stage1_sharded_submit(h, ctypes.addressof(alloc) + 64, len(data), ctypes.addressof(idx), len(data) + 3,
+                                             2 * len(data), int(rank > 0), None, None, 0, None, 0, ctypes.byref(ticket))
+            assert rc == -3, rc
+        host.fail_at = None
         q.put((rank, results, int(L.msj_sharded_reruns(h)), int(L.msj_sharded_rounds(h))))
         L.msj_sharded_destroy(h)
     finally:
         dist.destroy_process_group()
+
+
+def test_failed_rerun_frees_the_ticket():
+    """a launch that fails while a rank indexes again used to return with the slot still busy, so
+    three such failures exhausted the object.  World 1, host operations, a speculation that is refuted by the
+    chain (the stream cannot start inside a string), a shard runner that fails the re-run."""
+    L = sharded.lib()
+    host = _HostOps()
+
+    def allgather(comm, d_send, d_recv, nbytes, stream):
+        ctypes.memmove(d_recv, d_send, nbytes)
+        return 0
+
+    cb = sharded.ALLGATHER_FN(allgather)
+    x = sharded.MsjExchange(None, cb, 0, 1, 0, 0)
+    h = ctypes.c_void_p()
+    assert L.msj_sharded_create(None, ctypes.byref(x), ctypes.byref(host.ops), ctypes.byref(h)) == 0
+    data = b'["abc",1]'
+    buf = ctypes.create_string_buffer(data, len(data))
+    idx = (ctypes.c_uint32 * (len(data) + 3))()
+    wrong = MsjCarry()
+    wrong.in_string = 1
+    for attempt in range(5):  # more often than there are slots
+        host.fail_at = host.launches + 2  # the first launch runs, the re-run fails
+        ticket = ctypes.c_uint32()
+        assert L.msj_stage1_sharded_submit(h, ctypes.addressof(buf), len(data), ctypes.addressof(idx), len(data) + 3, len(data),
+                                           0, ctypes.byref(wrong), None, 0, None, 0, ctypes.byref(ticket)) == 0, attempt
+        code, total = ctypes.c_int32(), ctypes.c_uint64()
+        rc = L.msj_stage1_sharded_result(h, ticket.value, ctypes.byref(code), ctypes.byref(total), None, None, None)
+        assert rc == -3, (attempt, rc)
+        # the ticket is gone: asking again is a bad argument, not a hang
+        assert L.msj_stage1_sharded_result(h, ticket.value, None, None, None, None, None) == -1
+    host.fail_at = None
+    ticket = ctypes.c_uint32()
+    assert L.msj_stage1_sharded_submit(h, ctypes.addressof(buf), len(data), ctypes.addressof(idx), len(data) + 3, len(data),
+                                       0, ctypes.byref(wrong), None, 0, None, 0, ctypes.byref(ticket)) == 0
+    code, total = ctypes.c_int32(), ctypes.c_uint64()
+    place = sharded.MsjShardPlacement()
+    assert L.msj_stage1_sharded_result(h, ticket.value, ctypes.byref(code), ctypes.byref(total), None, None, ctypes.byref(place)) == 0
+    want = serial_run(data)[0]
+    assert (code.value, total.value, list(idx[:len(want)])) == (0, len(want), want)
+    assert (place.index_begin, place.byte_base, place.count, place.bytes) == (0, 0, len(want), len(data))
+    assert L.msj_sharded_reruns(h) == 6
+    L.msj_sharded_destroy(h)
 
 
 def test_gloo_world2_live_protocol():
@@ -251,10 +328,17 @@ def test_gloo_world2_live_protocol():
     # unclosed string / control character inside a string on rank 1
     cases.append((b'[1,2,"abc' + b" " * 80 + b'"x', [0, 50, 92]))
     cases.append((b'["' + b"s" * 70 + b"\n" + b's"]', [0, 30, 76]))
+    # an index buffer that is too small on ONE rank (a non-last rank used to clip silently and the
+    # stream still came back as SUCCESS): the whole stream reports CAPACITY, whichever rank it is
+    dense = b"[" * 100 + b"1" + b"]" * 100
+    n_cases_plain = len(cases)
+    cases.append((dense, [0, 96, len(dense)], (0, 50)))
+    cases.append((dense, [0, 96, len(dense)], (1, 50)))
+    cases.append((dense, [0, 96, len(dense)], (1, len(dense) - 96 + 2)))  # room for the indices, not for the trailer
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    payload = [(d.hex(), c) for d, c in cases]
+    payload = [(c[0].hex(),) + tuple(c[1:]) for c in cases]
     procs = [ctx.Process(target=_live_worker, args=(r, 2, port, payload, q)) for r in range(2)]
     for p in procs:
         p.start()
@@ -263,12 +347,18 @@ def test_gloo_world2_live_protocol():
         p.join(timeout=60)
         assert p.exitcode == 0
     total_reruns = 0
-    for k, (data, cuts) in enumerate(cases):
+    for k, case in enumerate(cases):
+        data, cuts = case[0], case[1]
         idx, bad, esc, instr, pnq = serial_run(data)
         want_code = 15 if instr else 14 if bad else 13 if not idx else 0
         r0, r1 = res[0][0][k], res[1][0][k]
-        assert r0[0] == r1[0] == want_code, (k, r0[0], want_code)
+        # the stitched offsets (msj_shard_placement): rank 1's first index is index_begin of the stream's array
+        assert r0[6] == 0 and r1[6] == sum(1 for v in idx if v < cuts[1]), (k, r0[6], r1[6])
         assert r0[1] == r1[1] == len(idx)
+        if k >= n_cases_plain:
+            assert r0[0] == r1[0] == 1, (k, r0[0], r1[0])  # CAPACITY on every rank
+            continue
+        assert r0[0] == r1[0] == want_code, (k, r0[0], want_code)
         assert r0[2] + r1[2] == idx, f"case {k}"
         e, s, ps = serial_state(data[:cuts[1]])
         assert r1[3] == (e, s, ps) and r0[3] == (0, 0, 0)

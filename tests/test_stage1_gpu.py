@@ -503,6 +503,8 @@ def _sharded_worker(rank, world, port, q):
             sh = ShardedStage1(dev, rank, world)
             code, total_count, c = sh.run(d_shard, end - start, d_idx, total, has_prefix=(rank > 0))
             reruns_first = sh.reruns
+            assert sh.last_placement[1:] == (start, int(c.count), end - start)
+            index_begin = sh.last_placement[0]
             # two submissions in flight (what bench.py does for N > 1) give the same answer
             d_idx2 = torch.full_like(d_idx, -1)
             t1 = sh.submit(d_shard, end - start, d_idx2, total, has_prefix=(rank > 0))
@@ -511,7 +513,7 @@ def _sharded_worker(rank, world, port, q):
             assert (r1[0], r1[1], int(r1[2].count)) == (code, total_count, int(c.count)) == (r2[0], r2[1], int(r2[2].count))
             assert torch.equal(d_idx2[: int(c.count)], d_idx[: int(c.count)])
             got = d_idx[: int(c.count) + (3 if rank == world - 1 else 0)].cpu().numpy().view(np.uint32)
-            results.append((name, code, total_count, int(c.count), start, got.tobytes(), reruns_first))
+            results.append((name, code, total_count, int(c.count), start, got.tobytes(), reruns_first, index_begin))
         q.put((rank, results))
         dev.close()
     finally:
@@ -541,8 +543,10 @@ def test_sharded_two_ranks_one_gpu(oracle):
         assert code == 0
         merged = []
         for rank in range(2):
-            rname, rcode, total_count, cnt, start, raw, reruns = out[rank][i]
+            rname, rcode, total_count, cnt, start, raw, reruns, index_begin = out[rank][i]
             assert rname == name and rcode == code and total_count == n
+            # the stitched offset: this shard's first index is index `index_begin` of the stream-wide array
+            assert index_begin == int(np.searchsorted(idx[:n], start)) and (rank > 0 or index_begin == 0)
             if name == "guesswrong" and rank == 1:
                 assert reruns == 1  # the refuted speculation was repaired by exactly one re-run
             vals = np.frombuffer(raw, dtype=np.uint32).astype(np.int64)
@@ -646,20 +650,22 @@ def test_sharded_world8_one_gpu(torch_mod, oracle):
                                              sp, 0, ctypes.byref(ticket))
             assert rc == 0, rc
             rcode, rtotal = ctypes.c_int32(), ctypes.c_uint64()
-            local, used = MsjCarry(), MsjCarry()
+            local, used, place = MsjCarry(), MsjCarry(), sharded.MsjShardPlacement()
             rc = L.msj_stage1_sharded_result(h, ticket.value, ctypes.byref(rcode), ctypes.byref(rtotal), ctypes.byref(local),
-                                             ctypes.byref(used))
+                                             ctypes.byref(used), ctypes.byref(place))
             assert rc == 0, rc
             stream.synchronize()
             cnt = int(local.count)
+            assert (int(place.byte_base), int(place.count), int(place.bytes)) == (lo, cnt, hi - lo)
             segs = np.frombuffer(d_seg.cpu().numpy().tobytes(), dtype=np.uint64).reshape(nseg, 4)
             vals = d_idx[: cnt + (3 if rank == world - 1 else 0)].cpu().numpy().view(np.uint32).astype(np.int64)
-            # indices are relative to their segment's byte_base (msj_segment): back to stream offsets
+            # indices are relative to their segment's byte_base (msj_segment): back to stream offsets with the
+            # placement the stitch returned
             out = vals[:cnt].copy()
             for base, blen, ibeg, c in segs:
-                out[int(ibeg):int(ibeg) + int(c)] += int(base) + lo
+                out[int(ibeg):int(ibeg) + int(c)] += int(base) + int(place.byte_base)
             results[rank] = (rcode.value, int(rtotal.value), out, vals[cnt:], int(L.msj_sharded_reruns(h)),
-                             int(local.utf8_error), nseg, int(segs[:, 3].sum()) == cnt)
+                             int(local.utf8_error), nseg, int(segs[:, 3].sum()) == cnt, int(place.index_begin))
             L.msj_sharded_destroy(h)
         except BaseException as exc:  # surface failures of worker threads
             with lock:
@@ -679,6 +685,10 @@ def test_sharded_world8_one_gpu(torch_mod, oracle):
     merged = np.concatenate([r[2] for r in results])
     assert all(r[0] == code and r[1] == n for r in results)
     assert np.array_equal(merged, idx[:n].astype(np.int64))
+    # the stitched offsets address the oracle's global array: index_begin[g] + local k
+    for g, r in enumerate(results):
+        assert r[8] == int(np.searchsorted(idx[:n], cuts[g])), (g, r[8])
+        assert np.array_equal(idx[r[8]:r[8] + len(r[2])].astype(np.int64), r[2])
     assert list(results[-1][3]) == [total & 0xFFFFFFFF, total & 0xFFFFFFFF, 0]
     assert all(r[7] for r in results) and max(r[6] for r in results) >= 2  # segment tables add up; some shard spans segments
     assert sum(r[4] for r in results) >= 1  # at least one refuted guess was repaired by a re-run
@@ -727,6 +737,176 @@ def test_multi_segment_over_4gib(torch_mod, dev, oracle):
     assert tail == [total & 0xFFFFFFFF, total & 0xFFFFFFFF, 0]
 
 
+def test_config5_share_of_a_non_first_rank_8gib(torch_mod, dev, oracle):
+    """BASELINE.json config 5 as one of its ranks sees it, at full size, index by index: the stream is 1 024 units
+    (64 GiB) cut into 8 byte ranges of ~8 GiB; this is the exact share of a rank > 0 whose cut falls INSIDE A STRING
+    of a unit -- 64-byte halo in front (has_prefix), carry-in from msj_shard_speculate on the halo and the shard's
+    first 4 KiB (checked against the oracle's state at the cut), two uint32 segments, is_final = 0.  Every index is
+    compared on the device with the oracle's unit indices + k * unit_len (tests/replication.py), placed with the
+    segment table the launch wrote; the carry out is the oracle's state at the shard's last byte.  (The reference's
+    own harness compares every index and the trailer, tests/test_stage_1.mojo:43-82; its UInt32 offsets would wrap
+    where the segments start, json_structural_indexer.mojo:138.)"""
+    torch = torch_mod
+    from mojo_simdjson_amd import sharded, synth
+    from tests import replication
+
+    world, SEG = 8, 0xFFFF0000
+    u = synth.workload("minified", 64 << 20)
+    b = u.tobytes()
+    L = len(b)
+    code, n, idx = helpers.run_oracle(oracle.msj_oracle_stage1, b)
+    assert code == 0
+    u_idx = idx[:n].astype(np.int64)
+    total = (world * (8 << 30) // L) * L
+    nominal = -(-(-(-total // world)) // 16384) * 16384
+    fast = helpers.load_oracle_fast()
+
+    def state_at(off):
+        """(in_string, next_is_escaped, prev_scalar) after unit[:off]: in_string from the oracle (a prefix that ends
+        inside a string is UNCLOSED_STRING), the other two from the bytes (tests/test_sharded_cpu.py does the same)."""
+        scratch = np.zeros(off + 3, dtype=np.uint32)
+        nn = ctypes.c_uint64(0)
+        rc = fast.msj_fast_stage1(b[:off], off, scratch.ctypes.data, scratch.size, ctypes.byref(nn))
+        assert rc in (0, 15), rc
+        run = 0
+        while b[off - 1 - run] == 0x5C:
+            run += 1
+        e = run & 1
+        c = b[off - 1]
+        nonscalar = c in (0x20, 0x09, 0x0A, 0x0D, 0x0C, 0x1A, 0x2C, 0x3A, 0x5B, 0x5D, 0x7B, 0x7D)
+        if run:
+            ps = 1
+        elif c == 0x22:
+            r2 = 0
+            while b[off - 2 - r2] == 0x5C:
+                r2 += 1
+            ps = r2 & 1
+        else:
+            ps = int(not nonscalar)
+        return int(rc == 15), e, ps
+
+    rank = next(r for r in range(1, world) if state_at((r * nominal) % L)[0] == 1)  # a cut inside a string
+    start = rank * nominal
+    shard_len = min(total, start + nominal) - start
+    assert shard_len > SEG and start % L != 0 and (start + shard_len) % L != 0
+    d_unit = torch.from_numpy(u).to(dev.device)
+    d_alloc = synth.stream_shard(d_unit, L, start - 64, shard_len + 64)
+    d_shard = d_alloc[64:]
+    assert d_shard.data_ptr() % 16 == 0
+    halo = b[(start - 64) % L:(start - 64) % L + 64] if (start % L) >= 64 else None
+    assert halo is not None
+    head = d_shard[:4096].cpu().numpy().tobytes()
+    assert d_alloc[:64].cpu().numpy().tobytes() == halo
+    spec = sharded.speculate_bytes(halo, head)
+    assert spec == state_at(start % L), "the speculation from the shard's own bytes is the oracle's state at the cut"
+    ib = replication.expected_index_begin(u_idx, L, start)
+    ie = replication.expected_index_begin(u_idx, L, start + shard_len)
+    cap = ie - ib + 16
+    d_idx = torch.empty(cap, dtype=torch.int32, device=dev.device)
+    segs = torch.zeros(4 * 32, dtype=torch.uint8, device=dev.device)
+    cin, cout = dev.make_carry(*spec), dev.new_carry()
+    rc, nseg = dev.shard(d_shard, shard_len, d_idx, cin, cout, segments=segs, has_prefix=True, is_final=False,
+                         trailer_len=total)
+    assert rc == 0 and nseg == 2
+    res = dev.fetch(cout)
+    assert res.internal_error == 0 and res.capacity_error == 0 and res.utf8_error == 0 and res.unescaped_error == 0
+    assert (res.count, res.bytes) == (ie - ib, shard_len)
+    assert (res.in_string, res.next_is_escaped, res.prev_scalar) == state_at((start + shard_len) % L)
+    table = np.frombuffer(segs.cpu().numpy().tobytes(), dtype=np.uint64).reshape(4, 4)[:2]
+    assert [int(x) for x in table[0][:3]] == [0, SEG, 0] and [int(x) for x in table[1][:2]] == [SEG, shard_len - SEG]
+    c0 = replication.expected_index_begin(u_idx, L, start + SEG) - ib
+    assert [int(table[0][3]), int(table[1][2]), int(table[1][3])] == [c0, c0, ie - ib - c0]
+    d_uidx = torch.from_numpy(u_idx).to(dev.device)
+    bad, h = replication.check_shard(torch, d_idx, ie - ib, d_uidx, L, start, ib,
+                                     [(int(r[0]), int(r[2]), int(r[3])) for r in table])
+    assert bad == 0
+    # and the hash is what the expected array itself gives (the piece bench.py's ranks add up)
+    want = 0
+    for a in range(ib, ie, 1 << 26):
+        j = torch.arange(a, min(ie, a + (1 << 26)), dtype=torch.int64, device=dev.device)
+        q = torch.div(j, n, rounding_mode="floor")
+        want = (want + int(((d_uidx[j - q * n] + q * L + 1) * (2 * j + 1)).sum().item())) & replication.MASK64
+    assert h == want
+
+
+def test_capacity_clip_is_reported_by_non_final_shards(torch_mod, dev, oracle):
+    """a non-final shard whose index buffer is too small used to clip its writes and say nothing
+    (only a FINAL segment compared n + 3 with the capacity), so a sharded stream came back as SUCCESS.  The carry
+    out now has a sticky capacity_error; a final shard still returns CAPACITY (1)."""
+    torch = torch_mod
+    from mojo_simdjson_amd import synth
+
+    u = synth.workload("minified", 2 << 20)
+    b = u.tobytes()
+    code, n, idx = helpers.run_oracle(oracle.msj_oracle_stage1, b)
+    d_buf = torch.from_numpy(u).to(dev.device)
+    for cap, final, want_flag in ((n - 1000, False, 1), (n, False, 0), (n + 2, True, 1), (n + 3, True, 0)):
+        d_idx = torch.full((n + 64,), -1, dtype=torch.int32, device=dev.device)
+        cin, cout = dev.new_carry(), dev.new_carry()
+        dev.shard(d_buf, len(b), d_idx[:cap], cin, cout, is_final=final, trailer_len=len(b))
+        res = dev.fetch(cout)
+        assert res.capacity_error == want_flag, (cap, final)
+        assert res.code == (1 if (final and want_flag) else 0)
+        got = d_idx.cpu().numpy().view(np.uint32)
+        m = min(cap, n)
+        assert np.array_equal(got[:m], idx[:m]) and (got[cap:] == 0xFFFFFFFF).all()  # clipped, nothing past the end
+        # sticky along a chain: the next shard of the stream inherits it
+        cout2 = dev.new_carry()
+        dev.shard(d_buf, 4096, d_idx[:8], cout, cout2, is_final=False, no_emit=True)
+        assert dev.fetch(cout2).capacity_error == want_flag
+
+
+def test_single_document_over_a_segment_boundary(torch_mod, oracle):
+    """msj_stage1_device takes documents up to 2^32 - 1 bytes but one launch indexes at most
+    0xFFFF0000; a document in the last 64 KiB runs as two segments, and without a segment table the second one's
+    offsets must stay relative to the document.  With the test hook's small segments: equal to the oracle."""
+    torch = torch_mod
+    from mojo_simdjson_amd import sharded, synth
+    from mojo_simdjson_amd.device import Stage1Device
+
+    d2 = Stage1Device(0)
+    try:
+        assert sharded.lib().msj_debug_set_segment_bytes(d2.ctx, 256 << 10) == 0
+        u = synth.workload("minified", 1 << 20)
+        b = u.tobytes()
+        code, n, idx = helpers.run_oracle(oracle.msj_oracle_stage1, b)
+        d_buf = torch.from_numpy(u).to(d2.device)
+        d_idx, res = device_indices(torch, d2, d_buf, len(b), n + 3)
+        assert res.code == code == 0 and res.count == n
+        assert np.array_equal(d_idx[: n + 3].cpu().numpy().view(np.uint32), idx[: n + 3])
+    finally:
+        d2.close()
+
+
+def test_host_pipeline_unavailable_falls_back_to_plain_staging(oracle):
+    """when the chunked pinned pipeline cannot be set up (no pinned memory to be had, e.g. a memlock
+    limit), large host-pointer inputs used to fail outright.  With the set-up forced to fail the call goes through
+    the plain staging path -- same result -- and the context stops retrying."""
+    from mojo_simdjson_amd import _lib, synth
+
+    lib = _lib.load()
+    u = synth.workload("pretty4", 40 << 20)
+    b = u.tobytes()
+    code, n, idx = helpers.run_oracle(oracle.msj_oracle_stage1, b)
+    out = np.zeros(len(b) + 3, dtype=np.uint32)
+    nn = ctypes.c_uint64(0)
+    lib.msj_debug_set_pipeline_min_bytes(None, 24 << 20)
+    try:
+        assert lib.msj_debug_fail_pipeline_setup(None, 1) == 0
+        for _ in range(2):
+            out[:] = 0
+            rc = lib.msj_stage1(b, len(b), out.ctypes.data_as(ctypes.c_void_p), out.size, ctypes.byref(nn), None, 0)
+            assert rc == code == 0 and nn.value == n and np.array_equal(out[: n + 3], idx[: n + 3])
+        assert lib.msj_debug_fail_pipeline_setup(None, 1) == 1  # given up: the plain path from now on
+        assert lib.msj_debug_fail_pipeline_setup(None, 0) == 0
+        out[:] = 0
+        rc = lib.msj_stage1(b, len(b), out.ctypes.data_as(ctypes.c_void_p), out.size, ctypes.byref(nn), None, 0)  # the pipeline again
+        assert rc == 0 and nn.value == n and np.array_equal(out[: n + 3], idx[: n + 3])
+    finally:
+        lib.msj_debug_fail_pipeline_setup(None, 0)
+        lib.msj_debug_set_pipeline_min_bytes(None, 0)
+
+
 def _rccl_single_rank_worker(port, q, exchange="rccl"):
     """world_size 1 over the real "nccl" (= RCCL) backend: the asynchronous all-gather, the side
     stream and the pinned read-back of ShardedStage1 on the one GPU this box has."""
@@ -735,7 +915,6 @@ def _rccl_single_rank_worker(port, q, exchange="rccl"):
 
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
-    os.environ["MSJ_SHARDED_EXCHANGE"] = exchange
     torch.cuda.set_device(0)
     dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
     try:
@@ -745,7 +924,7 @@ def _rccl_single_rank_worker(port, q, exchange="rccl"):
         dev = Stage1Device(0)
         data = _sharded_dataset(_SHARDED_SETS[0])
         d_buf = torch.from_numpy(np.frombuffer(data, dtype=np.uint8).copy()).to(dev.device)
-        sh = ShardedStage1(dev, 0, 1, always_gather=True)
+        sh = ShardedStage1(dev, 0, 1, always_gather=True, exchange=exchange)
         bufs = [torch.full((len(data) + 3,), -1, dtype=torch.int32, device=dev.device) for _ in range(3)]
         tickets = []
         out = []
@@ -757,6 +936,10 @@ def _rccl_single_rank_worker(port, q, exchange="rccl"):
             out.append(sh.result(tickets.pop(0)))
         code, total, c = out[-1]
         got = bufs[2][: total + 3].cpu().numpy().view(np.uint32).tobytes()
+        st = sh.stats()
+        assert sh.exchange_used == exchange and sh.rccl_ranks == (1 if exchange == "rccl" else 0)
+        assert st["results"] == 6 and st["rounds"] == 6 and st["reruns"] == 0 and st["stitch_device_ns"] > 0
+        assert sh.last_placement == (0, 0, total, len(data))
         q.put(([(o[0], o[1]) for o in out], got))
         dev.close()
     finally:

@@ -218,13 +218,13 @@ def _check_spans(dev, data, where):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("lds_limit", ["", "0", "4096"])
-def test_token_spans(dev, lds_limit, monkeypatch):
+def test_token_spans(dev, lds_limit, request):
     """Both paths of the kernel: the workgroup's stretch staged in LDS with per-byte class bitmaps (default),
     and the per-token path from global memory that long stretches take (forced by a limit of 0; 4096 mixes them)."""
     from mojo_simdjson_amd import synth
 
-    if lds_limit:
-        monkeypatch.setenv("MSJ_SPANS_LDS_LIMIT", lds_limit)
+    dev.lib.msj_debug_set_span_limits(int(lds_limit) if lds_limit else 0xFFFFFFFF, 0xFFFFFFFF)
+    request.addfinalizer(lambda: dev.lib.msj_debug_set_span_limits(0xFFFFFFFF, 0xFFFFFFFF))
 
     for f in helpers.golden_valid_files():
         js, _ = helpers.read_fixture(f)
@@ -258,9 +258,9 @@ def test_token_spans(dev, lds_limit, monkeypatch):
     # ... many of them: the work list of the fix-up pass, and (capacity lowered to 3 entries) its overflow path
     many = b"[" + (b"1," * 255 + b'1.5"xx"' + b"y" * 300 + b" ,") * 40 + b"7]"
     _check_spans(dev, many, "forty tokens on the fix-up list")
-    monkeypatch.setenv("MSJ_SPANS_FIX_CAP", "3")
+    dev.lib.msj_debug_set_span_limits(int(lds_limit) if lds_limit else 0xFFFFFFFF, 3)
     _check_spans(dev, many, "the fix-up list overflows")
-    monkeypatch.delenv("MSJ_SPANS_FIX_CAP")
+    dev.lib.msj_debug_set_span_limits(int(lds_limit) if lds_limit else 0xFFFFFFFF, 0xFFFFFFFF)
     _check_spans(dev, many, "the list is clean again")
     # the closing quote is found from the NEXT structural: byte soups (valid or not) must agree with the forward scan
     rng = np.random.default_rng(9)
@@ -327,12 +327,12 @@ def _check_prep(dev, data, where):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("lds_limit", ["", "0", "4096"])
-def test_stage2_prep_equals_the_separate_calls(dev, lds_limit, monkeypatch):
+def test_stage2_prep_equals_the_separate_calls(dev, lds_limit, request):
     """msj_stage2_prep_device = token pre-pass + token spans from one pass over the buffer."""
     from mojo_simdjson_amd import synth
 
-    if lds_limit:
-        monkeypatch.setenv("MSJ_SPANS_LDS_LIMIT", lds_limit)
+    dev.lib.msj_debug_set_span_limits(int(lds_limit) if lds_limit else 0xFFFFFFFF, 0xFFFFFFFF)
+    request.addfinalizer(lambda: dev.lib.msj_debug_set_span_limits(0xFFFFFFFF, 0xFFFFFFFF))
     for f in helpers.golden_valid_files():
         js, _ = helpers.read_fixture(f)
         _check_prep(dev, js, f)
