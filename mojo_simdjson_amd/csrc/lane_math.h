@@ -324,47 +324,63 @@ MSJ_HD uint64_t unescaped_quotes0(uint64_t quote_chr, uint64_t tt) {
 // an empty stub (json_structural_indexer.mojo:16-30); this implements what
 // upstream simdjson's checker accepts/rejects.
 //
-// Carry word from the previous block (bits of the planes at its top end):
+// Two kinds of rules, checked from two sides so that only five planes have to move across
+// byte positions (each move is a cross-lane shift of three half-rate operations on the device):
+//   * structure -- a byte is a continuation (10xxxxxx) exactly where a lead byte 1, 2 or 3
+//     positions back asks for one: the three lead planes are shifted FORWARD onto the bytes they
+//     constrain (exp1 / exp2 / exp3);
+//   * the four second-byte ranges (E0 A0..BF, ED 80..9F, F0 90..BF, F4 80..8F) -- checked AT THE
+//     LEAD byte against the NEXT byte's bits b5 and (b5 | b4), shifted BACKWARD by one (nb5, nb54:
+//     two planes instead of the four lead classes moving forward).  The pair (last byte of a
+//     block, first byte of the next) is the caller's: `pairmask` clears positions whose next byte
+//     it has not supplied, and utf8_boundary_error() checks such a pair from the carry word.
+//
+// Carry word of the bytes in front of a block (bits of the planes at their top end):
 //   bit 0      : byte[-1] is a lead byte (2-, 3- or 4-byte)
 //   bits 1..2  : byte[-2], byte[-1] is a 3/4-byte lead        (bit1 = byte[-2])
 //   bits 3..5  : byte[-3..-1] is a 4-byte lead                (bit3 = byte[-3])
 //   bit 6 / 7 / 8 / 9 : byte[-1] is E0 / ED / F0 / F4
-struct Utf8Planes {
-    uint64_t lead234, lead34, lead4, isE0, isED, isF0, isF4;
+struct Utf8Leads {
+    uint64_t lead234, lead34, lead4;  // C0..F7 / E0..F7 / F0..F7
+    uint64_t l3, hi2, f;              // 1110xxxx / 11xxxxxx / 1111xxxx (shared with the error terms)
 };
 
-MSJ_HD Utf8Planes utf8_planes(const uint64_t p[8]) {
-    const uint64_t b0 = p[0], b1 = p[1], b2 = p[2], b3 = p[3];
-    const uint64_t b4 = p[4], b5 = p[5], b6 = p[6], b7 = p[7];
-    // three-input LUTs throughout (v_bitop3_b32 on the device)
-    const uint64_t hi2 = b7 & b6;                                          // 11xxxxxx
-    const uint64_t l3 = lut3<MSJ_TT(TA & TB & ~TC)>(hi2, b5, b4);          // 1110xxxx
-    const uint64_t f = lut3<MSJ_TT(TA & TB & TC)>(hi2, b5, b4);            // 1111xxxx
-    const uint64_t l4 = lut3<MSJ_TT(TA & ~TB)>(f, b3, b3);                 // 11110xxx
-    const uint64_t z210 = lut3<MSJ_TT(~TA & ~TB & ~TC)>(b2, b1, b0);       // xxxxx000
-    const uint64_t n101 = lut3<MSJ_TT(TA & ~TB & TC)>(b2, b1, b0);         // xxxxx101
-    const uint64_t n100 = lut3<MSJ_TT(TA & ~TB & ~TC)>(b2, b1, b0);        // xxxxx100
-    Utf8Planes u;
-    u.lead234 = lut3<MSJ_TT(TA & ~(TB & TC))>(hi2, f, b3);                 // C0..F7
-    u.lead34 = l3 | l4;
-    u.lead4 = l4;
-    u.isE0 = lut3<MSJ_TT(TA & ~TB & TC)>(l3, b3, z210);
-    u.isED = lut3<MSJ_TT(TA & TB & TC)>(l3, b3, n101);
-    u.isF0 = l4 & z210;
-    u.isF4 = l4 & n100;
+MSJ_HD Utf8Leads utf8_leads(const uint64_t p[8]) {
+    const uint64_t b3 = p[3], b4 = p[4], b5 = p[5], b6 = p[6], b7 = p[7];
+    Utf8Leads u;
+    u.hi2 = b7 & b6;                                                       // 11xxxxxx
+    u.f = lut3<MSJ_TT(TA & TB & TC)>(u.hi2, b5, b4);                       // 1111xxxx
+    u.l3 = lut3<MSJ_TT(TA & TB & ~TC)>(u.hi2, b5, b4);                     // 1110xxxx
+    u.lead4 = lut3<MSJ_TT(TA & ~TB)>(u.f, b3, b3);                         // 11110xxx
+    u.lead234 = lut3<MSJ_TT(TA & ~(TB & TC))>(u.hi2, u.f, b3);             // C0..F7
+    u.lead34 = u.l3 | u.lead4;                                             // E0..F7
     return u;
 }
 
-MSJ_HD uint32_t utf8_carry_out(const Utf8Planes &u) {
-    return (uint32_t)(u.lead234 >> 63) | ((uint32_t)(u.lead34 >> 62) << 1) |
-           ((uint32_t)(u.lead4 >> 61) << 3) | ((uint32_t)(u.isE0 >> 63) << 6) |
-           ((uint32_t)(u.isED >> 63) << 7) | ((uint32_t)(u.isF0 >> 63) << 8) |
-           ((uint32_t)(u.isF4 >> 63) << 9);
+// bits 6..9 of the carry word: the block's last byte is E0 / ED / F0 / F4
+MSJ_HD uint32_t utf8_special_top(const uint64_t p[8], const Utf8Leads &u) {
+    const uint32_t t = 63;
+    const uint32_t b0 = (uint32_t)(p[0] >> t) & 1u, b1 = (uint32_t)(p[1] >> t) & 1u, b2 = (uint32_t)(p[2] >> t) & 1u;
+    const uint32_t b3 = (uint32_t)(p[3] >> t) & 1u, l3 = (uint32_t)(u.l3 >> t) & 1u, l4 = (uint32_t)(u.lead4 >> t) & 1u;
+    const uint32_t z210 = !(b2 | b1 | b0), n101 = b2 & !b1 & b0, n100 = b2 & !b1 & !b0;
+    return ((l3 & !b3 & z210) << 6) | ((l3 & b3 & n101) << 7) | ((l4 & z210) << 8) | ((l4 & n100) << 9);
 }
 
-// Error mask of one block given the previous block's carry word.  Planes must
-// already be masked with `valid` (bytes past the end read as 0x00 = ASCII, so a
-// sequence truncated at EOF shows up as a missing continuation).
+MSJ_HD uint32_t utf8_carry_out(const uint64_t p[8], const Utf8Leads &u) {
+    return (uint32_t)(u.lead234 >> 63) | ((uint32_t)(u.lead34 >> 62) << 1) | ((uint32_t)(u.lead4 >> 61) << 3) |
+           utf8_special_top(p, u);
+}
+
+// The pair (byte[-1], byte[0]) across a block boundary: byte[-1]'s class from the carry word (bits 6..9),
+// byte[0]'s bits b5 and b4.  Non-zero = the second byte is outside the range its lead byte allows.
+MSJ_HD uint32_t utf8_boundary_error(uint32_t carry_in, uint32_t first_b5, uint32_t first_b4) {
+    const uint32_t n5 = first_b5 & 1u, n54 = (first_b5 | first_b4) & 1u;
+    return (((carry_in >> 6) & 1u) & (n5 ^ 1u)) |   // E0 80..9F  (overlong)
+           (((carry_in >> 7) & 1u) & n5) |          // ED A0..BF  (surrogates)
+           (((carry_in >> 8) & 1u) & (n54 ^ 1u)) |  // F0 80..8F  (overlong)
+           (((carry_in >> 9) & 1u) & n54);          // F4 90..BF  (> U+10FFFF)
+}
+
 // (x << K) with `low` (K bits) shifted in at the bottom: three operations on the halves
 // (bit-field extract by the caller, v_lshl_or_b32, v_alignbit_b32) instead of a 64-bit shift.
 template <int K>
@@ -378,55 +394,64 @@ MSJ_HD uint64_t shl_in(uint64_t x, uint32_t low) {
     return u64((lo << K) | low, nh);
 }
 
-// The lead planes moved to the positions of the bytes they constrain (1, 2 or 3 bytes on),
-// with the previous block's top bits shifted in at the bottom.
+// What moves across byte positions: the lead planes forward onto the bytes they constrain (with the
+// previous bytes' top bits shifted in at the bottom), b5 and b5 | b4 of the NEXT byte backward.
 struct Utf8Shifted {
-    uint64_t exp1, exp2, exp3;     // a continuation byte is expected here (lead 1 / 2 / 3 bytes back)
-    uint64_t pE0, pED, pF0, pF4;   // the byte before is E0 / ED / F0 / F4
+    uint64_t exp1, exp2, exp3;  // a continuation byte is expected here (lead 1 / 2 / 3 bytes back)
+    uint64_t nb5, nb54;         // the next byte's b5 / b5 | b4
 };
 
-MSJ_HD Utf8Shifted utf8_shift(const Utf8Planes &u, uint32_t carry_in) {
+// Error masks of one block.  Planes must already be masked with `valid` (bytes past the end read as
+// 0x00 = ASCII, so a sequence truncated at EOF shows up as a missing continuation).  Returns the errors that
+// stand as they are; *pair_bad receives the second-byte violations, which the caller keeps only at positions
+// whose next byte s.nb5 / s.nb54 really describe (everywhere but a block's last byte without a successor).
+MSJ_HD uint64_t utf8_errors_shifted(const uint64_t p[8], const Utf8Leads &u, const Utf8Shifted &s, uint64_t *pair_bad) {
+    const uint64_t b0 = p[0], b1 = p[1], b2 = p[2], b3 = p[3];
+    const uint64_t b4 = p[4], b5 = p[5], b6 = p[6], b7 = p[7];
+    // expected ^ continuation (10xxxxxx): a missing or a stray continuation byte
+    const uint64_t cont = lut3<MSJ_TT(TA & ~TB)>(b7, b6, b6);
+    const uint64_t e12 = s.exp1 | s.exp2;
+    uint64_t err = lut3<MSJ_TT((TA | TB) ^ TC)>(e12, s.exp3, cont);
+    // F5..FF: 1111xxxx with b3, or with b2 and one of b1, b0
+    const uint64_t x567 = lut3<MSJ_TT(TA & (TB | TC))>(b2, b1, b0);
+    const uint64_t f5ff = lut3<MSJ_TT(TA & (TB | TC))>(u.f, b3, x567);
+    // C0, C1: 1100000x
+    const uint64_t z432 = lut3<MSJ_TT(~TA & ~TB & ~TC)>(b4, b3, b2);
+    const uint64_t w = lut3<MSJ_TT(TA & ~TB & ~TC)>(z432, b1, b5);
+    const uint64_t c0c1 = u.hi2 & w;
+    err = lut3<MSJ_TT(TA | TB | TC)>(err, f5ff, c0c1);
+    // the second byte of E0 / ED / F0 / F4, judged at the lead byte from the next byte's b5, b5 | b4
+    const uint64_t z210 = lut3<MSJ_TT(~TA & ~TB & ~TC)>(b2, b1, b0);       // xxxxx000: E0, F0
+    const uint64_t m10 = lut3<MSJ_TT(TA & ~TB)>(b2, b1, b1);               // xxxxx10x: ED (b0 = 1), F4 (b0 = 0)
+    const uint64_t t1 = lut3<MSJ_TT(TA & ~TB & ~TC)>(u.l3, b3, s.nb5);     // E0 (given z210) followed by 80..9F
+    const uint64_t t2 = lut3<MSJ_TT((TA & ~TB) | TC)>(u.lead4, s.nb54, t1); // ... or F0 followed by 80..8F
+    const uint64_t u1 = lut3<MSJ_TT(TA & TB & TC)>(u.l3, b3, s.nb5);       // ED (given m10, b0) followed by A0..BF
+    const uint64_t v1 = u.lead4 & s.nb54;                                  // F4 (given m10, ~b0) followed by 90..BF
+    const uint64_t sel = lut3<MSJ_TT((TC & TA) | (~TC & TB))>(u1, v1, b0);
+    const uint64_t lo_bad = z210 & t2;
+    *pair_bad = lut3<MSJ_TT(TA | (TB & TC))>(lo_bad, m10, sel);
+    return err;
+}
+
+// One block with the bytes around it given explicitly (host harness, CPU tests): carry word of the
+// bytes in front, b5 / b4 of the byte behind (0 / 0 at the end of the input: the pair is not judged, a
+// lead byte there is a truncated sequence and flagged as such).
+MSJ_HD uint64_t utf8_errors(const uint64_t p[8], const Utf8Leads &u, uint32_t carry_in, uint32_t next_b5,
+                            uint32_t next_b4, bool have_next) {
     const uint32_t c = carry_in;
     Utf8Shifted s;
     s.exp1 = shl_in<1>(u.lead234, c & 1u);
     s.exp2 = shl_in<2>(u.lead34, (c >> 1) & 3u);
     s.exp3 = shl_in<3>(u.lead4, (c >> 3) & 7u);
-    s.pE0 = shl_in<1>(u.isE0, (c >> 6) & 1u);
-    s.pED = shl_in<1>(u.isED, (c >> 7) & 1u);
-    s.pF0 = shl_in<1>(u.isF0, (c >> 8) & 1u);
-    s.pF4 = shl_in<1>(u.isF4, (c >> 9) & 1u);
-    return s;
-}
-
-// Error mask of one block.  Planes must already be masked with `valid` (bytes past the end
-// read as 0x00 = ASCII, so a sequence truncated at EOF shows up as a missing continuation).
-MSJ_HD uint64_t utf8_errors_shifted(const uint64_t p[8], const Utf8Planes &u, const Utf8Shifted &s) {
-    const uint64_t b0 = p[0], b1 = p[1], b2 = p[2], b3 = p[3];
-    const uint64_t b4 = p[4], b5 = p[5], b6 = p[6], b7 = p[7];
-    const uint64_t expected = lut3<MSJ_TT(TA | TB | TC)>(s.exp1, s.exp2, s.exp3);
-    // expected ^ continuation (10xxxxxx): a missing or a stray continuation byte
-    const uint64_t cont = lut3<MSJ_TT(TA & ~TB)>(b7, b6, b6);
-    uint64_t err = expected ^ cont;
-    const uint64_t hi2 = b7 & b6;
-    // F8..FF; C0, C1 (110 0000x)
-    const uint64_t bad5 = lut3<MSJ_TT(TA & TB & TC)>(lut3<MSJ_TT(TA & TB & TC)>(hi2, b5, b4), b3, b3);
-    const uint64_t z432 = lut3<MSJ_TT(~TA & ~TB & ~TC)>(b4, b3, b2);
-    const uint64_t c0c1 = lut3<MSJ_TT(TA & ~TB & TC)>(hi2, b5, lut3<MSJ_TT(TA & ~TB)>(z432, b1, b1));
-    err = lut3<MSJ_TT(TA | TB | TC)>(err, bad5, c0c1);
-    // F5..F7 (lead4 with low bits 101, 110, 111)
-    const uint64_t f567 = lut3<MSJ_TT(TA & (TB | TC))>(b2, b1, b0);
-    err = lut3<MSJ_TT(TA | (TB & TC))>(err, u.lead4, f567);
-    err = lut3<MSJ_TT(TA | (TB & ~TC))>(err, s.pE0, b5);                    // E0 80..9F  (overlong)
-    err = lut3<MSJ_TT(TA | (TB & TC))>(err, s.pED, b5);                     // ED A0..BF  (surrogates)
-    const uint64_t f0bad = lut3<MSJ_TT(TA & ~TB & ~TC)>(s.pF0, b5, b4);     // F0 80..8F  (overlong)
-    const uint64_t f4bad = lut3<MSJ_TT(TA & (TB | TC))>(s.pF4, b5, b4);     // F4 90..BF  (> U+10FFFF)
-    err = lut3<MSJ_TT(TA | TB | TC)>(err, f0bad, f4bad);
+    s.nb5 = (p[5] >> 1) | ((uint64_t)(next_b5 & 1u) << 63);
+    s.nb54 = ((p[5] | p[4]) >> 1) | ((uint64_t)((next_b5 | next_b4) & 1u) << 63);
+    const uint64_t pairmask = have_next ? ~0ull : ~(1ull << 63);
+    uint64_t bad2;
+    uint64_t err = utf8_errors_shifted(p, u, s, &bad2);
+    err |= bad2 & pairmask;
+    // the pair across the block's front edge
+    err |= utf8_boundary_error(c, (uint32_t)p[5] & 1u, (uint32_t)p[4] & 1u);
     return err;
-}
-
-// Same, given the previous block's carry word.
-MSJ_HD uint64_t utf8_errors(const uint64_t p[8], const Utf8Planes &u, uint32_t carry_in) {
-    return utf8_errors_shifted(p, u, utf8_shift(u, carry_in));
 }
 
 // ---------------------------------------------------------------------------

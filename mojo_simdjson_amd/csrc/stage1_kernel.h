@@ -17,6 +17,8 @@ constexpr uint32_t kTicketShards = 8;
 constexpr uint32_t kTicketStrideWords = 512;       // in 8-byte words
 constexpr uint32_t kDescOffset = kTicketShards * kTicketStrideWords;  // ws[kDescOffset..] = agg[], ragg[], rpre[]
 constexpr uint32_t kStageWords = 1024;             // per-wave LDS staging of indices (4 KiB) per round
+constexpr uint32_t kStageSlack = 64;               // words in front of and behind a staging slice: where the lane that straddles
+                                                   // the border between the two rounds of a dense tile writes the indices of the other round
 constexpr uint32_t kBatch = 2;                     // tiles per wave per ticket range
 constexpr uint32_t kDefer = 2;                     // a tile is emitted kDefer ranges after it was computed
 constexpr uint32_t kRange = kWaves * kBatch;       // tiles per ticket range = per range aggregate

@@ -97,6 +97,21 @@ __device__ __forceinline__ uint64_t wave_shl_in(uint64_t x, uint32_t first_low) 
     const uint32_t prev_hi = dpp_shift_up1(hi, first_low << (32 - K));
     return u64(__builtin_amdgcn_alignbit(lo, prev_hi, 32 - K), __builtin_amdgcn_alignbit(hi, lo, 32 - K));
 }
+// The same with zeros shifted into lane 0 (bound_ctrl: no register has to hold a value for it)
+template <int K>
+__device__ __forceinline__ uint64_t wave_shl_0(uint64_t x) {
+    const uint32_t lo = (uint32_t)x, hi = (uint32_t)(x >> 32);
+    const uint32_t prev_hi = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)hi, 0x138, 0xF, 0xF, true);  // wave_shr:1
+    return u64(__builtin_amdgcn_alignbit(lo, prev_hi, 32 - K), __builtin_amdgcn_alignbit(hi, lo, 32 - K));
+}
+
+// (x >> 1) of a 64-bit per-lane plane, with bit 0 of the NEXT lane's plane shifted in at the top
+// (the last lane: 0): the backward counterpart of wave_shl_in.  One DPP move, two v_alignbit_b32.
+__device__ __forceinline__ uint64_t wave_shr1_in(uint64_t x) {
+    const uint32_t lo = (uint32_t)x, hi = (uint32_t)(x >> 32);
+    const uint32_t next_lo = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)lo, 0x130, 0xF, 0xF, true);  // wave_shl:1, 0 into the last lane
+    return u64(__builtin_amdgcn_alignbit(hi, lo, 1), __builtin_amdgcn_alignbit(next_lo, hi, 1));
+}
 
 // A value every lane holds identically (loaded from one address): move it to an SGPR so
 // that everything derived from it is scalar code.
@@ -145,7 +160,7 @@ struct Shared {
     // resolver hand-off between its waves
     uint32_t rs_seq, rs_s, rs_cnt, rs_err, rs_u8, rs_poison;
     // per-wave index staging for coalesced stores
-    uint32_t stage[kWaves][kStageWords] __attribute__((aligned(16)));
+    uint32_t stage[kWaves][kStageSlack + kStageWords + kStageSlack] __attribute__((aligned(16)));
     // computed-but-not-yet-emitted tiles (two ranges deep), per wave and slot:
     // per lane T0|T1 masks and the packed exclusive count scan; per slot a few words
     uint4 pend_masks[kWaves][kPendSlots][64];
@@ -499,30 +514,50 @@ __device__ __forceinline__ Pending compute_tile(const KernelArgs &a, const uint3
     const uint64_t me1 = __ballot(e0 != cls.ctrl);
     MSJ_STAMP(tile, 4);
 
-    // ---- utf8
+    // ---- utf8 (lane_math.h: structure from lead planes moved forward, the four second-byte ranges judged at
+    //      the lead byte from the next byte's b5 / b5 | b4 moved backward: five cross-lane shifts)
     uint32_t tile_pend = 0;
     uint64_t mu8 = 0;
     if (!(a.flags & kFlagNoUtf8) && (tc.u8_in != 0u || nonascii != 0ull)) {
-        const Utf8Planes u8p = utf8_planes(p);
-        // the lead planes moved onto the bytes they constrain; across lanes by DPP, into lane 0
-        // from the carry word of the window bytes (lane_math.h: utf8_carry_out layout)
+        const uint32_t lane0_mask = lane == 0u ? ~0u : 0u;                // loop invariants of the caller's loop
+        const uint32_t last_pair_hi = lane == 63u ? 0x7FFFFFFFu : ~0u;
+        const Utf8Leads u8l = utf8_leads(p);
+        // forward: across lanes by DPP (zeros into lane 0); what the bytes in front of the tile ask of its first
+        // three bytes comes from the carry word of the window bytes -- one three-bit value, ORed into lane 0
         const uint32_t c = tc.u8_in;
         Utf8Shifted sh8;
-        sh8.exp1 = wave_shl_in<1>(u8p.lead234, c & 1u);
-        sh8.exp2 = wave_shl_in<2>(u8p.lead34, (c >> 1) & 3u);
-        sh8.exp3 = wave_shl_in<3>(u8p.lead4, (c >> 3) & 7u);
-        sh8.pE0 = wave_shl_in<1>(u8p.isE0, (c >> 6) & 1u);
-        sh8.pED = wave_shl_in<1>(u8p.isED, (c >> 7) & 1u);
-        sh8.pF0 = wave_shl_in<1>(u8p.isF0, (c >> 8) & 1u);
-        sh8.pF4 = wave_shl_in<1>(u8p.isF4, (c >> 9) & 1u);
-        uint64_t u8bad = utf8_errors_shifted(p, u8p, sh8);
-        // a character cut by the end of a NON-final shard continues in the next one (which checks it
-        // from its window bytes); only at the end of the stream is the missing continuation an error
-        if (partial && !(a.flags & kFlagFinal)) u8bad &= valid;
+        sh8.exp1 = wave_shl_0<1>(u8l.lead234);
+        sh8.exp2 = wave_shl_0<2>(u8l.lead34);
+        const uint64_t e3 = wave_shl_0<3>(u8l.lead4);
+        const uint32_t c_low3 = (c & 1u) | ((c >> 1) & 3u) | ((c >> 3) & 7u);  // scalar
+        sh8.exp3 = u64(lut3<MSJ_TT(TA | (TB & TC))>((uint32_t)e3, lane0_mask, c_low3), (uint32_t)(e3 >> 32));
+        // backward: the tile's last byte has no next byte here -- that pair is the next tile's (its window bytes)
+        sh8.nb5 = wave_shr1_in(p[5]);
+        sh8.nb54 = wave_shr1_in(p[5] | p[4]);
+        uint64_t bad2;
+        uint64_t u8bad = utf8_errors_shifted(p, u8l, sh8, &bad2);
+        if (!partial) {  // uniform
+            // every pair but (the tile's last byte, the next tile's first) is judged here
+            u8bad |= u64((uint32_t)bad2, (uint32_t)(bad2 >> 32) & last_pair_hi);
+        } else {
+            asm volatile("; partial tile" ::: "memory");  // a real branch: if-converted, its masks cost every tile four operations
+            // in a tile cut short by the end of the input the pair is judged only where the next byte is input too
+            // (at the end of the stream the lead byte is a truncated sequence anyway; at the end of a non-final
+            // shard the next shard judges the pair from its window)
+            u8bad |= bad2 & wave_shr1_in(valid);
+            // a character cut by the end of a NON-final shard continues in the next one (which checks it
+            // from its window bytes); only at the end of the stream is the missing continuation an error
+            if (!(a.flags & kFlagFinal)) u8bad &= valid;
+        }
         mu8 = __ballot(u8bad != 0ull);
+        // the pair (last byte in front of the tile, the tile's first byte): rare (that byte is E0 / ED / F0 / F4)
+        if (c >> 6) {  // uniform
+            const uint32_t f5 = bcast((uint32_t)p[5], 0), f4 = bcast((uint32_t)p[4], 0);
+            if (utf8_boundary_error(c, f5, f4)) mu8 |= 1ull;
+        }
         // a sequence still open at the end of the tile (the last lane's top lead bits)
-        tile_pend = ((bcast((uint32_t)(u8p.lead234 >> 32), 63) >> 31) | (bcast((uint32_t)(u8p.lead34 >> 32), 63) >> 30) |
-                     (bcast((uint32_t)(u8p.lead4 >> 32), 63) >> 29)) ? 1u : 0u;
+        tile_pend = ((bcast((uint32_t)(u8l.lead234 >> 32), 63) >> 31) | (bcast((uint32_t)(u8l.lead34 >> 32), 63) >> 30) |
+                     (bcast((uint32_t)(u8l.lead4 >> 32), 63) >> 29)) ? 1u : 0u;
     }
     MSJ_STAMP(tile, 5);
     MSJ_STAMP(tile, 6);
@@ -540,7 +575,7 @@ __device__ __forceinline__ Pending compute_tile(const KernelArgs &a, const uint3
 //      output (LDS only), emit_store() turns them into aligned 16-byte
 //      stores (one L2 request per 64 B instead of one per index).  Wave-local: no barrier.
 // Everything that decides HOW a tile is emitted is wave-uniform and lives in scalar registers.
-enum : uint32_t { kEmitNone = 0, kEmitStaged, kEmitDense, kEmitGeneral };
+enum : uint32_t { kEmitNone = 0, kEmitStaged, kEmitStaged2, kEmitDense, kEmitGeneral };
 struct EmitU {
     uint32_t mode;
     uint32_t tile;
@@ -585,8 +620,11 @@ __device__ __forceinline__ EmitU emit_prepare(const KernelArgs &a, const Shared 
         e.mode = kEmitGeneral;  // the output buffer has no room for all of the tile's indices
     else if (e.vend <= kStageWords)
         e.mode = kEmitStaged;   // per-lane chains into the staging slice, 16-byte stores (up to 1020 indices: the common case)
+    else if (e.vend <= 2u * kStageWords + 3u)
+        e.mode = kEmitStaged2;  // up to half of the tile's bytes: the same in two rounds of the slice (the second round's
+                                // copy-out moves kStageWords / 4 full quads and up to three more elements)
     else
-        e.mode = kEmitDense;    // more than a quarter of the tile's bytes: block by block, straight to the output
+        e.mode = kEmitDense;    // more: block by block, straight to the output
     e.mode = uniform32(e.mode);
     return e;
 }
@@ -644,6 +682,7 @@ __device__ __forceinline__ void copy_out(const KernelArgs &a, const EmitU &e, co
     }
 }
 
+__device__ __forceinline__ uint32_t lane64_of(const uint32_t lane) { return lane * 64u; }
 __device__ __forceinline__ void lds_wave_sync() {
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -746,17 +785,60 @@ __device__ __forceinline__ uint64_t range_prefix(const KernelArgs &a, const uint
 
 // The two halves of one parked tile's emission: LDS-only staging (the one-round cases), then
 // everything that stores to global memory (copy-out, or the multi-round / clipped paths).
-__device__ __forceinline__ void emit_stage(const Shared &sh, const EmitU &e, const uint32_t wave, const uint32_t slot,
+// Two rounds of the staging slice for a tile with 1 021 .. 2 048 indices (a quarter to a half of its bytes:
+// BitIndexer.write, json_structural_indexer.mojo:46-58, at the density of `[123,123,...`).  Round 0 is the lanes
+// whose first slot lies in the slice's first kStageWords, round 1 the lanes whose last slot lies beyond them; the one
+// lane that straddles the border runs its chain in both rounds and writes the other round's part into the slack
+// words behind (round 0) or in front of (round 1) the slice, which nobody copies out.
+__device__ __forceinline__ void stage_indices_round(const EmitU &e, EmitV v, uint32_t *stage, const uint32_t lane64,
+                                                    const uint32_t round) {
+    const uint32_t n = (uint32_t)__builtin_popcount(v.tlo) + (uint32_t)__builtin_popcount(v.thi);
+    const bool mine = round == 0u ? v.vpos < kStageWords : v.vpos + n > kStageWords;
+    if (!mine) v.tlo = v.thi = 0u;
+    stage_indices(e, v, stage - round * kStageWords, lane64);
+}
+// what copy_out moves in a round: round 0 slots [shift, kStageWords), round 1 slots [kStageWords, vend) from the slice's start
+__device__ __forceinline__ EmitU emit_round(const EmitU &e, const uint32_t round) {
+    EmitU r = e;
+    if (round == 0u) {
+        r.vend = kStageWords;
+    } else {
+        r.base = e.base - e.shift + kStageWords;  // 16-byte aligned like base - shift
+        r.shift = 0u;
+        r.vend = e.vend - kStageWords;
+    }
+    return r;
+}
+
+__device__ __forceinline__ void emit_stage(const Shared &sh, EmitU &e, const uint32_t wave, const uint32_t slot,
                                            uint32_t *stage, const uint32_t lane, const uint32_t lane64) {
     if (e.mode == kEmitStaged) {  // uniform
         const EmitV v = emit_lane(sh, wave, slot, lane, e);
         stage_indices(e, v, stage, lane64);
+    } else if (e.mode == kEmitStaged2) {
+        const EmitV v = emit_lane(sh, wave, slot, lane, e);
+        // A tile whose blocks all hold the same number of indices, a multiple of 32 (`[123,123,...`: 32 per block),
+        // puts every lane's k-th write on the same LDS bank: measured 1.03 ms per GiB against 0.68 for the block-wise
+        // emission.  More than half of the lanes on one bank: leave the tile to emit_dense.
+        const uint64_t same = __ballot(((v.vpos ^ bcast(v.vpos, 0)) & 31u) == 0u);
+        if (__popcll(same) > 32) {  // uniform
+            e.mode = kEmitDense;
+            return;
+        }
+        stage_indices_round(e, v, stage, lane64, 0u);
     }
 }
 __device__ __forceinline__ void emit_store(const KernelArgs &a, const Shared &sh, const EmitU &e, const uint32_t wave,
                                            const uint32_t slot, uint32_t *stage, const uint32_t lane) {
     if (e.mode == kEmitStaged) {  // uniform
         copy_out(a, e, stage, lane);
+    } else if (e.mode == kEmitStaged2) {
+        copy_out(a, emit_round(e, 0u), stage, lane);
+        lds_wave_sync();  // the slice is reused by the second round
+        const EmitV v = emit_lane(sh, wave, slot, lane, e);
+        stage_indices_round(e, v, stage, lane64_of(lane), 1u);
+        lds_wave_sync();
+        copy_out(a, emit_round(e, 1u), stage, lane);
     } else if (e.mode == kEmitDense) {
         const EmitV v = emit_lane(sh, wave, slot, lane, e);
         emit_dense(a.idx, e.tile_base, e.base, v.tlo, v.thi, v.vpos - e.shift, lane);
@@ -808,7 +890,7 @@ __device__ __forceinline__ void worker_wave(const KernelArgs &a, Shared &sh, con
     const uint32_t shards = workers < kTicketShards ? workers : kTicketShards;
     const uint32_t shard = uniform32(sh.shard);
     unsigned int *ticket_ctr = reinterpret_cast<unsigned int *>(a.ws + (uint64_t)shard * kTicketStrideWords);
-    uint32_t *stage = sh.stage[wave];
+    uint32_t *stage = sh.stage[wave] + kStageSlack;
     const uint32_t tid = threadIdx.x;
     const uint32_t lane64 = lane * 64u;  // loop invariants in vector registers
     const uint32_t lane_off[4] = {lane64, lane64 + 16u, lane64 + 32u, lane64 + 48u};
@@ -969,14 +1051,14 @@ __device__ __forceinline__ void worker_wave(const KernelArgs &a, Shared &sh, con
         MSJ_STAMP(srow, 12);  // next range known, its loads issued, the old range's prefix in hand
         static_assert(kBatch == 2, "the emission below is written for two tiles per wave and range");
         const uint32_t slot0 = ring * kBatch;
-        const EmitU e0 = emit_prepare(a, sh, wave, slot0, rp, count0, timeout);
+        EmitU e0 = emit_prepare(a, sh, wave, slot0, rp, count0, timeout);
         emit_stage(sh, e0, wave, slot0, stage, lane, lane64);
         lds_wave_sync();
         MSJ_STAMP(srow, 13);  // tile A staged
         emit_store(a, sh, e0, wave, slot0, stage, lane);
         lds_wave_sync();  // the staging slice is reused by the next tile
         MSJ_STAMP(srow, 14);  // tile A stored
-        const EmitU e1 = emit_prepare(a, sh, wave, slot0 + 1u, rp, count0, timeout);
+        EmitU e1 = emit_prepare(a, sh, wave, slot0 + 1u, rp, count0, timeout);
         emit_stage(sh, e1, wave, slot0 + 1u, stage, lane, lane64);
         lds_wave_sync();
         MSJ_STAMP(srow, 15);  // tile B staged
@@ -1014,7 +1096,7 @@ __device__ __forceinline__ void worker_wave(const KernelArgs &a, Shared &sh, con
 #pragma unroll
             for (uint32_t j = 0; j < kBatch; j++) {
                 const uint32_t slot = ring * kBatch + j;
-                const EmitU e = emit_prepare(a, sh, wave, slot, w, count0, timeout);
+                EmitU e = emit_prepare(a, sh, wave, slot, w, count0, timeout);
                 emit_stage(sh, e, wave, slot, stage, lane, lane64);
                 lds_wave_sync();
                 emit_store(a, sh, e, wave, slot, stage, lane);
@@ -1445,8 +1527,8 @@ __global__ __launch_bounds__(kThreads) void twopass_emit_kernel(const KernelArgs
     sh.pend_excl[wave][0][lane] = r.excl;
     if (lane == 0) *reinterpret_cast<uint4 *>(sh.pend_meta[wave][0]) = make_uint4(tile, r.tile_cnt, 0u, s_in | (s_in << 1));
     lds_wave_sync();
-    uint32_t *stage = sh.stage[wave];
-    const EmitU e = emit_prepare(a, sh, wave, 0, kPre | (uint64_t)(uint32_t)pw, count0, timeout);
+    uint32_t *stage = sh.stage[wave] + kStageSlack;
+    EmitU e = emit_prepare(a, sh, wave, 0, kPre | (uint64_t)(uint32_t)pw, count0, timeout);
     emit_stage(sh, e, wave, 0, stage, lane, lane64);
     lds_wave_sync();
     emit_store(a, sh, e, wave, 0, stage, lane);

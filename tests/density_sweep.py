@@ -28,6 +28,11 @@ CASES = [("spaces + one scalar", lambda: synth.extreme(UNIT, 3)), ("one giant st
 
 
 def main():
+    if len(sys.argv) > 1:  # A/B of kernel builds: tests/density_sweep.py path/to/libmsj_stage1.so
+        from mojo_simdjson_amd import _lib
+
+        _lib.LIB_PATH = os.path.abspath(sys.argv[1])
+        print("library:", _lib.LIB_PATH)
     oracle = helpers.load_oracle()
     dev = Stage1Device(0)
     torch.cuda.set_device(0)

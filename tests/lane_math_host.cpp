@@ -34,9 +34,12 @@ int32_t lane_stage1(const uint8_t *buf, uint64_t len, uint32_t *idx, uint64_t ca
         uint64_t p[8];
         msj::bitplanes(x, p);
         for (int k = 0; k < 8; k++) p[k] &= valid;
-        msj::Utf8Planes u = msj::utf8_planes(p);
-        u8err |= msj::utf8_errors(p, u, ucarry);
-        ucarry = msj::utf8_carry_out(u);
+        msj::Utf8Leads u = msj::utf8_leads(p);
+        // the byte behind the block (the kernel's lanes see it through a backward cross-lane shift)
+        const bool have_next = off + 64 < len;
+        const uint32_t nb = have_next ? buf[off + 64] : 0u;
+        u8err |= msj::utf8_errors(p, u, ucarry, nb >> 5, nb >> 4, have_next);
+        ucarry = msj::utf8_carry_out(p, u);
     }
     if (len % 64 == 0 && (ucarry & 0x3F)) u8err |= 1;  // sequence truncated exactly at EOF
     *utf8_out = u8err ? 11 : 0;

@@ -128,3 +128,32 @@ def test_utf8_text_and_truncations(lane, oracle):
         k = rng.randint(1, len(s))
         d = s[:k]
         assert run_lane(lane, d)[3] == oracle.msj_oracle_utf8(d, len(d)), d
+
+
+def test_utf8_every_pair_at_every_block_position(lane, oracle):
+    """The second-byte rules (E0 / ED / F0 / F4) are judged at the LEAD byte from the next byte's bits, the structure
+    from lead planes moved forward: every (lead, second) pair and every 3- / 4-byte shape with its second byte at the
+    extremes, placed so that each of its bytes in turn is the first byte of a 64-byte block, the last one, or the last
+    byte of the input -- against the oracle's validator (itself pinned to CPython's strict decoder)."""
+    seqs = []
+    for a in range(0x80, 0x100):
+        for b in (0x00, 0x41, 0x7F, 0x80, 0x8F, 0x90, 0x9F, 0xA0, 0xBF, 0xC0, 0xC2, 0xE0, 0xED, 0xF0, 0xF4, 0xFF):
+            seqs.append(bytes([a, b]))
+            seqs.append(bytes([a, b, 0x80]))
+            seqs.append(bytes([a, b, 0xBF, 0x80]))
+            seqs.append(bytes([a, b, 0x80, 0x41]))
+    for a in (0xE0, 0xE1, 0xEC, 0xED, 0xEE, 0xEF, 0xF0, 0xF1, 0xF3, 0xF4, 0xF5):
+        for b in range(0x70, 0xD0):
+            seqs += [bytes([a, b, 0x80, 0x80]), bytes([a, b, 0x80]), bytes([a, b])]
+    bad = 0
+    for s in seqs:
+        for start in (61, 62, 63, 64, 127, 0):
+            d = b"a" * start + s + b"bc"
+            for cut in {len(d), start + len(s), start + len(s) - 1, start + 1}:
+                dd = d[:cut]
+                want = oracle.msj_oracle_utf8(dd, len(dd))
+                got = run_lane(lane, dd)[3]
+                if got != want:
+                    bad += 1
+                    assert bad < 5, (s.hex(), start, cut, got, want)
+    assert bad == 0

@@ -227,6 +227,34 @@ def test_workload_units_device_path(torch_mod, dev, oracle, name):
     assert int(d_idx[n + 3].item()) == -1  # nothing written past the trailer
 
 
+def test_dense_tiles_around_the_emission_limits(oracle):
+    """BitIndexer.write (json_structural_indexer.mojo:46-58) where the emission changes its form: up to 1 020 indices
+    per 4 KiB tile are staged in one round, up to 2 051 in two rounds of the staging slice (the lane that straddles
+    the border writes in both), more go block by block.  Periodic documents with 1 024 and 2 048 structurals per tile,
+    shifted by 0..12 leading brackets so that the tile counts and the alignment of the output (count mod 4) take every
+    value around the limits; tiles whose blocks all hold the same multiple of 32 indices (all lanes on one LDS bank:
+    left to the block-wise form); random soups between the densities."""
+    import random
+
+    for unit in (b"1234567,", b"123,", b"1234,", b"12,", b"[1,", b'"a",12,'):
+        body = unit * ((5 * TILE) // len(unit))
+        for pre in range(0, 13):
+            assert_matches_oracle(oracle, b"[" * pre + body + b"1" + b"]" * pre, f"{unit!r} pre {pre}")
+    rng = random.Random(31)
+    for k in range(40):
+        dens = rng.choice((0.22, 0.26, 0.3, 0.4, 0.45, 0.5, 0.55))
+        n = rng.choice((3 * TILE + 7, 5 * TILE - 1))
+        d = bytearray(rng.choice(b"123456789") for _ in range(n))
+        for i in range(n):
+            if rng.random() < dens / 2:
+                d[i] = 0x2C  # a comma and (usually) the scalar behind it: two structurals
+        # stretches of other densities inside the same tile: the lanes' counts differ widely
+        for _ in range(6):
+            a = rng.randrange(0, n - 600)
+            d[a:a + 512] = rng.choice((b" " * 512, b"[" * 512, b"1,[" * 170 + b"  "))
+        assert_matches_oracle(oracle, b"[" + bytes(d) + b"]", f"soup {k} density {dens}")
+
+
 def test_capacity_clip(torch_mod, dev, oracle):
     torch = torch_mod
     from mojo_simdjson_amd import synth
