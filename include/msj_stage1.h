@@ -238,6 +238,11 @@ typedef struct msj_shard_report {
  * characters and the letters of true / false / null), else the neighbours of the first unescaped quote decide. */
 int32_t msj_shard_speculate(const uint8_t *halo, uint64_t halo_len, const uint8_t *head, uint64_t head_len,
                             msj_carry *out);
+/* The same; *decided_out (optional) = 1 when one hypothesis was contradicted by the head (or there is no halo: the
+ * start of the stream), 0 when the in_string guess rests on the quote-neighbour rule or on nothing at all -- a caller
+ * with more bytes at hand then asks again with a longer head (msj_stage1_sharded_submit does: 4 KiB, 64 KiB, 1 MiB). */
+int32_t msj_shard_speculate_ex(const uint8_t *halo, uint64_t halo_len, const uint8_t *head, uint64_t head_len,
+                               msj_carry *out, int32_t *decided_out);
 /* Replays the chain of all ranks' reports.  exact_in[g] (world entries) receives the exact carry at the start of
  * shard g for every g < return value -- in_string / next_is_escaped / prev_scalar, and the STITCHED OFFSETS:
  * exact_in[g].count = structurals of the stream in front of shard g (the position of its first index in the

@@ -176,8 +176,14 @@ static void halo_state(const uint8_t *halo, uint64_t n, uint32_t *e, uint32_t *p
 
 int32_t msj_shard_speculate(const uint8_t *halo, uint64_t halo_len, const uint8_t *head, uint64_t head_len,
                             msj_carry *out) {
+    return msj_shard_speculate_ex(halo, halo_len, head, head_len, out, nullptr);
+}
+
+int32_t msj_shard_speculate_ex(const uint8_t *halo, uint64_t halo_len, const uint8_t *head, uint64_t head_len,
+                               msj_carry *out, int32_t *decided_out) {
     if (!out || (halo_len && !halo) || (head_len && !head)) return MSJ_ERR_BAD_ARGUMENT;
     std::memset(out, 0, sizeof *out);
+    if (decided_out) *decided_out = 1;
     if (halo_len == 0) return MSJ_SUCCESS;  // start of the stream: the all-zero state
     uint32_t e, ps;
     int decided;
@@ -215,7 +221,9 @@ int32_t msj_shard_speculate(const uint8_t *halo, uint64_t halo_len, const uint8_
         }
     }
     // second try: the first unescaped quote of the shard opens a string if one of `: , [ {` precedes it,
-    // closes one if one of `: , ] }` follows it (blanks skipped).
+    // closes one if one of `: , ] }` follows it (blanks skipped).  Nothing in the head contradicted either
+    // hypothesis: the caller may want to look at more bytes before it relies on this.
+    if (decided_out) *decided_out = 0;
     uint32_t esc = e;
     int64_t q = -1;
     for (uint64_t i = 0; i < head_len; i++) {
@@ -441,13 +449,29 @@ int32_t msj_stage1_sharded_submit(msj_sharded *sh, const uint8_t *d_shard, uint6
     } else if (!has_prefix) {
         std::memset(sl.h_spec, 0, sizeof(msj_carry));
     } else {
-        // from the shard's own bytes: the 64 stream bytes in front of it and its first <= 4 KiB
-        uint8_t ctx_bytes[64 + 4096];
-        const uint64_t head = shard_len < 4096 ? shard_len : 4096;
-        int32_t rc = o.copy(o.user, ctx_bytes, d_shard - 64, 64 + head, 1, stream);
-        if (rc == MSJ_SUCCESS) rc = o.sync(o.user, stream);
-        if (rc != MSJ_SUCCESS) return rc;
-        rc = msj_shard_speculate(ctx_bytes, 64, ctx_bytes + 64, head, sl.h_spec);
+        // from the shard's own bytes: the 64 stream bytes in front of it and its first 4 KiB -- or, while those
+        // contradict neither hypothesis (strings made of digits, blanks or the letters of the literals), its first
+        // 64 KiB, then its first MiB: a refuted guess costs the whole shard a second launch, a longer look one more
+        // small read, once per placed shard
+        static const uint64_t kHeads[] = {4096, 65536, 1048576};
+        uint8_t small[64 + 4096];
+        uint8_t *big = nullptr;
+        int32_t rc = MSJ_SUCCESS;
+        for (const uint64_t want : kHeads) {
+            const uint64_t head = shard_len < want ? shard_len : want;
+            uint8_t *ctx_bytes = small;
+            if (head > 4096) {
+                if (!big) big = new (std::nothrow) uint8_t[64 + kHeads[2]];
+                if (!big) break;  // keep the guess from the shorter head
+                ctx_bytes = big;
+            }
+            rc = o.copy(o.user, ctx_bytes, d_shard - 64, 64 + head, 1, stream);
+            if (rc == MSJ_SUCCESS) rc = o.sync(o.user, stream);
+            int32_t decided = 0;
+            if (rc == MSJ_SUCCESS) rc = msj_shard_speculate_ex(ctx_bytes, 64, ctx_bytes + 64, head, sl.h_spec, &decided);
+            if (rc != MSJ_SUCCESS || decided || head == shard_len) break;
+        }
+        delete[] big;
         if (rc != MSJ_SUCCESS) return rc;
     }
     sl.d_shard = d_shard;

@@ -320,6 +320,20 @@ int main(int argc, char **argv) {
     }
     CHECK(g_reruns > 0 && g_clipped > 0, "the re-run loop and the capacity flag were exercised (%llu, %llu)", (unsigned long long)g_reruns,
           (unsigned long long)g_clipped);
+    {  // shards whose first 4 KiB (and first 64 KiB) decide nothing: the library reads a longer head, never past the shard
+        std::string d = "[\"";
+        for (int i = 0; i < 30000; i++) d += "1 2 3 ";
+        d += "x\",7,\"";
+        for (int i = 0; i < 3000; i++) d += "4 5 ";
+        d += "\"]";
+        const uint64_t n = d.size();
+        const uint64_t before = g_reruns;
+        protocol_case(rng, d, {0, 80, n}, -1);
+        protocol_case(rng, d, {0, 80, n - 5000, n}, -1);       // the last shard starts inside the second string, 5 000 bytes long
+        protocol_case(rng, d, {0, n - 70000, n - 66, n}, -1);  // a 66-byte shard behind a 70 KB one
+        (void)before;
+        cases += 3;
+    }
     std::printf("sanitize_host ok: seed %llu, %d fuzz documents (%zu bytes) through the oracle and the lane math, %d sharded streams "
                 "(%llu refuted speculations repaired, %llu with an index buffer too small)\n",
                 (unsigned long long)seed, rounds * 10, bytes, cases, (unsigned long long)g_reruns, (unsigned long long)g_clipped);

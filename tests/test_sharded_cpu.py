@@ -79,6 +79,17 @@ def test_speculate_matches_serial():
     assert sharded.speculate_bytes(b"", b'"abc') == (0, 0, 0)
     assert sharded.speculate_bytes(b'["a', b'b",1]')[1:] == (0, 1)
     assert sharded.speculate_bytes(b"\\" * 64, b'"x')[1:] == (0, 1)  # any guess: the chain check settles it
+    # msj_shard_speculate_ex says whether a hypothesis was contradicted (else the caller may look at more bytes)
+    L = sharded.lib()
+    L.msj_shard_speculate_ex.restype = ctypes.c_int32
+    L.msj_shard_speculate_ex.argtypes = [ctypes.c_char_p, ctypes.c_uint64, ctypes.c_char_p, ctypes.c_uint64, ctypes.POINTER(MsjCarry),
+                                         ctypes.POINTER(ctypes.c_int32)]
+    for head, want in ((b"1 2 3 4 5", 0), (b"1 2 3 x", 1), (b'abc",1]', 1), (b"\n 12", 1), (b"", 0)):
+        c, d = MsjCarry(), ctypes.c_int32(-1)
+        assert L.msj_shard_speculate_ex(b'{"k":"' + b"1" * 58, 64, head, len(head), ctypes.byref(c), ctypes.byref(d)) == 0
+        assert d.value == want, (head, d.value)
+    c, d = MsjCarry(), ctypes.c_int32(-1)
+    assert L.msj_shard_speculate_ex(b"", 0, b"xyz", 3, ctypes.byref(c), ctypes.byref(d)) == 0 and d.value == 1  # start of the stream
     rng = random.Random(9)
     alpha = b'\\\\\\""a1 ,:[]{}\n'
     for _ in range(2000):
@@ -328,6 +339,11 @@ def test_gloo_world2_live_protocol():
     # unclosed string / control character inside a string on rank 1
     cases.append((b'[1,2,"abc' + b" " * 80 + b'"x', [0, 50, 92]))
     cases.append((b'["' + b"s" * 70 + b"\n" + b's"]', [0, 30, 76]))
+    # a cut inside a 12 KB string of digits and blanks: the shard's first 4 KiB contradict neither hypothesis (and hold no
+    # quote for the neighbour rule), so the library looks at its first 64 KiB before it guesses -- no second launch
+    longstr = b'["' + b"1 2 3 " * 2000 + b'x",7]'
+    long_case = len(cases)
+    cases.append((longstr, [0, 80, len(longstr)]))
     # an index buffer that is too small on ONE rank (a non-last rank used to clip silently and the
     # stream still came back as SUCCESS): the whole stream reports CAPACITY, whichever rank it is
     dense = b"[" * 100 + b"1" + b"]" * 100
@@ -363,6 +379,8 @@ def test_gloo_world2_live_protocol():
         e, s, ps = serial_state(data[:cuts[1]])
         assert r1[3] == (e, s, ps) and r0[3] == (0, 0, 0)
         assert r0[4] == 1 and r1[4] in (1, 2)  # rank 0 never launches twice
+        if k == long_case:
+            assert r1[4] == 1 and r1[3] == (0, 1, 0), r1[3:5]  # the longer look got it right: one launch
         total_reruns += r1[4] - 1
         if want_code in (0, 13):
             assert r1[5] == [len(data), len(data), 0]
