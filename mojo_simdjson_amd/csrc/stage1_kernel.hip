@@ -651,7 +651,7 @@ __device__ __forceinline__ void stage_indices(const EmitU &e, const EmitV &v, ui
 }
 
 __device__ __forceinline__ void copy_out(const KernelArgs &a, const EmitU &e, const uint32_t *stage,
-                                         const uint32_t lane) {
+                                         const uint32_t lane, const uint32_t lane_p) {
     // uniform 64-bit base + 32-bit lane offsets; full 16-byte quads in the body, the (at
     // most two) partial quads at the ends element by element
     uint8_t *out = reinterpret_cast<uint8_t *>(a.idx + (e.base - e.shift));  // out[4v] <-> stage[v]; 16-byte aligned
@@ -667,15 +667,15 @@ __device__ __forceinline__ void copy_out(const KernelArgs &a, const EmitU &e, co
         if (q_lo + 64u * (k + 1u) <= q_hi) {  // uniform: a full round, every lane stores
             *reinterpret_cast<uint4 *>(out + off + 1024u * k) = *reinterpret_cast<const uint4 *>(src + off + 1024u * k);
         } else {  // the last round: the first (q_hi - q_lo - 64k) lanes
-            if (lane < q_hi - q_lo - 64u * k)
+            if (lane_p < q_hi - q_lo - 64u * k)
                 *reinterpret_cast<uint4 *>(out + off + 1024u * k) = *reinterpret_cast<const uint4 *>(src + off + 1024u * k);
             break;
         }
     }
     // head (elements shift .. 4*q_lo) and tail (4*q_hi .. vend): < 8 elements in total, one
     // element per lane of the first eight
-    if (lane < 8u) {
-        const bool head = lane < 4u;
+    if (lane_p < 8u) {
+        const bool head = lane_p < 4u;
         const uint32_t v = head ? lane : 4u * q_hi + (lane - 4u);
         const bool ok = head ? (v >= e.shift && v < 4u * q_lo && v < e.vend) : (v < e.vend && v >= 4u * q_lo);
         if (ok) *reinterpret_cast<uint32_t *>(out + 4u * v) = *reinterpret_cast<const uint32_t *>(src + 4u * v);
@@ -829,16 +829,16 @@ __device__ __forceinline__ void emit_stage(const Shared &sh, EmitU &e, const uin
     }
 }
 __device__ __forceinline__ void emit_store(const KernelArgs &a, const Shared &sh, const EmitU &e, const uint32_t wave,
-                                           const uint32_t slot, uint32_t *stage, const uint32_t lane) {
+                                           const uint32_t slot, uint32_t *stage, const uint32_t lane, const uint32_t lane_p) {
     if (e.mode == kEmitStaged) {  // uniform
-        copy_out(a, e, stage, lane);
+        copy_out(a, e, stage, lane, lane_p);
     } else if (e.mode == kEmitStaged2) {
-        copy_out(a, emit_round(e, 0u), stage, lane);
+        copy_out(a, emit_round(e, 0u), stage, lane, lane_p);
         lds_wave_sync();  // the slice is reused by the second round
         const EmitV v = emit_lane(sh, wave, slot, lane, e);
         stage_indices_round(e, v, stage, lane64_of(lane), 1u);
         lds_wave_sync();
-        copy_out(a, emit_round(e, 1u), stage, lane);
+        copy_out(a, emit_round(e, 1u), stage, lane, lane_p);
     } else if (e.mode == kEmitDense) {
         const EmitV v = emit_lane(sh, wave, slot, lane, e);
         emit_dense(a.idx, e.tile_base, e.base, v.tlo, v.thi, v.vpos - e.shift, lane);
@@ -889,9 +889,9 @@ __device__ __forceinline__ void worker_wave(const KernelArgs &a, Shared &sh, con
     const uint32_t workers = gridDim.x - 1u;
     const uint32_t shards = workers < kTicketShards ? workers : kTicketShards;
     const uint32_t shard = uniform32(sh.shard);
-    unsigned int *ticket_ctr = reinterpret_cast<unsigned int *>(a.ws + (uint64_t)shard * kTicketStrideWords);
     uint32_t *stage = sh.stage[wave] + kStageSlack;
     const uint32_t tid = threadIdx.x;
+    (void)tid;  // the diagnostic builds' stamps
     const uint32_t lane64 = lane * 64u;  // loop invariants in vector registers
     const uint32_t lane_off[4] = {lane64, lane64 + 16u, lane64 + 32u, lane64 + 48u};
     const uint32_t ntiles = a.ntiles;
@@ -914,6 +914,18 @@ __device__ __forceinline__ void worker_wave(const KernelArgs &a, Shared &sh, con
 
     uint32_t r = 0, ring = 0;  // ring = r % kDefer: the slots to emit from, then to park in
     while (lo_cur < ntiles) {  // uniform across the workgroup
+        // Predicates on the lane / wave index and tests of the launch's flags are recomputed where they are used (one
+        // compare each) instead of living in scalar register pairs across the whole loop: the loop holds more uniform
+        // values than there are scalar registers, and every pair kept costs two v_readlane per use once it is spilled.
+        uint32_t lane_p = lane, wave_p = wave;
+        asm volatile("" : "+v"(lane_p));
+        asm volatile("" : "+s"(wave_p));
+        KernelArgs al = a;
+        asm volatile("" : "+s"(al.flags));
+        const uint32_t tid_p = wave_p * 64u + lane_p;
+        uint32_t carry0_p = carry0, shard_p = shard;  // the same for values the loop only takes bits or addresses from
+        asm volatile("" : "+s"(carry0_p), "+s"(shard_p));
+        unsigned int *ticket_ctr_p = reinterpret_cast<unsigned int *>(al.ws + (uint64_t)shard_p * kTicketStrideWords);
         const uint32_t par = r & 1u;
         // prefix of the range parked in this ring position (published long ago, normally)
         const uint32_t old_first = uniform32(sh.pend_meta[wave][ring * kBatch][0]);  // its first tile of this wave
@@ -934,16 +946,16 @@ __device__ __forceinline__ void worker_wave(const KernelArgs &a, Shared &sh, con
             now[j].T1 = 0;
             now[j].excl = 0;
             now[j].tile_cnt = 0;
-            if (valid_tile) now[j] = compute_tile(a, t_cur, lane, blk[j], carry0, timeout, agg_word);
+            if (valid_tile) now[j] = compute_tile(al, t_cur, lane, blk[j], carry0_p, timeout, agg_word);
             if (j == 0) {
                 // the prefix word requested above has arrived (nothing younger is in flight yet) ...
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 touch_u64(rp_word);
                 // ... and the next range's ticket is drawn: one compute + one staging phase
                 // ahead of its use, which covers the atomic's round trip
-                if (tid == 0) req_reg = ticket_request(ticket_ctr, 0u, 1u);
+                if (tid_p == 0) req_reg = ticket_request(ticket_ctr_p, 0u, 1u);
             }
-            if (lane == 0) {
+            if (lane_p == 0) {
                 if (valid_tile) st_desc(&a.ws[kDescOffset + t_cur], agg_word);  // carries for t_cur + 1
                 sh.tagg[par][kWaves * j + wave] = agg_word;
             }
@@ -957,10 +969,10 @@ __device__ __forceinline__ void worker_wave(const KernelArgs &a, Shared &sh, con
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
         MSJ_STAMP(srow, 9);   // barrier passed
         // wave 0 passes the next range's ticket on (drawn a compute phase ago) ...
-        if (wave == 0) {
+        if (wave_p == 0) {
             const uint32_t v = ticket_value(req_reg);
-            if (lane == 0)
-                __hip_atomic_store(&sh.handoff, ((uint64_t)(r + 1u) << 32) | (uint64_t)(ticket_range(v, shard, shards) * kRange),
+            if (lane_p == 0)
+                __hip_atomic_store(&sh.handoff, ((uint64_t)(r + 1u) << 32) | (uint64_t)(ticket_range(v, shard_p, shards) * kRange),
                                    __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         }
         // ---- 2. fold the range's kRange tile aggregates in tile order -> the range aggregate
@@ -999,7 +1011,7 @@ __device__ __forceinline__ void worker_wave(const KernelArgs &a, Shared &sh, con
                 const uint32_t sk = (uint32_t)__builtin_popcount(P8 & ((1u << k) - 1u)) & 1u;
                 in_state[j] = sk | ((sk ^ 1u) << 1);
             }
-            if (tid == 0) {
+            if (tid_p == 0) {
                 const uint32_t tot = bcast(inc, (int)kRange - 1);
                 const uint32_t s_out = (uint32_t)__builtin_popcount(P8) & 1u;
                 st_desc(&ragg[lo_cur / kRange], kAgg | ((uint64_t)s_out << 61) | ((uint64_t)e0s << 60) |
@@ -1008,15 +1020,15 @@ __device__ __forceinline__ void worker_wave(const KernelArgs &a, Shared &sh, con
                                                     (uint64_t)(tot & 0xFFFFu));
             }
         }
-        if (a.ws_clean && wave == kWaves - 1) {  // uniform
+        if (a.ws_clean && wave_p == kWaves - 1) {  // uniform
             // double-buffered workspace: zero, in the buffer the NEXT launch will use, exactly
             // the words this range dirtied in the previous launch (same ntiles, same layout)
             const uint32_t rid = lo_cur / kRange;
-            if (lane < kRange) {
+            if (lane_p < kRange) {
                 if (lo_cur + lane < ntiles) a.ws_clean[kDescOffset + lo_cur + lane] = 0ull;
-            } else if (lane == kRange) {
+            } else if (lane_p == kRange) {
                 a.ws_clean[kDescOffset + ntiles + rid] = 0ull;
-            } else if (lane == kRange + 1u) {
+            } else if (lane_p == kRange + 1u) {
                 a.ws_clean[kDescOffset + ntiles + nranges + rid] = 0ull;
             }
         }
@@ -1051,14 +1063,14 @@ __device__ __forceinline__ void worker_wave(const KernelArgs &a, Shared &sh, con
         MSJ_STAMP(srow, 12);  // next range known, its loads issued, the old range's prefix in hand
         static_assert(kBatch == 2, "the emission below is written for two tiles per wave and range");
         const uint32_t slot0 = ring * kBatch;
-        EmitU e0 = emit_prepare(a, sh, wave, slot0, rp, count0, timeout);
+        EmitU e0 = emit_prepare(al, sh, wave, slot0, rp, count0, timeout);
         emit_stage(sh, e0, wave, slot0, stage, lane, lane64);
         lds_wave_sync();
         MSJ_STAMP(srow, 13);  // tile A staged
-        emit_store(a, sh, e0, wave, slot0, stage, lane);
+        emit_store(a, sh, e0, wave, slot0, stage, lane, lane_p);
         lds_wave_sync();  // the staging slice is reused by the next tile
         MSJ_STAMP(srow, 14);  // tile A stored
-        EmitU e1 = emit_prepare(a, sh, wave, slot0 + 1u, rp, count0, timeout);
+        EmitU e1 = emit_prepare(al, sh, wave, slot0 + 1u, rp, count0, timeout);
         emit_stage(sh, e1, wave, slot0 + 1u, stage, lane, lane64);
         lds_wave_sync();
         MSJ_STAMP(srow, 15);  // tile B staged
@@ -1067,7 +1079,7 @@ __device__ __forceinline__ void worker_wave(const KernelArgs &a, Shared &sh, con
 #pragma unroll
         for (uint32_t j = 0; j < kBatch; j++) touch_block(blk[j]);
         MSJ_STAMP(srow, 11);  // the next range's bytes have arrived
-        emit_store(a, sh, e1, wave, slot0 + 1u, stage, lane);
+        emit_store(a, sh, e1, wave, slot0 + 1u, stage, lane, lane_p);
         lds_wave_sync();
         // ---- 4. park this iteration's tiles
 #pragma unroll
@@ -1077,7 +1089,7 @@ __device__ __forceinline__ void worker_wave(const KernelArgs &a, Shared &sh, con
             sh.pend_masks[wave][slot][lane] = make_uint4((uint32_t)now[j].T0, (uint32_t)(now[j].T0 >> 32),
                                                          (uint32_t)now[j].T1, (uint32_t)(now[j].T1 >> 32));
             sh.pend_excl[wave][slot][lane] = now[j].excl;
-            if (lane == 0)
+            if (lane_p == 0)
                 *reinterpret_cast<uint4 *>(sh.pend_meta[wave][slot]) =
                     make_uint4(t_cur < ntiles ? t_cur : 0xFFFFFFFFu, now[j].tile_cnt, in_cnt[j], in_state[j]);
         }
@@ -1099,7 +1111,7 @@ __device__ __forceinline__ void worker_wave(const KernelArgs &a, Shared &sh, con
                 EmitU e = emit_prepare(a, sh, wave, slot, w, count0, timeout);
                 emit_stage(sh, e, wave, slot, stage, lane, lane64);
                 lds_wave_sync();
-                emit_store(a, sh, e, wave, slot, stage, lane);
+                emit_store(a, sh, e, wave, slot, stage, lane, lane);
                 lds_wave_sync();  // the staging slice is reused by the next tile
             }
         }
@@ -1531,7 +1543,7 @@ __global__ __launch_bounds__(kThreads) void twopass_emit_kernel(const KernelArgs
     EmitU e = emit_prepare(a, sh, wave, 0, kPre | (uint64_t)(uint32_t)pw, count0, timeout);
     emit_stage(sh, e, wave, 0, stage, lane, lane64);
     lds_wave_sync();
-    emit_store(a, sh, e, wave, 0, stage, lane);
+    emit_store(a, sh, e, wave, 0, stage, lane, lane);
 }
 
 __global__ __launch_bounds__(kThreads, 4) void stage1_kernel(const KernelArgs a) {

@@ -488,9 +488,10 @@ def _sharded_dataset(name):
     from mojo_simdjson_amd import synth
 
     if name == "guesswrong":
-        # the cut falls inside a string whose closing quote follows a ':' -> the in_string
+        # the cut falls inside a string of a letter that also occurs outside of strings, which goes on for more than
+        # the 1 MiB a rank looks at before it guesses, and whose closing quote follows a ':' -> the in_string
         # speculation of rank 1 is wrong and it must run again with the exact carry
-        return b'["' + b"a" * (6 * 16384) + b':",1,2,"zz"]'
+        return b'["' + b"a" * (3 << 20) + b':",1,2,"zz"]'
     u = synth.workload(name, 3 << 20)
     data = u.tobytes() * 2
     if name == "minified":  # extra tail with escapes
@@ -604,9 +605,9 @@ def test_sharded_world8_one_gpu(torch_mod, oracle):
 
     world = 8
     u = synth.workload("utf8", 1 << 20).tobytes()
-    # (a string longer than the 4 KiB of its head a rank speculates from, made of a letter that also occurs outside of
-    # strings: nothing contradicts either hypothesis and the guess of the rank that starts inside it is wrong)
-    parts = [u, b' ["' + b"a" * 8000 + b':",1,2,"zz"] ', synth.workload("minified", 1 << 20).tobytes()]
+    # (a string longer than the 1 MiB of its head a rank looks at before it guesses, made of a letter that also occurs
+    # outside of strings: nothing contradicts either hypothesis and the guess of the rank that starts inside it is wrong)
+    parts = [u, b' ["' + b"a" * ((1 << 20) + 8000) + b':",1,2,"zz"] ', synth.workload("minified", 1 << 20).tobytes()]
     p1 = len(parts[0])
     p3 = sum(len(x) for x in parts)
     head3 = b' ["x' + b"\\" * 70 + b'","'
