@@ -650,6 +650,19 @@ __device__ __forceinline__ void stage_indices(const EmitU &e, const EmitV &v, ui
     scatter_bits32(v.thi, lds0 + 4u * nlo, nhi, v0 | 32u);
 }
 
+// The index array is written once and read by a later kernel, if at all: streaming (non-temporal) stores keep
+// it from displacing the input in L2 / MALL (a trivial kernel with this read : write mix gains 2 % from them,
+// profiles/r02/hbm_bw_ubench_nt.txt).
+__device__ __forceinline__ void st_index_quad(uint8_t *p, const uint4 v) {
+#ifdef MSJ_PLAIN_INDEX_STORES
+    *reinterpret_cast<uint4 *>(p) = v;
+#else
+    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+    u32x4 w = {v.x, v.y, v.z, v.w};
+    __builtin_nontemporal_store(w, reinterpret_cast<u32x4 *>(p));
+#endif
+}
+
 __device__ __forceinline__ void copy_out(const KernelArgs &a, const EmitU &e, const uint32_t *stage,
                                          const uint32_t lane, const uint32_t lane_p) {
     // uniform 64-bit base + 32-bit lane offsets; full 16-byte quads in the body, the (at
@@ -665,10 +678,10 @@ __device__ __forceinline__ void copy_out(const KernelArgs &a, const EmitU &e, co
     for (uint32_t k = 0; k < kStageWords / 256u; k++) {
         if (q_lo + 64u * k >= q_hi) break;  // uniform
         if (q_lo + 64u * (k + 1u) <= q_hi) {  // uniform: a full round, every lane stores
-            *reinterpret_cast<uint4 *>(out + off + 1024u * k) = *reinterpret_cast<const uint4 *>(src + off + 1024u * k);
+            st_index_quad(out + off + 1024u * k, *reinterpret_cast<const uint4 *>(src + off + 1024u * k));
         } else {  // the last round: the first (q_hi - q_lo - 64k) lanes
             if (lane_p < q_hi - q_lo - 64u * k)
-                *reinterpret_cast<uint4 *>(out + off + 1024u * k) = *reinterpret_cast<const uint4 *>(src + off + 1024u * k);
+                st_index_quad(out + off + 1024u * k, *reinterpret_cast<const uint4 *>(src + off + 1024u * k));
             break;
         }
     }
@@ -714,7 +727,7 @@ __device__ __noinline__ void emit_dense(uint32_t *idx, const uint32_t tile_base,
         asm volatile(
             "s_mov_b64 %[save], exec\n"
             "s_mov_b64 exec, %[m]\n"
-            "global_store_dword %[off], %[val], %[out]\n"
+            "global_store_dword %[off], %[val], %[out] nt\n"
             "s_mov_b64 exec, %[save]\n"
             : [save] "=&s"(save)
             : [m] "s"(m), [off] "v"(off), [val] "v"(val), [out] "s"(out)
