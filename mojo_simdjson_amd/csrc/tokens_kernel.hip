@@ -318,8 +318,11 @@ __global__ __launch_bounds__(kThreads) void apply_depth(const uint8_t *__restric
         before += d[k];
     }
     if (base + kPer <= n) {
-        *reinterpret_cast<int4 *>(depth + base) = make_int4(out[0], out[1], out[2], out[3]);
-        *reinterpret_cast<int4 *>(depth + base + 4) = make_int4(out[4], out[5], out[6], out[7]);
+        // write-once streams: non-temporal stores (the arrays are far larger than L2 / MALL)
+        typedef int i32x4 __attribute__((ext_vector_type(4)));
+        const i32x4 o0 = {out[0], out[1], out[2], out[3]}, o1 = {out[4], out[5], out[6], out[7]};
+        __builtin_nontemporal_store(o0, reinterpret_cast<i32x4 *>(depth + base));
+        __builtin_nontemporal_store(o1, reinterpret_cast<i32x4 *>(depth + base + 4));
     } else {
 #pragma unroll
         for (int k = 0; k < kPer; k++)
@@ -1047,9 +1050,11 @@ __global__ __launch_bounds__(kSpanThreads) void token_spans(const uint8_t *__res
         }
     }
     if (full) {
-        if (kSpans) {
-            *reinterpret_cast<uint2 *>(end + tok0) = make_uint2(e0, e1);
-            *reinterpret_cast<uint16_t *>(flags + tok0) = (uint16_t)(f0 | (f1 << 8));
+        if (kSpans) {  // write-once streams: non-temporal stores
+            typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+            const u32x2 ee = {e0, e1};
+            __builtin_nontemporal_store(ee, reinterpret_cast<u32x2 *>(end + tok0));
+            __builtin_nontemporal_store((uint16_t)(f0 | (f1 << 8)), reinterpret_cast<uint16_t *>(flags + tok0));
         }
         if (kFused) *reinterpret_cast<uint16_t *>(type + tok0) = (uint16_t)(c0 | (c1 << 8));
     } else if (have0) {

@@ -19,7 +19,12 @@ ap.add_argument("--match", action="store_true")
 ap.add_argument("--iters", type=int, default=200)
 ap.add_argument("--warm", type=int, default=200)
 ap.add_argument("--mib", type=int, default=1024)
+ap.add_argument("--lib", default=None, help="A/B: load this build of libmsj_stage1.so")
 a = ap.parse_args()
+if a.lib:
+    from mojo_simdjson_amd import _lib
+
+    _lib.LIB_PATH = os.path.abspath(a.lib)
 
 dev = Stage1Device(0)
 torch.cuda.set_device(0)
