@@ -203,6 +203,14 @@ __device__ __forceinline__ uint64_t wait_desc(const uint64_t *p, const uint32_t 
     return d;
 }
 
+// LDS written by some lanes of the wave, read by others: in order for one wave, the compiler only has to keep it so
+__device__ __forceinline__ void lds_wave_sync_early() {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
 // The 64 bytes one lane owns, as loaded (4 x 16 B), plus one byte of the 64-byte
 // window in front of the tile (lane l holds byte [tile_start - 64 + l]).
 struct Block {
@@ -212,9 +220,24 @@ struct Block {
 
 // Branch-free (so the compiler can leave all five loads in flight) and free of vector address
 // arithmetic beyond one clamp per piece: the tile's base is scalar, the lane's piece offsets
-// are loop invariants (lane_off[k] = 64 * lane + 16 * k), and pieces past the end are redirected to the
-// last 16-B piece that starts inside the input -- whatever they return is masked by `valid` in
-// compute_tile.  For a tile inside the input the clamp is a no-op.
+// are loop invariants, and pieces past the end are redirected to the last 16-B piece that starts
+// inside the input -- whatever they return is masked by `valid` in compute_tile.  For a tile inside
+// the input the clamp is a no-op.
+//
+// Two shapes:
+//   kCoalesced = false  lane_off[k] = 64 * lane + 16 * k: the lane gets its own 64-byte block, every wave
+//       instruction touches 64 separate blocks and the other three quarters of each line come from L1 (four
+//       passes of the texture path over the same 32 lines).  The two-pass kernels' shape.
+//   kCoalesced = true   lane_off[k] = 16 * lane + 1024 * k: every wave instruction is 1 KiB contiguous; piece k of
+//       lane l is chunk s = 64 k + l of the tile = quarter s & 3 of block s >> 2, and chunks_to_block() hands every
+//       lane its own block through LDS.  The single-pass kernel's shape: measured against the block shape in one
+//       session (1 GiB, settled clocks, profiles/r03/load_shape_ab.txt) sparse input 0.221 -> 0.210 ms, pretty-printed
+//       0.286 -> 0.276, minified 0.354 -> 0.346, UTF-8-heavy 0.317 -> 0.308.  A bare read loop shows no difference
+//       between the two shapes (6.2 TB/s both, scripts/ubench/read_shape.hip): what the kernel gains is the texture
+//       path's time, which its stores and descriptor traffic share.  Non-temporal loads were tried on top (the bare
+//       loop reads 6.9 TB/s with them): no further gain on these workloads and 4-6 % LOST on the dense extremes
+//       (`[10,10,...` 0.759 -> 0.807 ms), so the loads are plain.
+template <bool kCoalesced>
 __device__ __forceinline__ void load_block(const KernelArgs &a, const uint32_t tile, const uint32_t (&lane_off)[4],
                                            const uint32_t lane, Block &b) {
     // one launch covers < 2^32 bytes (kSegmentBytes), so offsets fit 32 bits
@@ -225,7 +248,13 @@ __device__ __forceinline__ void load_block(const KernelArgs &a, const uint32_t t
 #pragma unroll
     for (int k = 0; k < 4; k++) {
         const uint32_t off = lane_off[k] < lim ? lane_off[k] : lim;
-        b.q[k] = *reinterpret_cast<const uint4 *>(base + off);
+        if (kCoalesced) {
+            typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+            const u32x4 v = *reinterpret_cast<const u32x4 *>(base + off);
+            b.q[k] = make_uint4(v.x, v.y, v.z, v.w);
+        } else {
+            b.q[k] = *reinterpret_cast<const uint4 *>(base + off);
+        }
     }
     // the 64 bytes in front of the tile; the launch's first tile has them only with kFlagHasPrefix
     // (without: any readable bytes will do, compute_tile ignores them)
@@ -235,6 +264,40 @@ __device__ __forceinline__ void load_block(const KernelArgs &a, const uint32_t t
     b.wb = wbase[lane < wlim ? lane : wlim];
 }
 
+// From the coalesced shape to "a lane owns a block": the wave's staging slice (4 KiB, free between two emissions)
+// takes the chunks and gives the blocks back.  Lane l's piece k is chunk s = 64 k + l = quarter l & 3 of block
+// bb = 16 k + (l >> 2); it goes to byte 64 bb + 16 ((l & 3) ^ ((bb >> 1) & 3)) -- (bb >> 1) & 3 = (l >> 3) & 3 whatever k
+// is, so one lane-invariant address and three immediate offsets -- and lane L reads quarter c of its block at
+// 64 L + 16 (c ^ ((L >> 1) & 3)).  The XOR keeps the eight lanes of a ds_read_b128 group on different banks (their
+// blocks lie 64 bytes apart: without it four of them would share a bank); the writes are permutations inside
+// 64-byte groups.  Eight LDS instructions per tile, no vector arithmetic beyond three XORs.
+struct ChunkAddr {
+    uint32_t wr, rd, sw16;  // LDS byte addresses: this lane's chunk slot for piece 0; this lane's block; 16 x its swizzle
+};
+__device__ __forceinline__ ChunkAddr chunk_addresses(const uint32_t *stage, const uint32_t lane) {
+    const uint32_t s0 = (uint32_t)(uintptr_t)stage;
+    ChunkAddr c;
+    c.wr = s0 + 64u * (lane >> 2) + 16u * ((lane & 3u) ^ ((lane >> 3) & 3u));
+    c.rd = s0 + 64u * lane;
+    c.sw16 = 16u * ((lane >> 1) & 3u);
+    return c;
+}
+__device__ __forceinline__ void chunks_to_block(Block &b, const ChunkAddr &ca) {
+    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+    typedef __attribute__((address_space(3))) u32x4 *lds_u32x4_ptr;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const u32x4 v = {b.q[k].x, b.q[k].y, b.q[k].z, b.q[k].w};
+        *(lds_u32x4_ptr)(uintptr_t)(ca.wr + 1024u * k) = v;
+    }
+    lds_wave_sync_early();
+#pragma unroll
+    for (int c = 0; c < 4; c++) {
+        const u32x4 v = *(lds_u32x4_ptr)(uintptr_t)(ca.rd + (ca.sw16 ^ (16u * c)));
+        b.q[c] = make_uint4(v.x, v.y, v.z, v.w);
+    }
+}
+
 // The kBatch tiles of this wave in the range that starts at tile `lo`.
 __device__ __forceinline__ void load_range(const KernelArgs &a, const uint32_t lo, const uint32_t wave,
                                            const uint32_t (&lane_off)[4], const uint32_t lane, Block (&blk)[kBatch]) {
@@ -242,7 +305,7 @@ __device__ __forceinline__ void load_range(const KernelArgs &a, const uint32_t l
 #pragma unroll
     for (uint32_t j = 0; j < kBatch; j++) {
         const uint32_t t = lo + kWaves * j + wave;
-        load_block(a, t < ntiles ? t : ntiles - 1u, lane_off, lane, blk[j]);  // past the end: harmless re-read
+        load_block<true>(a, t < ntiles ? t : ntiles - 1u, lane_off, lane, blk[j]);  // past the end: harmless re-read
     }
 }
 
@@ -709,7 +772,8 @@ __device__ __forceinline__ void lds_wave_sync() {
 // scalar registers and becomes the EXEC mask; lane j then stands for byte j of the block, its rank among the
 // set bits below it (v_mbcnt) is its slot, and one store instruction writes the block's indices -- up to 256
 // contiguous bytes -- straight to the output.  16 instructions per 64-byte block whatever the density; no
-// staging, no LDS.
+// staging, no LDS.  (Plain stores: a block's store covers a part of one or two 128-byte lines and the next block's
+// store the rest; as non-temporal stores the parts reach memory one by one -- `[10,10,...`: 0.76 -> 1.09 ms per GiB.)
 __device__ __noinline__ void emit_dense(uint32_t *idx, const uint32_t tile_base, const uint64_t base, const uint32_t tlo,
                                         const uint32_t thi, const uint32_t first_slot, const uint32_t lane) {
     // out[k] = the tile's k-th index; wave-uniform (the arguments of a called function arrive in vector registers)
@@ -727,7 +791,7 @@ __device__ __noinline__ void emit_dense(uint32_t *idx, const uint32_t tile_base,
         asm volatile(
             "s_mov_b64 %[save], exec\n"
             "s_mov_b64 exec, %[m]\n"
-            "global_store_dword %[off], %[val], %[out] nt\n"
+            "global_store_dword %[off], %[val], %[out]\n"
             "s_mov_b64 exec, %[save]\n"
             : [save] "=&s"(save)
             : [m] "s"(m), [off] "v"(off), [val] "v"(val), [out] "s"(out)
@@ -906,7 +970,9 @@ __device__ __forceinline__ void worker_wave(const KernelArgs &a, Shared &sh, con
     const uint32_t tid = threadIdx.x;
     (void)tid;  // the diagnostic builds' stamps
     const uint32_t lane64 = lane * 64u;  // loop invariants in vector registers
-    const uint32_t lane_off[4] = {lane64, lane64 + 16u, lane64 + 32u, lane64 + 48u};
+    const uint32_t lane16 = lane * 16u;  // the coalesced load shape: piece k of lane l is chunk 64 k + l of the tile
+    const uint32_t lane_off[4] = {lane16, lane16 + 1024u, lane16 + 2048u, lane16 + 3072u};
+    const ChunkAddr chunk_at = chunk_addresses(stage, lane);
     const uint32_t ntiles = a.ntiles;
     const uint32_t nranges = (ntiles + kRange - 1u) / kRange;
     uint64_t *ragg = a.ws + kDescOffset + ntiles;
@@ -959,7 +1025,13 @@ __device__ __forceinline__ void worker_wave(const KernelArgs &a, Shared &sh, con
             now[j].T1 = 0;
             now[j].excl = 0;
             now[j].tile_cnt = 0;
-            if (valid_tile) now[j] = compute_tile(al, t_cur, lane, blk[j], carry0_p, timeout, agg_word);
+            if (valid_tile) {
+                // the chunks the coalesced loads brought become this lane's block (the staging slice is free: the
+                // last emission's copy-out has been waited for)
+                chunks_to_block(blk[j], chunk_at);
+                now[j] = compute_tile(al, t_cur, lane, blk[j], carry0_p, timeout, agg_word);
+                lds_wave_sync_early();  // the next tile's chunks (or the emission) reuse the slice
+            }
             if (j == 0) {
                 // the prefix word requested above has arrived (nothing younger is in flight yet) ...
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -1457,7 +1529,7 @@ __global__ __launch_bounds__(kThreads) void twopass_summary_kernel(const KernelA
     const uint32_t lane_off[4] = {lane64, lane64 + 16u, lane64 + 32u, lane64 + 48u};
     const uint32_t carry0 = uniform32((a.carry_in->next_is_escaped & 1u) | ((a.carry_in->prev_scalar & 1u) << 1));
     Block blk;
-    load_block(a, tile, lane_off, lane, blk);
+    load_block<false>(a, tile, lane_off, lane, blk);
     uint64_t *tp = a.tp;
     if (!window_carries(a, tile, blk.wb, carry0).resolved) {
         if (lane == 0) tp[tile] = kTpUnresolved;
@@ -1510,7 +1582,7 @@ __global__ __launch_bounds__(64) void twopass_scan_kernel(const KernelArgs a) {
                 uint32_t exact = 0;
                 if ((wk >> 62) == 3ull) {
                     Block blk;
-                    load_block(a, base + k, lane_off, lane, blk);
+                    load_block<false>(a, base + k, lane_off, lane, blk);
                     uint32_t timeout = 0;
                     exact = 1u | (e_prev << 1) | (ps_prev << 2);
                     (void)compute_tile(a, base + k, lane, blk, carry0, timeout, wk, exact);
@@ -1541,7 +1613,7 @@ __global__ __launch_bounds__(kThreads) void twopass_emit_kernel(const KernelArgs
     const uint32_t carry0 = uniform32((a.carry_in->next_is_escaped & 1u) | ((a.carry_in->prev_scalar & 1u) << 1));
     const uint64_t count0 = uniform64(a.carry_in->count);
     Block blk;
-    load_block(a, tile, lane_off, lane, blk);
+    load_block<false>(a, tile, lane_off, lane, blk);
     const uint64_t pw = uniform64(a.tp[a.ntiles + tile]);  // state and count in front of the tile (scan pass)
     uint32_t timeout = 0;
     uint64_t agg_word;
