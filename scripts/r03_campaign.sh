@@ -26,4 +26,10 @@ else
   timeout -k 10 120 python tests/stress_tokens.py 60 34 > $O/stress_tokens_34.txt 2>&1; tail -1 $O/stress_tokens_34.txt
   timeout -k 10 120 python tests/stress_documents.py 60 35 > $O/stress_documents_35.txt 2>&1; tail -1 $O/stress_documents_35.txt
   timeout -k 10 120 python tests/stress_host.py 60 36 > $O/stress_host_36.txt 2>&1; tail -1 $O/stress_host_36.txt
+  if [ -f variants/r3_base.so ]; then  # round 2's kernel (+ the capacity flag) against this build, same box, interleaved
+    cp mojo_simdjson_amd/libmsj_stage1.so variants/r3_ship.so
+    bash scripts/ab3.sh variants/r3_base.so variants/r3_ship.so > $O/ab_sustained_r02_r03.txt 2>&1; cat $O/ab_sustained_r02_r03.txt
+    bash scripts/ab2.sh variants/r3_base.so variants/r3_ship.so > $O/ab_unsettled_r02_r03.txt 2>&1; cat $O/ab_unsettled_r02_r03.txt
+  fi
+  bash scripts/clock_probe.sh minified > $O/clock_probe_r03_minified.txt 2>&1; tail -30 $O/clock_probe_r03_minified.txt
 fi
