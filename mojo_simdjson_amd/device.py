@@ -8,7 +8,7 @@ import ctypes
 
 import torch
 
-from . import _lib, errors
+from . import _lib
 
 CARRY_BYTES = 64
 SEGMENT_BYTES = 32

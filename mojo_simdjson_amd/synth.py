@@ -3,7 +3,6 @@
 Thin wrapper over ``libmsj_gen.so`` (csrc/synth_gen.c, host-only C).  Seeds and
 shapes follow SURVEY.md section 8d.
 """
-import ctypes
 
 import numpy as np
 

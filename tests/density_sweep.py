@@ -9,7 +9,6 @@ oracle's count of the unit (checker only, outside the timed region).
 import os
 import sys
 
-import numpy as np
 import torch
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))

@@ -9,14 +9,12 @@ import os
 import random
 import socket
 
-import numpy as np
 import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
 from mojo_simdjson_amd import sharded
 from mojo_simdjson_amd._lib import MsjCarry
-from tests import helpers
 
 _NONSCALAR = frozenset([0x20, 0x09, 0x0A, 0x0D, 0x0C, 0x1A, 0x2C, 0x3A, 0x5B, 0x5D, 0x7B, 0x7D])
 
