@@ -366,9 +366,9 @@ def main():
     else:
         code, total_count, res = last
         placement = sh.last_placement
-    assert code == 0, f"stage 1 returned {code}"
     reps = total_len // unit_len
-    assert total_count == unit_n * reps, (total_count, unit_n, reps)
+    # (wrong results do not raise here: they go into the printed line as a failed verification, exit code 3)
+    count_ok = code == 0 and total_count == unit_n * reps
     local_count = int(res.count) if world > 1 else total_count
 
     # ---- every index of this rank's shard, on the device, placed with the offsets the stitch returned
@@ -379,22 +379,23 @@ def main():
 
         torch.cuda.synchronize()
         index_begin, byte_base, cnt, nbytes = placement
-        assert (byte_base, cnt, nbytes) == (start, local_count, shard_len), (placement, start, local_count, shard_len)
+        # nothing in here raises before the all-gather below: a rank that found something wrong still takes part
+        place_ok = (byte_base, cnt, nbytes) == (start, local_count, shard_len)
         segs = None
         if world > 1 or shard_len > 0xFFFFFFFF:
             nseg = -(-shard_len // 0xFFFF0000)
             table = np.frombuffer(d_seg.cpu().numpy().tobytes(), dtype=np.uint64).reshape(n_seg_max, 4)[:nseg]
             segs = [(int(r[0]), int(r[2]), int(r[3])) for r in table]
-            assert sum(sg[2] for sg in segs) == local_count, (segs, local_count)
+            place_ok = place_ok and sum(sg[2] for sg in segs) == local_count
         d_uidx = torch.from_numpy(u_idx.astype(np.int64)).to(device)
-        bad, h = replication.check_shard(torch, d_idx, local_count, d_uidx, unit_len, byte_base, index_begin, segs)
+        bad, h = replication.check_shard(torch, d_idx, local_count, d_uidx, unit_len, start, index_begin, segs)
         want_begin = replication.expected_index_begin(u_idx, unit_len, start)
         tail_ok = True
         if rank == world - 1:
             tail = (d_idx[local_count:local_count + 3].to(torch.int64) & 0xFFFFFFFF).tolist()
             tail_ok = tail == [total_len & 0xFFFFFFFF, total_len & 0xFFFFFFFF, 0]
         # one all-gather of (mismatches, hash, index_begin ok, trailer ok) per rank
-        mine = torch.tensor([bad, h - (1 << 64) if h >= (1 << 63) else h, int(index_begin == want_begin), int(tail_ok)],
+        mine = torch.tensor([bad, h - (1 << 64) if h >= (1 << 63) else h, int(index_begin == want_begin and place_ok), int(tail_ok)],
                             dtype=torch.int64, device=device if backend == "nccl" else "cpu")
         if dist is not None:
             allv = [torch.empty_like(mine) for _ in range(world)]
@@ -404,12 +405,16 @@ def main():
         rows = [[int(x) for x in v.tolist()] for v in allv]
         h_sum = sum(r[1] for r in rows) & replication.MASK64
         h_want = replication.stream_hash(u_idx, unit_len, reps)
-        ok = all(r[0] == 0 and r[2] == 1 and r[3] == 1 for r in rows) and h_sum == h_want
+        ok = count_ok and all(r[0] == 0 and r[2] == 1 and r[3] == 1 for r in rows) and h_sum == h_want
         verify_detail = {"mismatches": sum(r[0] for r in rows), "hash": f"{h_sum:016x}", "hash_expected": f"{h_want:016x}",
                          "index_begin_ok": all(r[2] == 1 for r in rows), "trailer_ok": all(r[3] == 1 for r in rows)}
-        assert ok, f"index verification failed: {verify_detail} (per rank: {rows})"
-        verified = "indices"
+        # a failed verification does not swallow the measurement: the line is printed with the verdict in it and the
+        # process then exits with code 3
+        verified = "indices" if ok else (f"FAILED (code {code}, count {total_count} want {unit_n * reps}; per rank [mismatches, hash, "
+                                         f"placement ok, trailer ok]: {rows})")
         del d_uidx
+    elif not count_ok:
+        verified = f"FAILED (code {code}, count {total_count} want {unit_n * reps})"
 
     t = torch.tensor([dt], dtype=torch.float64, device=device if backend == "nccl" else "cpu")
     if dist is not None:
@@ -535,12 +540,15 @@ def main():
                 "note": "rank 0's clock; the first ~100 ms after idle run 10-15 % slower than the sustained rate",
             }
         print(json.dumps(out), flush=True)
+    verify_failed = verified.startswith("FAILED")
     if world > 1:
         barrier()
         sh.close()  # the RCCL communicator of the stitch goes before torch's process group does
     dev.close()
     if dist is not None:
         dist.destroy_process_group()
+    if verify_failed:
+        sys.exit(3)
 
 
 if __name__ == "__main__":
