@@ -508,41 +508,48 @@ __device__ __forceinline__ Pending compute_tile(const KernelArgs &a, const uint3
     //      the per-lane carries (carry-lookahead).  A block that starts escaped is rare (the byte
     //      before it ends an odd run of backslashes): quotes and strings are computed for carry-in 0
     //      first, and only a tile that has such a block redoes them with the lanes' carries.
-    const uint64_t tt = escape_tt0(cls.backslash);
-    const uint64_t G = __ballot(escape_out0(tt, cls.backslash) != 0u);
-    const uint64_t Pm = __ballot(((uint32_t)cls.backslash & (uint32_t)(cls.backslash >> 32)) == 0xFFFFFFFFu);
-    uint64_t quote = unescaped_quotes0(cls.quote_chr, tt);  // eq['"'] & ~escaped  (json_string_scanner.mojo:58)
-    // ---- strings (json_string_scanner.mojo:55-69)
-    uint64_t S0 = prefix_xor(quote);  // in_string if the lane started outside a string
-    const uint64_t add_a = G | Pm, add_b = G;
-    uint64_t add_s = add_a + add_b + tc.e_in;
-    uint64_t carries = add_s ^ add_a ^ add_b;
-    uint64_t escaped = 0;  // only needed (and only right) on the rare path
-    MSJ_STAMP(tile, 3);
-    if (carries != 0ull || partial || !tc.resolved) {  // uniform, rare
-        if (!tc.resolved) {
-            // >= 63 consecutive backslashes in front of the tile: exact carries from the predecessor
-            uint32_t to = 0;
-            const uint64_t d = wait_desc(&a.ws[kDescOffset + tile - 1], a.wait_ticks, &to);
-            if (to) timeout = 1;
-            tc.e_in = (uint32_t)(d >> 58) & 1u;
-            tc.ps_in = (uint32_t)(d >> 57) & 1u;
-            add_s = add_a + add_b + tc.e_in;
-            carries = add_s ^ add_a ^ add_b;
+    // A tile without a quote or a backslash (the inside of a long string, a run of blanks, a column of numbers)
+    // has no escape or string work at all: its in-string state is its predecessor's, for every byte.
+    const uint64_t qb = cls.quote_chr | cls.backslash;
+    const bool quiet = __ballot(((uint32_t)qb | (uint32_t)(qb >> 32)) != 0u) == 0ull && !partial && tc.resolved;  // uniform
+    uint64_t quote = 0, in_string0 = 0, escaped = 0;  // escaped: only needed (and only right) on the rare path
+    uint32_t tile_e_out = 0, tile_par = 0;
+    if (!quiet) {
+        const uint64_t tt = escape_tt0(cls.backslash);
+        const uint64_t G = __ballot(escape_out0(tt, cls.backslash) != 0u);
+        const uint64_t Pm = __ballot(((uint32_t)cls.backslash & (uint32_t)(cls.backslash >> 32)) == 0xFFFFFFFFu);
+        quote = unescaped_quotes0(cls.quote_chr, tt);  // eq['"'] & ~escaped  (json_string_scanner.mojo:58)
+        // ---- strings (json_string_scanner.mojo:55-69)
+        uint64_t S0 = prefix_xor(quote);  // in_string if the lane started outside a string
+        const uint64_t add_a = G | Pm, add_b = G;
+        uint64_t add_s = add_a + add_b + tc.e_in;
+        uint64_t carries = add_s ^ add_a ^ add_b;
+        MSJ_STAMP(tile, 3);
+        if (carries != 0ull || partial || !tc.resolved) {  // uniform, rare
+            if (!tc.resolved) {
+                // >= 63 consecutive backslashes in front of the tile: exact carries from the predecessor
+                uint32_t to = 0;
+                const uint64_t d = wait_desc(&a.ws[kDescOffset + tile - 1], a.wait_ticks, &to);
+                if (to) timeout = 1;
+                tc.e_in = (uint32_t)(d >> 58) & 1u;
+                tc.ps_in = (uint32_t)(d >> 57) & 1u;
+                add_s = add_a + add_b + tc.e_in;
+                carries = add_s ^ add_a ^ add_b;
+            }
+            uint32_t lane_e_out;
+            escaped = escaped_mask(cls.backslash, (uint32_t)(carries >> lane) & 1u, &lane_e_out);
+            quote = cls.quote_chr & ~escaped;
+            S0 = prefix_xor(quote);
         }
-        uint32_t lane_e_out;
-        escaped = escaped_mask(cls.backslash, (uint32_t)(carries >> lane) & 1u, &lane_e_out);
-        quote = cls.quote_chr & ~escaped;
-        S0 = prefix_xor(quote);
+        tile_e_out = (uint32_t)(((add_a & add_b) | ((add_a | add_b) & ~add_s)) >> 63);
+        const uint64_t PM = __ballot((int32_t)(uint32_t)(S0 >> 32) < 0);
+        const uint32_t lane_par = lanes_below(PM);  // bit 0: parity of the lanes before me in the tile
+        tile_par = (uint32_t)__popcll(PM) & 1u;
+        const uint32_t lane_in32 = (uint32_t)__builtin_amdgcn_sbfe((int)lane_par, 0, 1);  // all-ones: inside a string
+        const uint64_t lane_in = u64(lane_in32, lane_in32);
+        // in_string assuming the TILE starts outside a string
+        in_string0 = S0 ^ lane_in;
     }
-    uint32_t tile_e_out = (uint32_t)(((add_a & add_b) | ((add_a | add_b) & ~add_s)) >> 63);
-    const uint64_t PM = __ballot((int32_t)(uint32_t)(S0 >> 32) < 0);
-    const uint32_t lane_par = lanes_below(PM);  // bit 0: parity of the lanes before me in the tile
-    const uint32_t tile_par = (uint32_t)__popcll(PM) & 1u;
-    const uint32_t lane_in32 = (uint32_t)__builtin_amdgcn_sbfe((int)lane_par, 0, 1);  // all-ones: inside a string
-    const uint64_t lane_in = u64(lane_in32, lane_in32);
-    // in_string assuming the TILE starts outside a string
-    const uint64_t in_string0 = S0 ^ lane_in;
 
     // ---- scalars (json_scanner.mojo:64-79); three-input mask operations throughout
     const uint64_t nqs = lut3<MSJ_TT(~TA & ~TB & ~TC)>(cls.op, cls.ws, quote);  // scalar & ~quote

@@ -170,6 +170,47 @@ def test_strings_spanning_tiles(oracle):
     assert_matches_oracle(oracle, odd, "one quote per lane")
 
 
+def test_quiet_tiles(oracle):
+    """Tiles without a quote or a backslash take a shorter path (no escape / string work): next to every kind of
+    neighbour, inside and outside a string, with control characters, scalars and UTF-8 in them."""
+    from mojo_simdjson_amd import errors
+
+    q = TILE
+    cases = {
+        "blanks between values": b"[1," + b" " * (3 * q) + b"2]",
+        "digits only": b"[" + b"7" * (2 * q + 5) + b"," + b"8" * (q + 9) + b"]",
+        "inside a string": b'["' + b"x" * (q - 2) + b"y" * (2 * q) + b'"]',
+        "string ends on the tile edge": b'["' + b"x" * (q - 3) + b'"' + b" " * (2 * q) + b',"z"]',
+        "backslash as the byte before a quiet tile": b'["' + b"x" * (q - 3) + b"\\" + b"n" * (2 * q) + b'"]',
+        "escaped quote as the byte before": b'["' + b"x" * (q - 4) + b'\\"' + b"n" * (2 * q) + b'"]',
+        "escaped backslash then quiet": b'["' + b"x" * (q - 4) + b"\\\\" + b"n" * (2 * q) + b'"]',
+        "long backslash run in front (unresolved window)": b'["' + b"x" * (q - 2 - 70) + b"\\" * 70 + b"n" * (2 * q) + b'"]',
+        "odd backslash run in front": b'["' + b"x" * (q - 2 - 71) + b"\\" * 71 + b"n" * (2 * q) + b'"]',
+        "newline in a quiet tile inside a string": b'["' + b"x" * (q + 100) + b"\n" + b"x" * (2 * q) + b'"]',
+        "newline in a quiet tile outside": b"[1," + b" " * (q + 100) + b"\n" + b" " * (2 * q) + b"2]",
+        "scalar over the edge into a quiet tile": b"[" + b" " * (q - 3) + b"12345" + b" " * (2 * q) + b",true]",
+        "scalar run through quiet tiles": b"[" + b" " * (q - 3) + b"1" * (2 * q + 9) + b",null]",
+        "brackets only": b"[" * (q + 7) + b" " * q + b"]" * (q + 7),
+        "utf-8 in a quiet tile": b'["' + "é漢😀".encode() * (q // 3) + b'"]',
+        "utf-8 cut by the edges of quiet tiles": b'["x' + "漢".encode() * (3 * q // 3 + 11) + b'"]',
+        "bad utf-8 in a quiet tile": b'["' + b"x" * (q + 50) + b"\xff" + b"x" * q + b'"]',
+        "unclosed": b'["' + b"x" * (3 * q),
+    }
+    for name, d in cases.items():
+        assert_matches_oracle(oracle, d, name)
+        try:
+            d.decode("utf-8")
+        except UnicodeDecodeError:
+            # the reference ignores UTF-8 (its checker is a stub); with the strict flag a structurally good document is rejected
+            if helpers.run_oracle(oracle.msj_oracle_stage1, d)[0] == 0:
+                assert host_stage1(d, flags=1)[0] == errors.UTF8_ERROR, name
+        else:
+            assert_matches_oracle(oracle, d, name + " (strict utf-8)", flags=1)
+    for cut in (q - 1, q, q + 1, 2 * q + 63, 2 * q + 64):  # a quiet tile cut short by the end of the input
+        assert_matches_oracle(oracle, (b"[1," + b" " * (3 * q))[:cut], f"quiet, cut at {cut}")
+        assert_matches_oracle(oracle, (b'["' + b"x" * (3 * q))[:cut], f"quiet in a string, cut at {cut}")
+
+
 def test_density_extremes(oracle):
     from mojo_simdjson_amd import synth
 
