@@ -43,6 +43,23 @@
 #include "lane_math.h"
 #include "stage1_kernel.h"
 
+// Issue priority of a worker wave by phase (s_setprio; the resolver runs at 3).  The four waves of a SIMD are in
+// different phases of their range iterations; left to the default arbitration, a wave in a latency-bound phase -- the
+// dependent steps of the scatter chain, the LDS round trip of the copy-out, the fold and the hand-over behind the
+// barrier -- queues for issue slots behind waves that are in the middle of 300 independent vector instructions of a
+// compute phase.  Raising the priority of those phases shortens them without costing the compute phase anything it
+// would notice: +3.5 % minified, +4.8 % UTF-8-heavy, +5.8 % pretty-printed in one session
+// (profiles/r03/ab_wave_priority.txt; any level above the compute phase's does it, the levels differ by < 1 %).
+#ifndef MSJ_PRIO_COORD
+#define MSJ_PRIO_COORD 2    // behind the barrier: fold, publish, hand-over, issue of the next range's loads
+#endif
+#ifndef MSJ_PRIO_EMIT
+#define MSJ_PRIO_EMIT 3     // staging chains and copy-out of the parked tiles
+#endif
+#ifndef MSJ_PRIO_COMPUTE
+#define MSJ_PRIO_COMPUTE 0  // bit-planes, classification, masks, scans of the range's two tiles
+#endif
+
 namespace msj {
 
 // ---- tile descriptors -------------------------------------------------------
@@ -1060,6 +1077,7 @@ __device__ __forceinline__ void worker_wave(const KernelArgs &a, Shared &sh, con
         // completed (__syncthreads() would wait for them)
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
         MSJ_STAMP(srow, 9);   // barrier passed
+        __builtin_amdgcn_s_setprio(MSJ_PRIO_COORD);
         // wave 0 passes the next range's ticket on (drawn a compute phase ago) ...
         if (wave_p == 0) {
             const uint32_t v = ticket_value(req_reg);
@@ -1154,6 +1172,7 @@ __device__ __forceinline__ void worker_wave(const KernelArgs &a, Shared &sh, con
         timeout = uniform32(timeout);
         MSJ_STAMP(srow, 12);  // next range known, its loads issued, the old range's prefix in hand
         static_assert(kBatch == 2, "the emission below is written for two tiles per wave and range");
+        __builtin_amdgcn_s_setprio(MSJ_PRIO_EMIT);
         const uint32_t slot0 = ring * kBatch;
         EmitU e0 = emit_prepare(al, sh, wave, slot0, rp, count0, timeout);
         emit_stage(sh, e0, wave, slot0, stage, lane, lane64);
@@ -1173,6 +1192,7 @@ __device__ __forceinline__ void worker_wave(const KernelArgs &a, Shared &sh, con
         MSJ_STAMP(srow, 11);  // the next range's bytes have arrived
         emit_store(a, sh, e1, wave, slot0 + 1u, stage, lane, lane_p);
         lds_wave_sync();
+        __builtin_amdgcn_s_setprio(MSJ_PRIO_COMPUTE);
         // ---- 4. park this iteration's tiles
 #pragma unroll
         for (uint32_t j = 0; j < kBatch; j++) {
@@ -1190,7 +1210,8 @@ __device__ __forceinline__ void worker_wave(const KernelArgs &a, Shared &sh, con
         ring = (ring + 1u == kDefer) ? 0u : ring + 1u;
     }
     MSJ_RSTAMP(a.ntiles + 4096u + blockIdx.x, 4, tid == 0);  // last range computed
-    // ---- drain: oldest first
+    // ---- drain: oldest first (the launch's tail: nothing but emission is left for this wave)
+    __builtin_amdgcn_s_setprio(MSJ_PRIO_EMIT);
     for (uint32_t step = 0; step < kDefer; step++) {
         lds_wave_sync();
         const uint32_t old_first = uniform32(sh.pend_meta[wave][ring * kBatch][0]);
