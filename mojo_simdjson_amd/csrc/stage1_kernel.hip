@@ -49,7 +49,9 @@
 // barrier -- queues for issue slots behind waves that are in the middle of 300 independent vector instructions of a
 // compute phase.  Raising the priority of those phases shortens them without costing the compute phase anything it
 // would notice: +3.5 % minified, +4.8 % UTF-8-heavy, +5.8 % pretty-printed in one session
-// (profiles/r03/ab_wave_priority.txt; any level above the compute phase's does it, the levels differ by < 1 %).
+// (profiles/r03/ab_wave_priority.txt; any level above the compute phase's does it, the levels differ by < 1 %);
+// the second tile of the compute phase one level above the first: another +1.5 % / +1.8 % / +3.5 %.  The ladder
+// 0, 1, 2, 3 follows a wave's progress through its iteration.
 #ifndef MSJ_PRIO_COORD
 #define MSJ_PRIO_COORD 2    // behind the barrier: fold, publish, hand-over, issue of the next range's loads
 #endif
@@ -57,7 +59,10 @@
 #define MSJ_PRIO_EMIT 3     // staging chains and copy-out of the parked tiles
 #endif
 #ifndef MSJ_PRIO_COMPUTE
-#define MSJ_PRIO_COMPUTE 0  // bit-planes, classification, masks, scans of the range's two tiles
+#define MSJ_PRIO_COMPUTE 0  // bit-planes, classification, masks, scans of the range's first tile ...
+#endif
+#ifndef MSJ_PRIO_COMPUTE2
+#define MSJ_PRIO_COMPUTE2 1  // ... and of its second: the closer a wave is to the barrier its three siblings wait at, the sooner it issues
 #endif
 
 namespace msj {
@@ -1057,6 +1062,9 @@ __device__ __forceinline__ void worker_wave(const KernelArgs &a, Shared &sh, con
                 lds_wave_sync_early();  // the next tile's chunks (or the emission) reuse the slice
             }
             if (j == 0) {
+#if MSJ_PRIO_COMPUTE2 != MSJ_PRIO_COMPUTE
+                __builtin_amdgcn_s_setprio(MSJ_PRIO_COMPUTE2);
+#endif
                 // the prefix word requested above has arrived (nothing younger is in flight yet) ...
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 touch_u64(rp_word);
