@@ -633,7 +633,21 @@ extern "C" uint64_t msj_tokens_workspace_bytes(uint64_t n, int with_match);
 
 extern "C" int msj_launch_tokens(const uint8_t *d_buf, uint64_t len, const uint32_t *d_idx, uint64_t n, uint8_t *d_type,
                                         int32_t *d_depth, uint32_t *d_match, msj_tokens_result *d_result, int32_t *d_ws, void *stream);
-extern "C" uint64_t msj_stage2_prep_workspace_bytes(uint64_t n, int with_match);
+extern "C" uint64_t msj_stage2_prep_workspace_bytes(uint64_t n, uint64_t len, int with_match);
+
+// the workspace of the token calls (block aggregates, chunk aggregates, group table): grown when a call needs more
+static bool ensure_tok_ws(msj_ctx *ctx, uint64_t need) {
+    if (need <= ctx->tok_ws_bytes) return true;
+    if (ctx->tok_ws) {
+        (void)hipDeviceSynchronize();
+        (void)hipFree(ctx->tok_ws);
+    }
+    ctx->tok_ws = nullptr;
+    ctx->tok_ws_bytes = 0;
+    if (!hip_ok(hipMalloc(reinterpret_cast<void **>(&ctx->tok_ws), need + need / 4))) return false;
+    ctx->tok_ws_bytes = need + need / 4;
+    return true;
+}
 
 int32_t msj_tokens_device(msj_ctx *ctx, const uint8_t *d_buf, uint64_t len, const uint32_t *d_idx, uint64_t n,
                           uint8_t *d_type, int32_t *d_depth, uint32_t *d_match, msj_tokens_result *d_result,
@@ -645,17 +659,8 @@ int32_t msj_tokens_device(msj_ctx *ctx, const uint8_t *d_buf, uint64_t len, cons
         (reinterpret_cast<uintptr_t>(d_type) & 7u))
         return MSJ_ERR_BAD_ARGUMENT;
     if (!hip_ok(hipSetDevice(ctx->device))) return MSJ_ERR_HIP;
-    const uint64_t need = msj_stage2_prep_workspace_bytes(n, d_match != nullptr);  // incl. the span kernel's sub-aggregates
-    if (need > ctx->tok_ws_bytes) {
-        if (ctx->tok_ws) {
-            (void)hipDeviceSynchronize();
-            (void)hipFree(ctx->tok_ws);
-        }
-        ctx->tok_ws = nullptr;
-        ctx->tok_ws_bytes = 0;
-        if (!hip_ok(hipMalloc(reinterpret_cast<void **>(&ctx->tok_ws), need + need / 4))) return MSJ_MEMALLOC;
-        ctx->tok_ws_bytes = need + need / 4;
-    }
+    const uint64_t need = msj_stage2_prep_workspace_bytes(n, len, d_match != nullptr);  // incl. the fused kernel's chunk aggregates and table
+    if (!ensure_tok_ws(ctx, need)) return MSJ_MEMALLOC;
     ctx->tok_doc_n = ~0ull;
     if (msj_launch_tokens(d_buf, len, d_idx, n, d_type, d_depth, d_match, d_result, ctx->tok_ws, stream) != 0) return MSJ_ERR_HIP;
     ctx->tok_doc_n = n;
@@ -663,7 +668,7 @@ int32_t msj_tokens_device(msj_ctx *ctx, const uint8_t *d_buf, uint64_t len, cons
 }
 
 extern "C" int msj_launch_token_spans(const uint8_t *d_buf, uint64_t len, const uint32_t *d_idx, uint64_t n, uint32_t *d_end,
-                                      uint8_t *d_flags, uint32_t *d_fix, void *stream);
+                                      uint8_t *d_flags, int32_t *d_ws, uint32_t *d_fix, void *stream);
 extern "C" uint64_t msj_span_fix_bytes(void);
 
 static bool ensure_span_fix(msj_ctx *ctx) {
@@ -684,10 +689,11 @@ int32_t msj_token_spans_device(msj_ctx *ctx, const uint8_t *d_buf, uint64_t len,
     if (len > MSJ_MAX_SEGMENT_BYTES || n >= (1ull << 31)) return MSJ_CAPACITY;
     if (!hip_ok(hipSetDevice(ctx->device))) return MSJ_ERR_HIP;
     if (!ensure_span_fix(ctx)) return MSJ_MEMALLOC;
-    return msj_launch_token_spans(d_buf, len, d_idx, n, d_end, d_flags, ctx->span_fix, stream) == 0 ? MSJ_SUCCESS : MSJ_ERR_HIP;
+    if (!ensure_tok_ws(ctx, msj_stage2_prep_workspace_bytes(n, len, 0))) return MSJ_MEMALLOC;  // the group table lives there
+    ctx->tok_doc_n = ~0ull;
+    return msj_launch_token_spans(d_buf, len, d_idx, n, d_end, d_flags, ctx->tok_ws, ctx->span_fix, stream) == 0 ? MSJ_SUCCESS : MSJ_ERR_HIP;
 }
 
-extern "C" uint64_t msj_stage2_prep_workspace_bytes(uint64_t n, int with_match);
 extern "C" int msj_launch_stage2_prep(const uint8_t *d_buf, uint64_t len, const uint32_t *d_idx, uint64_t n, uint8_t *d_type,
                                       int32_t *d_depth, uint32_t *d_match, uint32_t *d_end, uint8_t *d_flags,
                                       msj_tokens_result *d_result, int32_t *d_ws, uint32_t *d_fix, void *stream);
@@ -702,17 +708,8 @@ int32_t msj_stage2_prep_device(msj_ctx *ctx, const uint8_t *d_buf, uint64_t len,
         (reinterpret_cast<uintptr_t>(d_type) & 7u))
         return MSJ_ERR_BAD_ARGUMENT;
     if (!hip_ok(hipSetDevice(ctx->device))) return MSJ_ERR_HIP;
-    const uint64_t need = msj_stage2_prep_workspace_bytes(n, d_match != nullptr);
-    if (need > ctx->tok_ws_bytes) {
-        if (ctx->tok_ws) {
-            (void)hipDeviceSynchronize();
-            (void)hipFree(ctx->tok_ws);
-        }
-        ctx->tok_ws = nullptr;
-        ctx->tok_ws_bytes = 0;
-        if (!hip_ok(hipMalloc(reinterpret_cast<void **>(&ctx->tok_ws), need + need / 4))) return MSJ_MEMALLOC;
-        ctx->tok_ws_bytes = need + need / 4;
-    }
+    const uint64_t need = msj_stage2_prep_workspace_bytes(n, len, d_match != nullptr);
+    if (!ensure_tok_ws(ctx, need)) return MSJ_MEMALLOC;
     ctx->tok_doc_n = ~0ull;
     if (!ensure_span_fix(ctx)) return MSJ_MEMALLOC;
     if (msj_launch_stage2_prep(d_buf, len, d_idx, n, d_type, d_depth, d_match, d_end, d_flags, d_result, ctx->tok_ws, ctx->span_fix, stream) != 0)

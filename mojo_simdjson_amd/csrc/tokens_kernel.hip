@@ -1115,6 +1115,338 @@ static uint32_t fix_cap() {  // host: the list's capacity for this launch
 }
 static uint32_t span_lds_limit() { return g_lds_limit < kSpanLds ? g_lds_limit : kSpanLds; }
 
+// ---- the same results from TILES of the buffer (round 3) -------------------------------------------------------
+// token_spans above is organised by tokens: a workgroup first loads idx[first], idx[first + 512] to learn WHICH bytes
+// it needs and only then asks for them -- two memory round trips one after the other in a workgroup that lives for
+// 4-5 us, with the classification running on the ~42 lanes the stretch has blocks for.  Here the unit is a GROUP of
+// kTgTiles 4 KiB tiles of the buffer: which bytes a workgroup stages is known from blockIdx alone, so the bytes, the
+// group's entry of a small table (`tbl[g]` = number of structurals in front of byte g * kTgBytes: group_table below)
+// and then the first chunk's indices are all requested before anything is waited for; one wave per tile stages and
+// classifies it with all 64 lanes (1 KiB-contiguous wave loads, linear in LDS, the lane's own 64-byte block read back
+// from there), a fifth wave does the same for a halo of kTgHaloBlocks blocks behind the group.  Tokens are handled in
+// CHUNKS of 128 on a global grid (chunk c = tokens [128 c, 128 c + 128), two per lane, the pair evaluated once --
+// staged_token_fast and its fallbacks exactly as above); a group owns the chunks whose FIRST token lies in its 16 KiB,
+// its five waves take them round robin, the next chunk's indices are requested before the present one is worked on.
+// A chunk whose tokens end inside the staged range (the halo is what the group's last chunk usually needs) reads
+// LDS; one that does not (sparse input, long strings) takes the per-token path from global memory, like a long
+// stretch above.  The depth aggregates leave per chunk (merge_sub_aggregates folds 16 of them into a block).
+constexpr uint32_t kTgTiles = 4;
+constexpr uint32_t kTgWaves = kTgTiles + 1;            // one wave per tile + one for the halo
+constexpr uint32_t kTgThreads = 64 * kTgWaves;
+constexpr uint32_t kTgBytes = kTgTiles * 4096u;        // bytes of the buffer per workgroup
+constexpr uint32_t kTgHaloBlocks = 32;                 // 2 KiB behind them (<= 64: one wave)
+constexpr uint32_t kTgBlocks = kTgTiles * 64 + kTgHaloBlocks;
+constexpr uint32_t kTgStage = kTgBlocks * 64;          // bytes staged
+constexpr uint32_t kTgMapWords = kSpanMapFront + 2 * kTgBlocks + 4;
+constexpr uint32_t kChunk = 128;                       // tokens per wave iteration
+static_assert(kTgHaloBlocks <= 64 && (kTgHaloBlocks * 64) % 1024 == 0, "the halo is staged by one wave, 1 KiB per instruction");
+static_assert(kBlock % kChunk == 0, "a block of the depth pass is a whole number of chunks");
+
+// staged_token_fast written so that it compiles to straight-line code (the hot loop of token_tiles): every LDS read
+// is unconditional (the positions are inside the staged range whatever the token is), conditions are 0 / 1 words
+// combined with & and | -- `a && b` over an LDS read makes the compiler guard the read with a branch, and the short
+// blocks between such branches expose every LDS round trip.  Same results as staged_token_fast; nonzero return = one
+// round was not enough (the caller takes staged_token for that lane).
+__device__ __forceinline__ uint32_t pair_fast(const uint8_t *stage, const uint32_t *m_num, const uint32_t *m_flt, const uint32_t *m_bs,
+                                              const uint16_t *bs_cnt, const uint32_t *m_ink, uint32_t lo, uint32_t span, uint32_t len,
+                                              uint32_t c, uint32_t is_num, uint32_t rs, uint32_t rn, uint32_t &e_out, uint32_t &f_out) {
+    const uint32_t rlen = min(len - lo, span);  // end of the buffer within the staged range
+    const uint32_t is_str = c == '"';
+    // ---- string
+    const uint32_t vi = bits_before(m_ink, rn);
+    const uint32_t q = (uint32_t)max((int)rn - __clz(vi), (int)rs + 1);
+    const uint32_t more_ink = (uint32_t)(vi == 0u) & (uint32_t)(rn - rs > 33u);
+    const uint32_t bq = stage[q - 1u];
+    const uint32_t isq = (uint32_t)(q > rs + 1u) & (uint32_t)(bq == '"');
+    const uint32_t vb = ~bits_before(m_bs, q - 1u);  // backslashes right in front of that quote
+    const uint32_t closed = isq & (~(uint32_t)__clz(vb) & 1u);
+    const uint32_t more_bs = isq & (uint32_t)(vb == 0u);
+    const uint32_t b0 = rs + 1u, close = q - 1u;  // body = [b0, close)
+    const uint32_t esc = bs_before(m_bs, bs_cnt, close) != bs_before(m_bs, bs_cnt, b0);
+    const uint32_t far = closed & (uint32_t)((b0 >> 12) != (close >> 12));
+    const uint32_t lng = close - b0 > kSpanCap;
+    const uint32_t f_str = MSJ_SPAN_STRING | (closed ? (lng ? MSJ_SPAN_LONG : (esc ? MSJ_SPAN_ESCAPED : 0u)) : MSJ_SPAN_OPEN);
+    const uint32_t e_str = closed ? lo + close : len;
+    // ---- number: parse_number's scan (include/generic/number_parsing.mojo:41-59), see staged_token
+    const uint32_t stop = min(rs + 1u + kSpanCap, rlen);
+    const uint32_t p0 = rs + (uint32_t)(c == '-');
+    const uint32_t wn = ~bits_at(m_num, p0);
+    const uint32_t p = min(p0 + min((uint32_t)(__ffs(wn) - 1), 32u), stop);
+    const uint32_t more_num = (uint32_t)(wn == 0u) & (uint32_t)(p0 + 32u < stop);
+    const uint32_t ends = (uint32_t)(p < stop) | (uint32_t)(lo + p == len);
+    const uint32_t bp = stage[p];  // p <= span: the array has 16 bytes behind the range
+    const uint32_t ch = p < rlen ? bp : 0x20u;
+    const uint32_t flt = ends & ((uint32_t)(ch == '.') | (uint32_t)((ch | 0x20u) == 'e'));
+    const uint32_t wf = bits_at(m_flt, p);
+    const uint32_t bad = ends & (flt ^ 1u) & (uint32_t)(p < rlen) & (~wf & 1u);
+    const uint32_t pe = flt ? min(p + min((uint32_t)(__ffs(wf) - 1), 32u), stop) : p;
+    const uint32_t more_flt = flt & (uint32_t)(wf == 0u) & (uint32_t)(p + 32u < stop);
+    const uint32_t no_end = (uint32_t)(pe == stop) & (uint32_t)(lo + stop < len);
+    const uint32_t f_num = MSJ_SPAN_NUMBER | (flt ? MSJ_SPAN_FLOAT : 0u) | (bad ? MSJ_SPAN_BAD : 0u);
+    const uint32_t e_num = lo + pe;
+    e_out = is_str ? e_str : (is_num ? e_num : 0u);
+    f_out = is_str ? f_str : (is_num ? f_num : 0u);
+    return is_str ? (more_ink | more_bs | far) : (is_num & (more_num | more_flt | no_end));
+}
+// '"', '-' or a digit, as a 0 / 1 word without a compare chain: bit (c - 0x22) of a 24-bit table
+__device__ __forceinline__ uint32_t starts_scalar(uint32_t c) {
+    const uint32_t t = c - 0x22u;
+    return (uint32_t)(t < 24u) & (0x00FFC801u >> (t & 31u));
+}
+
+// tbl[g] = number of structurals in front of byte g * kTgBytes (g = 0 .. ngroups; tbl[ngroups] = n): a binary search
+// per group in the index array.  (A few tens of microseconds for a 1 GiB buffer; stage 1 could hand the same numbers
+// over for nothing -- every tile's emission knows its first slot -- if the two calls shared more than the arrays.)
+__global__ __launch_bounds__(256) void group_table(const uint32_t *__restrict__ idx, uint32_t n, uint32_t ngroups, uint32_t *__restrict__ tbl) {
+    const uint32_t g = blockIdx.x * 256u + threadIdx.x;
+    if (g > ngroups) return;
+    uint32_t lo = 0, hi = n;
+    if (g == ngroups) lo = n;
+    const uint32_t target = g * kTgBytes;  // < len < 2^32
+    while (lo < hi) {
+        const uint32_t mid = lo + ((hi - lo) >> 1);
+        if (idx[mid] < target) lo = mid + 1u; else hi = mid;
+    }
+    tbl[g] = lo;
+}
+
+// 16 bytes at `pos`, blanks past the end of the buffer (the last group only)
+__device__ __noinline__ uint4 chunk16_or_blanks(const uint8_t *buf, uint64_t pos, uint64_t len) {
+    uint32_t w[4];
+#pragma unroll
+    for (int d = 0; d < 4; d++) {
+        uint32_t x = 0x20202020u;
+#pragma unroll
+        for (int bb = 0; bb < 4; bb++) {
+            const uint64_t p = pos + 4u * d + bb;
+            if (p < len) x = (x & ~(0xFFu << (8 * bb))) | ((uint32_t)buf[p] << (8 * bb));
+        }
+        w[d] = x;
+    }
+    return make_uint4(w[0], w[1], w[2], w[3]);
+}
+
+template <bool kFused, bool kSpans>
+__global__ __launch_bounds__(kTgThreads) void token_tiles(const uint8_t *__restrict__ buf, uint64_t len, const uint32_t *__restrict__ idx,
+                                                         uint64_t n, uint32_t *__restrict__ end, uint8_t *__restrict__ flags, uint32_t lds_limit,
+                                                         uint8_t *__restrict__ type, int4 *__restrict__ chunk_agg, uint32_t *__restrict__ fix,
+                                                         uint32_t fix_cap, const uint32_t *__restrict__ tbl) {
+    __shared__ __attribute__((aligned(16))) uint8_t stage[kTgStage + 16];  // a number may be asked for the byte behind the range
+    __shared__ __attribute__((aligned(8))) uint32_t m_num[kTgMapWords], m_flt[kTgMapWords], m_bs[kTgMapWords], m_ink[kTgMapWords];
+    __shared__ __attribute__((aligned(4))) uint16_t bs_cnt[kTgMapWords];  // set bits of m_bs in front of each word, from the wave's first block
+    __shared__ uint32_t bs_blocks[2 * kTgWaves + 2];                      // bit b: block b of the range holds a backslash
+    const uint32_t nt = (uint32_t)n, len32 = (uint32_t)len;  // n < 2^31, len < 2^32 (the entry points check)
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    const uint32_t base = blockIdx.x * kTgBytes;  // < len
+    // the chunks this group owns: those whose first token lies in [base, base + kTgBytes)
+    const uint32_t t_lo = tbl[blockIdx.x], t_hi = tbl[blockIdx.x + 1u];
+    const uint32_t c_lo = (t_lo + kChunk - 1u) / kChunk, c_hi = (t_hi + kChunk - 1u) / kChunk;
+    if (c_lo >= c_hi) return;  // uniform: none (sparse input: nothing to stage for)
+
+    // ---- the wave's part of the range: 1 KiB contiguous per wave instruction, linear in LDS
+    const uint32_t region = wave * 4096u + 16u * lane;
+    const bool tail = (uint64_t)base + kTgStage > len;  // uniform: the range reaches past the buffer (blanks there)
+    constexpr uint32_t kHaloInsts = kTgHaloBlocks * 64u / 1024u;
+    uint4 v[4];
+#pragma unroll
+    for (uint32_t k = 0; k < 4; k++) {
+        if (wave == kTgTiles && k >= kHaloInsts) break;  // uniform
+        const uint64_t pos = (uint64_t)base + region + 1024u * k;
+        v[k] = tail ? chunk16_or_blanks(buf, pos, len) : *reinterpret_cast<const uint4 *>(buf + pos);
+    }
+    // this wave's first chunk: its indices are on their way while the bytes are classified
+    const uint32_t last = nt - 1u;
+    const auto request = [&](uint32_t c, uint32_t &i0, uint32_t &i1, uint32_t &nxt) {
+        const uint32_t tok0 = c * kChunk + 2u * lane;
+        if ((c + 1u) * kChunk < nt) {  // uniform: all 128 tokens and one behind them exist
+            const uint2 p = *reinterpret_cast<const uint2 *>(idx + tok0);  // idx is 16-byte aligned, tok0 even
+            i0 = p.x, i1 = p.y;
+            nxt = idx[(c + 1u) * kChunk];
+        } else {
+            i0 = idx[min(tok0, last)], i1 = idx[min(tok0 + 1u, last)];
+            nxt = len32;
+        }
+    };
+    uint32_t c = c_lo + wave;
+    uint32_t i0 = 0, i1 = 0, nxt = 0;
+    if (c < c_hi) request(c, i0, i1, nxt);
+#pragma unroll
+    for (uint32_t k = 0; k < 4; k++) {
+        if (wave == kTgTiles && k >= kHaloInsts) break;
+        *reinterpret_cast<uint4 *>(stage + region + 1024u * k) = v[k];
+    }
+    const uint32_t j = threadIdx.x;  // lane j of the workgroup classifies block j of the range
+    if (kSpans) {
+        // LDS written by this wave, read by this wave
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        uint64_t has_bs = 0;
+        uint32_t bs_lo = 0, bs_all = 0;  // backslashes in the low word / in all of this lane's block
+        if (j < kTgBlocks) {
+            uint32_t x[16];
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                const uint4 w = *reinterpret_cast<const uint4 *>(stage + 64u * j + 16 * q);
+                x[4 * q] = w.x, x[4 * q + 1] = w.y, x[4 * q + 2] = w.z, x[4 * q + 3] = w.w;
+            }
+            uint64_t pl[8];
+            msj::bitplanes(x, pl);
+            const msj::SpanClasses cl = msj::span_classes(pl);
+            const uint32_t w = kSpanMapFront + 2u * j;
+            *reinterpret_cast<uint2 *>(m_num + w) = make_uint2((uint32_t)cl.digit, (uint32_t)(cl.digit >> 32));
+            *reinterpret_cast<uint2 *>(m_flt + w) = make_uint2((uint32_t)cl.sow, (uint32_t)(cl.sow >> 32));
+            *reinterpret_cast<uint2 *>(m_bs + w) = make_uint2((uint32_t)cl.backslash, (uint32_t)(cl.backslash >> 32));
+            *reinterpret_cast<uint2 *>(m_ink + w) = make_uint2((uint32_t)~cl.blank, (uint32_t)(~cl.blank >> 32));
+            has_bs = cl.backslash;
+            bs_lo = __popc((uint32_t)cl.backslash);
+            bs_all = bs_lo + __popc((uint32_t)(cl.backslash >> 32));
+        } else if (j < kTgBlocks + 2u) {  // zero words behind the maps
+            const uint32_t w = kSpanMapFront + 2u * j;
+            *reinterpret_cast<uint2 *>(m_num + w) = make_uint2(0, 0);
+            *reinterpret_cast<uint2 *>(m_flt + w) = make_uint2(0, 0);
+            *reinterpret_cast<uint2 *>(m_bs + w) = make_uint2(0, 0);
+            *reinterpret_cast<uint2 *>(m_ink + w) = make_uint2(0, 0);
+        }
+        if (j == kTgThreads - 1u) {  // ... and in front of them
+            *reinterpret_cast<uint2 *>(m_num) = make_uint2(0, 0);
+            *reinterpret_cast<uint2 *>(m_flt) = make_uint2(0, 0);
+            *reinterpret_cast<uint2 *>(m_bs) = make_uint2(0, 0);
+            *reinterpret_cast<uint2 *>(m_ink) = make_uint2(0, 0);
+            bs_blocks[2 * kTgWaves] = 0;
+            bs_blocks[2 * kTgWaves + 1] = 0;
+            *reinterpret_cast<uint32_t *>(bs_cnt) = 0;
+        }
+        {   // all lanes: blocks in front of this lane's, within the wave (= within its 4 KiB)
+            const uint32_t upto = wave_incl_sum(bs_all) - bs_all;
+            if (j < kTgBlocks + 2u) *reinterpret_cast<uint32_t *>(bs_cnt + kSpanMapFront + 2u * j) = upto | ((upto + bs_lo) << 16);
+        }
+        const uint64_t bsb = __ballot(has_bs != 0);
+        if (lane == 0) {
+            bs_blocks[2 * wave] = (uint32_t)bsb;
+            bs_blocks[2 * wave + 1] = (uint32_t)(bsb >> 32);
+        }
+    }
+    __syncthreads();
+
+    const bool wide = (reinterpret_cast<uintptr_t>(end) & 7u) == 0 &&
+                      ((reinterpret_cast<uintptr_t>(flags) | reinterpret_cast<uintptr_t>(type)) & 1u) == 0;  // uniform
+    for (; c < c_hi; c += kTgWaves) {
+        // the next chunk's indices: requested now, looked at in the next iteration
+        uint32_t n_i0 = 0, n_i1 = 0, n_nxt = 0;
+        if (c + kTgWaves < c_hi) request(c + kTgWaves, n_i0, n_i1, n_nxt);
+        const uint32_t tok0 = c * kChunk + 2u * lane;
+        const bool allhere = (c + 1u) * kChunk < nt;  // uniform: 128 tokens and one behind them
+        const bool have0 = allhere || tok0 < nt, have1 = allhere || tok0 + 1u < nt;
+        // the structural behind this lane's pair: the next lane's first token, the last lane's is the next chunk's first
+        const uint32_t i2 = (uint32_t)__builtin_amdgcn_update_dpp((int)nxt, (int)i0, 0x130, 0xF, 0xF, false);  // wave_shl:1
+        const uint32_t start0 = have0 ? i0 : 0u, start1 = have1 ? i1 : 0u;
+        const uint32_t next1 = (allhere || tok0 + 2u < nt) ? i2 : len32;
+        const uint32_t next0 = have1 ? start1 : len32;
+        // uniform: the chunk's bytes -- through the byte at the next chunk's first structural -- are staged
+        const uint32_t first_pos = (uint32_t)__builtin_amdgcn_readfirstlane((int)i0);
+        const uint32_t hi = allhere ? nxt + 1u : len32;
+        const bool staged = hi <= base + kTgStage && hi - first_pos <= lds_limit && first_pos >= base;
+        uint32_t e0 = 0, f0 = 0, c0 = 0, e1 = 0, f1 = 0, c1 = 0;
+        if (kSpans && staged && allhere) {
+            // the common case, straight-line: all 128 tokens exist, their bytes are staged; one evaluation per pair
+            // (in a valid document at most one of two neighbouring tokens is a string or a number)
+            const uint32_t rs0 = i0 - base, rs1 = i1 - base, rn1 = i2 - base;
+            c0 = stage[rs0];
+            c1 = stage[rs1];
+            const uint32_t s0 = starts_scalar(c0), s1 = starts_scalar(c1);
+            const uint32_t cs = s0 ? c0 : c1, rs = s0 ? rs0 : rs1, rn = s0 ? rs1 : rn1;
+            uint32_t e, f;
+            const uint32_t again = pair_fast(stage, m_num, m_flt, m_bs, bs_cnt, m_ink, base, kTgStage, len32, cs, s0 | s1, rs, rn, e, f);
+            if (__ballot((again | (s0 & s1)) != 0u) != 0ull) {  // rare: a window came up empty, or two scalars in a row
+                if (again && staged_token(stage, m_num, m_flt, m_bs, m_ink, bs_blocks, (uint64_t)base, kTgStage, len, cs, (uint64_t)base + rs,
+                                          (uint64_t)base + rn, e, f))
+                    fix_later(fix, fix_cap, tok0 + (s0 ? 0u : 1u), e, f);
+                if (s0 & s1) {
+                    if (!staged_token_fast(stage, m_num, m_flt, m_bs, bs_cnt, m_ink, base, kTgStage, len32, c1, rs1, rn1, e1, f1) &&
+                        staged_token(stage, m_num, m_flt, m_bs, m_ink, bs_blocks, (uint64_t)base, kTgStage, len, c1, (uint64_t)i1, (uint64_t)i2, e1, f1))
+                        fix_later(fix, fix_cap, tok0 + 1u, e1, f1);
+                }
+            }
+            e0 = s0 ? e : 0u, f0 = s0 ? f : 0u;
+            if (!(s0 & s1)) e1 = s0 ? 0u : e, f1 = s0 ? 0u : f;
+        } else if (!staged) {
+            if (have0) {
+                if (kSpans) span_of(FromGlobal{buf, len}, (uint64_t)start0, (uint64_t)next0, len, e0, f0);
+                if (kFused) c0 = buf[start0];
+            }
+            if (have1) {
+                if (kSpans) span_of(FromGlobal{buf, len}, (uint64_t)start1, (uint64_t)next1, len, e1, f1);
+                if (kFused) c1 = buf[start1];
+            }
+        } else if (!kSpans) {  // the type bytes only
+            if (have0) {
+                c0 = stage[start0 - base];
+                c1 = have1 ? (uint32_t)stage[start1 - base] : 0u;
+            }
+        } else if (have0) {
+            const uint32_t rs0 = start0 - base, rn0 = next0 - base;
+            const uint32_t rs1 = have1 ? start1 - base : rs0, rn1 = have1 ? next1 - base : rn0;
+            c0 = stage[rs0];
+            c1 = have1 ? (uint32_t)stage[rs1] : 0u;
+            const bool s0 = c0 == '"' || c0 == '-' || c0 - '0' < 10u;            // a string or a number: something to work out
+            const bool s1 = have1 && (c1 == '"' || c1 == '-' || c1 - '0' < 10u);
+            const uint32_t cs = s0 ? c0 : c1, rs = s0 ? rs0 : rs1, rn = s0 ? rn0 : rn1;
+            uint32_t e, f;
+            if (!staged_token_fast(stage, m_num, m_flt, m_bs, bs_cnt, m_ink, base, kTgStage, len32, cs, rs, rn, e, f) &&
+                staged_token(stage, m_num, m_flt, m_bs, m_ink, bs_blocks, (uint64_t)base, kTgStage, len, cs, (uint64_t)base + rs, (uint64_t)base + rn, e, f))
+                fix_later(fix, fix_cap, tok0 + (s0 ? 0u : 1u), e, f);
+            e0 = s0 ? e : 0u, f0 = s0 ? f : 0u;
+            e1 = s0 ? 0u : e, f1 = s0 ? 0u : f;
+            if (s0 && s1) {  // two scalars in a row (not a valid document)
+                if (!staged_token_fast(stage, m_num, m_flt, m_bs, bs_cnt, m_ink, base, kTgStage, len32, c1, rs1, rn1, e1, f1) &&
+                    staged_token(stage, m_num, m_flt, m_bs, m_ink, bs_blocks, (uint64_t)base, kTgStage, len, c1, (uint64_t)start1, (uint64_t)next1, e1, f1))
+                    fix_later(fix, fix_cap, tok0 + 1u, e1, f1);
+            }
+        }
+        if (allhere && wide) {
+            if (kSpans) {  // write-once streams: non-temporal stores
+                typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+                const u32x2 ee = {e0, e1};
+                __builtin_nontemporal_store(ee, reinterpret_cast<u32x2 *>(end + tok0));
+                __builtin_nontemporal_store((uint16_t)(f0 | (f1 << 8)), reinterpret_cast<uint16_t *>(flags + tok0));
+            }
+            if (kFused) *reinterpret_cast<uint16_t *>(type + tok0) = (uint16_t)(c0 | (c1 << 8));
+        } else if (have0) {
+            if (kSpans) {
+                end[tok0] = e0;
+                flags[tok0] = (uint8_t)f0;
+            }
+            if (kFused) type[tok0] = (uint8_t)c0;
+            if (have1) {
+                if (kSpans) {
+                    end[tok0 + 1] = e1;
+                    flags[tok0 + 1] = (uint8_t)f1;
+                }
+                if (kFused) type[tok0 + 1] = (uint8_t)c1;
+            }
+        }
+        if (kFused) {
+            // ordered reduction of the running-depth monoid over the chunk (see token_spans); the chunk's first token exists.
+            // '[' '{' are 5B 7B, ']' '}' are 5D 7D: one masked compare each, and the compare IS the ballot
+            const uint32_t k0 = have0 ? (c0 & 0xDFu) : 0u, k1 = have1 ? (c1 & 0xDFu) : 0u;
+            const uint64_t up0 = __ballot(k0 == 0x5Bu), dn0 = __ballot(k0 == 0x5Du), up1 = __ballot(k1 == 0x5Bu), dn1 = __ballot(k1 == 0x5Du);
+            const auto add_below = [](uint64_t m, uint32_t acc) { return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, acc)); };
+            const int ups_below = (int)add_below(up1, add_below(up0, 0u)), downs_below = (int)add_below(dn1, add_below(dn0, 0u));
+            const int d0 = (int)(k0 == 0x5Bu) - (int)(k0 == 0x5Du), d1 = (int)(k1 == 0x5Bu) - (int)(k1 == 0x5Du);
+            const int r0 = ups_below - downs_below + d0, r1 = r0 + d1;  // after token 2t / 2t + 1
+            int mn, mx;
+            wave_min_max(min(r0, r1), max(r0, r1), mn, mx);
+            if (lane == 0) {
+                const int ups = (int)__popcll(up0) + (int)__popcll(up1), downs = (int)__popcll(dn0) + (int)__popcll(dn1);
+                chunk_agg[c] = make_int4(ups - downs, mn, mx, ups);
+            }
+        }
+        i0 = n_i0, i1 = n_i1, nxt = n_nxt;
+    }
+}
+
 // the tokens on the work list, from global memory; the last workgroup to finish clears the list for the next call
 __global__ __launch_bounds__(256) void span_fixup(const uint8_t *__restrict__ buf, uint64_t len, const uint32_t *__restrict__ idx, uint64_t n,
                                                   uint32_t *__restrict__ end, uint8_t *__restrict__ flags, uint32_t *__restrict__ fix, uint32_t cap) {
@@ -1141,11 +1473,13 @@ __global__ __launch_bounds__(256) void span_fixup(const uint8_t *__restrict__ bu
     }
 }
 
-// block aggregates of the token pre-pass (kBlock tokens) from those of the fused kernel (kSpanTokens tokens)
+// block aggregates of the token pre-pass (kBlock tokens) from those of the fused kernels (kSubTokens tokens each:
+// kSpanTokens from token_spans, kChunk from token_tiles)
 static_assert(kBlock % kSpanTokens == 0, "a block of the depth pass is a whole number of span workgroups");
+template <uint32_t kSubTokens>
 __global__ __launch_bounds__(256) void merge_sub_aggregates(const int4 *__restrict__ sub, uint32_t nsub, int32_t *__restrict__ block_agg,
                                                             uint32_t nblocks) {
-    constexpr uint32_t kSub = kBlock / kSpanTokens;
+    constexpr uint32_t kSub = kBlock / kSubTokens;
     const uint32_t b = blockIdx.x * 256u + threadIdx.x;
     if (b >= nblocks) return;
     Agg t = {0, kNone, -kNone};
@@ -1159,36 +1493,66 @@ __global__ __launch_bounds__(256) void merge_sub_aggregates(const int4 *__restri
     }
     *reinterpret_cast<int4 *>(block_agg + 4 * (uint64_t)b) = make_int4(t.sum, t.mn, t.mx, no);
 }
+// 0: by tiles of the buffer (token_tiles); 1: by tokens (token_spans) -- msj_debug_set_span_mode, tests and A/B runs
+static uint32_t g_span_mode = 0;
 }  // namespace msj_tokens
 
 extern "C" void msj_debug_set_span_limits(uint32_t lds_limit_bytes, uint32_t fix_capacity) {
     msj_tokens::g_lds_limit = lds_limit_bytes;
     msj_tokens::g_fix_cap = fix_capacity;
 }
+extern "C" void msj_debug_set_span_mode(uint32_t mode) { msj_tokens::g_span_mode = mode; }
 
 // the work list of span_fixup: zeroed once by the owner (the kernels leave it zeroed)
 extern "C" uint64_t msj_span_fix_bytes(void) { return msj_tokens::kFixWords * sizeof(uint32_t); }
 
+// ---- workspace of the span / prep calls: the token pre-pass's own words, then (16-byte aligned) one int4 per chunk
+// of kChunk tokens (the fused kernels' depth aggregates), then the group table of token_tiles
+static uint64_t chunk_count(uint64_t n) { return n ? (n + msj_tokens::kChunk - 1) / msj_tokens::kChunk : 1; }
+static uint64_t group_count(uint64_t len) { return (len + msj_tokens::kTgBytes - 1) / msj_tokens::kTgBytes; }
+static uint64_t sub_offset_bytes(uint64_t n, int with_match) { return (msj_tokens_workspace_bytes(n, with_match) + 15u) & ~15ull; }
+extern "C" uint64_t msj_stage2_prep_workspace_bytes(uint64_t n, uint64_t len, int with_match) {
+    return sub_offset_bytes(n, with_match) + chunk_count(n) * sizeof(int4) + (group_count(len) + 2) * sizeof(uint32_t);
+}
+static int4 *sub_of(int32_t *d_ws, uint64_t n, int with_match) {
+    return reinterpret_cast<int4 *>(reinterpret_cast<uint8_t *>(d_ws) + sub_offset_bytes(n, with_match));
+}
+static uint32_t *table_of(int32_t *d_ws, uint64_t n, int with_match) {
+    return reinterpret_cast<uint32_t *>(sub_of(d_ws, n, with_match) + chunk_count(n));
+}
+
+// the tile-organised kernel with its table in front of it and the fix-up pass behind it
+template <bool kFused, bool kSpans>
+static void launch_token_tiles(const uint8_t *d_buf, uint64_t len, const uint32_t *d_idx, uint64_t n, uint32_t *d_end, uint8_t *d_flags,
+                               uint8_t *d_type, int4 *sub, uint32_t *tbl, uint32_t *d_fix, hipStream_t s) {
+    using namespace msj_tokens;
+    const uint32_t ngroups = (uint32_t)group_count(len);
+    hipLaunchKernelGGL(group_table, dim3((ngroups + 1u + 255u) / 256u), dim3(256), 0, s, d_idx, (uint32_t)n, ngroups, tbl);
+    hipLaunchKernelGGL((token_tiles<kFused, kSpans>), dim3(ngroups), dim3(kTgThreads), 0, s, d_buf, len, d_idx, n, d_end, d_flags,
+                       g_lds_limit < kTgStage ? g_lds_limit : 0xFFFFFFFFu, d_type, sub, d_fix, fix_cap(), tbl);
+    if (kSpans)
+        hipLaunchKernelGGL(span_fixup, dim3(kFixGroups), dim3(256), 0, s, d_buf, len, d_idx, n, d_end, d_flags, d_fix, fix_cap());
+}
+
 extern "C" int msj_launch_token_spans(const uint8_t *d_buf, uint64_t len, const uint32_t *d_idx, uint64_t n, uint32_t *d_end,
-                                      uint8_t *d_flags, uint32_t *d_fix, void *stream) {
+                                      uint8_t *d_flags, int32_t *d_ws, uint32_t *d_fix, void *stream) {
+    using namespace msj_tokens;
     if (n == 0) return 0;
-    const uint32_t lds_limit = msj_tokens::span_lds_limit();  // stretches over this many bytes take the global-memory path
-    hipLaunchKernelGGL(msj_tokens::token_spans<false>, dim3((uint32_t)((n + msj_tokens::kSpanTokens - 1) / msj_tokens::kSpanTokens)),
-                       dim3(msj_tokens::kSpanThreads), 0, static_cast<hipStream_t>(stream), d_buf, len, d_idx, n, d_end, d_flags, lds_limit,
-                       static_cast<uint8_t *>(nullptr), static_cast<int4 *>(nullptr), d_fix, msj_tokens::fix_cap());
-    hipLaunchKernelGGL(msj_tokens::span_fixup, dim3(msj_tokens::kFixGroups), dim3(256), 0, static_cast<hipStream_t>(stream), d_buf, len, d_idx, n,
-                       d_end, d_flags, d_fix, msj_tokens::fix_cap());
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (g_span_mode == 0 && (reinterpret_cast<uintptr_t>(d_idx) & 7u) == 0) {
+        launch_token_tiles<false, true>(d_buf, len, d_idx, n, d_end, d_flags, nullptr, nullptr, table_of(d_ws, n, 0), d_fix, s);
+        return (int)hipGetLastError();
+    }
+    const uint32_t lds_limit = span_lds_limit();  // stretches over this many bytes take the global-memory path
+    hipLaunchKernelGGL(token_spans<false>, dim3((uint32_t)((n + kSpanTokens - 1) / kSpanTokens)), dim3(kSpanThreads), 0, s, d_buf, len, d_idx, n,
+                       d_end, d_flags, lds_limit, static_cast<uint8_t *>(nullptr), static_cast<int4 *>(nullptr), d_fix, fix_cap());
+    hipLaunchKernelGGL(span_fixup, dim3(kFixGroups), dim3(256), 0, s, d_buf, len, d_idx, n, d_end, d_flags, d_fix, fix_cap());
     return (int)hipGetLastError();
 }
 
 // ---- everything stage 2 reads first, in one go (rows f1 + f2 + f4): the span kernel has every token's
 // first byte in LDS anyway, so it writes the type bytes and the depth aggregates as well and the token
 // pre-pass starts at its scan -- one pass over the buffer instead of two.
-extern "C" uint64_t msj_stage2_prep_workspace_bytes(uint64_t n, int with_match) {
-    const uint64_t nsub = (n + msj_tokens::kSpanTokens - 1) / msj_tokens::kSpanTokens;
-    return msj_tokens_workspace_bytes(n, with_match) + 32 + (nsub ? nsub : 1) * sizeof(int4);
-}
-
 extern "C" int msj_launch_stage2_prep(const uint8_t *d_buf, uint64_t len, const uint32_t *d_idx, uint64_t n, uint8_t *d_type,
                                       int32_t *d_depth, uint32_t *d_match, uint32_t *d_end, uint8_t *d_flags,
                                       msj_tokens_result *d_result, int32_t *d_ws, uint32_t *d_fix, void *stream) {
@@ -1197,15 +1561,18 @@ extern "C" int msj_launch_stage2_prep(const uint8_t *d_buf, uint64_t len, const 
     const uint64_t nb64 = (n + kBlock - 1) / kBlock;
     if (nb64 > 0x7FFFFFFFull) return (int)hipErrorInvalidValue;
     const uint32_t nb = (uint32_t)nb64;
-    const uint32_t nsub = (uint32_t)((n + kSpanTokens - 1) / kSpanTokens);
     // the fused kernel's aggregates live behind the token pre-pass's own workspace (16-byte aligned)
-    const uint64_t tok_bytes = (msj_tokens_workspace_bytes(n, d_match != nullptr) + 15u) & ~15ull;
-    int4 *sub = reinterpret_cast<int4 *>(reinterpret_cast<uint8_t *>(d_ws) + tok_bytes);
-    if (n) {
+    const int wm = d_match != nullptr;
+    int4 *sub = sub_of(d_ws, n, wm);
+    if (n && g_span_mode == 0) {
+        launch_token_tiles<true, true>(d_buf, len, d_idx, n, d_end, d_flags, d_type, sub, table_of(d_ws, n, wm), d_fix, s);
+        hipLaunchKernelGGL(merge_sub_aggregates<kChunk>, dim3((nb + 255u) / 256u), dim3(256), 0, s, sub, (uint32_t)chunk_count(n), d_ws, nb);
+    } else if (n) {
+        const uint32_t nsub = (uint32_t)((n + kSpanTokens - 1) / kSpanTokens);
         const uint32_t lds_limit = span_lds_limit();
         hipLaunchKernelGGL(token_spans<true>, dim3(nsub), dim3(kSpanThreads), 0, s, d_buf, len, d_idx, n, d_end, d_flags, lds_limit, d_type, sub, d_fix, fix_cap());
         hipLaunchKernelGGL(span_fixup, dim3(kFixGroups), dim3(256), 0, s, d_buf, len, d_idx, n, d_end, d_flags, d_fix, fix_cap());
-        hipLaunchKernelGGL(merge_sub_aggregates, dim3((nb + 255u) / 256u), dim3(256), 0, s, sub, nsub, d_ws, nb);
+        hipLaunchKernelGGL(merge_sub_aggregates<kSpanTokens>, dim3((nb + 255u) / 256u), dim3(256), 0, s, sub, nsub, d_ws, nb);
     }
     return launch_depth_passes(d_idx, n, d_type, d_depth, d_match, d_result, d_ws, s);
 }
@@ -1217,13 +1584,16 @@ extern "C" int msj_launch_tokens(const uint8_t *d_buf, uint64_t len, const uint3
     const uint64_t nb64 = (n + kBlock - 1) / kBlock;
     if (nb64 > 0x7FFFFFFFull) return (int)hipErrorInvalidValue;
     const uint32_t nb = (uint32_t)nb64;
-    const uint32_t nsub = (uint32_t)((n + kSpanTokens - 1) / kSpanTokens);
-    const uint64_t tok_bytes = (msj_tokens_workspace_bytes(n, d_match != nullptr) + 15u) & ~15ull;
-    int4 *sub = reinterpret_cast<int4 *>(reinterpret_cast<uint8_t *>(d_ws) + tok_bytes);
-    if (n) {
+    const int wm = d_match != nullptr;
+    int4 *sub = sub_of(d_ws, n, wm);
+    if (n && g_span_mode == 0) {
+        launch_token_tiles<true, false>(d_buf, len, d_idx, n, nullptr, nullptr, d_type, sub, table_of(d_ws, n, wm), nullptr, s);
+        hipLaunchKernelGGL(merge_sub_aggregates<kChunk>, dim3((nb + 255u) / 256u), dim3(256), 0, s, sub, (uint32_t)chunk_count(n), d_ws, nb);
+    } else if (n) {
+        const uint32_t nsub = (uint32_t)((n + kSpanTokens - 1) / kSpanTokens);
         hipLaunchKernelGGL((token_spans<true, false>), dim3(nsub), dim3(kSpanThreads), 0, s, d_buf, len, d_idx, n, static_cast<uint32_t *>(nullptr),
                            static_cast<uint8_t *>(nullptr), kSpanLds, d_type, sub, static_cast<uint32_t *>(nullptr), 0u);
-        hipLaunchKernelGGL(merge_sub_aggregates, dim3((nb + 255u) / 256u), dim3(256), 0, s, sub, nsub, d_ws, nb);
+        hipLaunchKernelGGL(merge_sub_aggregates<kSpanTokens>, dim3((nb + 255u) / 256u), dim3(256), 0, s, sub, nsub, d_ws, nb);
     }
     return launch_depth_passes(d_idx, n, d_type, d_depth, d_match, d_result, d_ws, s);
 }

@@ -19,6 +19,7 @@ ap.add_argument("--match", action="store_true")
 ap.add_argument("--iters", type=int, default=200)
 ap.add_argument("--warm", type=int, default=200)
 ap.add_argument("--mib", type=int, default=1024)
+ap.add_argument("--mode", type=int, default=0, help="0 = kernel organised by tiles (default), 1 = by tokens (round 2's)")
 ap.add_argument("--lib", default=None, help="A/B: load this build of libmsj_stage1.so")
 a = ap.parse_args()
 if a.lib:
@@ -27,6 +28,7 @@ if a.lib:
     _lib.LIB_PATH = os.path.abspath(a.lib)
 
 dev = Stage1Device(0)
+dev.lib.msj_debug_set_span_mode(a.mode)
 torch.cuda.set_device(0)
 u = synth.workload(a.workload, 64 << 20)
 d_buf = torch.from_numpy(u).to(dev.device).repeat((a.mib << 20) // u.size)
@@ -60,6 +62,6 @@ for _ in range(a.iters):
 e1.record()
 torch.cuda.synchronize()
 ms = e0.elapsed_time(e1) / a.iters
-print(f"{a.workload}{' +match' if a.match else ''}: {n} structurals, {nbytes} bytes: {ms:.4f} ms per call "
+print(f"{a.workload}{' +match' if a.match else ''} mode {a.mode}: {n} structurals, {nbytes} bytes: {ms:.4f} ms per call "
       f"({ms * (1 << 30) / nbytes:.4f} ms per GiB, {n / ms / 1e6:.1f} G structurals/s), {a.iters} calls after {a.warm} warm-up")
 dev.close()

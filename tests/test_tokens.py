@@ -186,8 +186,17 @@ def _check(dev, data, where):
     assert (res.n, res.final_depth, res.min_depth, res.max_depth) == (len(idx), final, mn, mx), where
 
 
+@pytest.fixture(params=["tiles", "tokens"])
+def span_mode(dev, request):
+    """The token calls' two kernels: organised by tiles of the buffer (the product's default) and by tokens (round 2's,
+    msj_debug_set_span_mode(1)): the same tests, the same definitions."""
+    dev.lib.msj_debug_set_span_mode(1 if request.param == "tokens" else 0)
+    request.addfinalizer(lambda: dev.lib.msj_debug_set_span_mode(0))
+    return request.param
+
+
 @pytest.mark.gpu
-def test_tokens_fixtures_and_shapes(dev):
+def test_tokens_fixtures_and_shapes(dev, span_mode):
     for f in helpers.golden_valid_files():
         js, _ = helpers.read_fixture(f)
         _check(dev, js, f)
@@ -218,7 +227,7 @@ def _check_spans(dev, data, where):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("lds_limit", ["", "0", "4096"])
-def test_token_spans(dev, lds_limit, request):
+def test_token_spans(dev, lds_limit, request, span_mode):
     """Both paths of the kernel: the workgroup's stretch staged in LDS with per-byte class bitmaps (default),
     and the per-token path from global memory that long stretches take (forced by a limit of 0; 4096 mixes them)."""
     from mojo_simdjson_amd import synth
@@ -272,7 +281,7 @@ def test_token_spans(dev, lds_limit, request):
 
 
 @pytest.mark.gpu
-def test_token_spans_arrays_off_the_wide_grid(dev):
+def test_token_spans_arrays_off_the_wide_grid(dev, span_mode):
     """The kernel writes a pair of tokens per access when the arrays allow it (8-byte aligned ends, 2-byte aligned
     flags): off that grid, and for odd token counts, it must write the same values one by one."""
     import torch
@@ -327,7 +336,7 @@ def _check_prep(dev, data, where):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("lds_limit", ["", "0", "4096"])
-def test_stage2_prep_equals_the_separate_calls(dev, lds_limit, request):
+def test_stage2_prep_equals_the_separate_calls(dev, lds_limit, request, span_mode):
     """msj_stage2_prep_device = token pre-pass + token spans from one pass over the buffer."""
     from mojo_simdjson_amd import synth
 
@@ -346,6 +355,44 @@ def test_stage2_prep_equals_the_separate_calls(dev, lds_limit, request):
     _check_prep(dev, b"]" * 5000 + b"[" * 7, "underflow")
     _check_prep(dev, b'[' + b'"a\\\\b",12,' * 3000 + b'"' + b"x" * 40000 + b'",' + b'"cd",3.5,' * 3000 + b"0]", "mixed paths")
     _check_prep(dev, b" ", "no structurals")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("lds_limit", ["", "4096"])
+def test_prep_around_the_tile_groups(dev, lds_limit, request):
+    """The kernel organised by tiles stages 16 KiB of the buffer + a 2 KiB halo per workgroup and hands out tokens in
+    chunks of 128 that belong to the group their first token lies in: tokens, chunk borders, long strings, floats whose
+    scan runs past the next structural and numbers at the cap are moved across the group border, the end of the halo
+    and the end of the buffer byte by byte."""
+    dev.lib.msj_debug_set_span_limits(int(lds_limit) if lds_limit else 0xFFFFFFFF, 0xFFFFFFFF)
+    request.addfinalizer(lambda: dev.lib.msj_debug_set_span_limits(0xFFFFFFFF, 0xFFFFFFFF))
+    G, H = 16384, 2048
+    rng = np.random.default_rng(77)
+    # (a) a dense run of short tokens across two borders, shifted byte by byte (chunk grid against byte grid)
+    for shift in list(range(0, 9)) + [63, 64, 65, 127, 128, 129]:
+        _check_prep(dev, b" " * shift + b"[" + b'1,"a\\",{"k":-2.5e3},' * 2100 + b"0]", f"dense run shifted by {shift}")
+    # (b) one token placed around the border / the end of the halo, its extent crossing either
+    for edge in (G, G + H, 2 * G, 2 * G + H):
+        for off in (-70, -64, -33, -2, -1, 0, 1, 31, 64):
+            for tok in (b'"' + b"s" * 90 + b'\n"', b"-" + b"8" * 70 + b".5e+7", b"3" * 1030, b'"' + b"\\" * 40 + b'"', b"true"):
+                head = b"[" + b"0," * 1500
+                pad = edge + off - len(head)
+                doc = head + b" " * pad + tok + b" ," + b"1," * 600 + b"2]"
+                _check_prep(dev, doc, f"{tok[:6]!r} at {edge}{off:+d}")
+    # (c) a float whose scan passes the next structural (a scalar behind a quote) and leaves the staged range: the
+    #     chunk's last token sits at the end of the halo
+    for fill in range(1020, 1030):
+        doc = b"[" + b"1," * 100 + b" " * (G - 1024 - 201) + b'"",' * 340 + b" " * fill + b'1.5"xx"' + b"y" * 3000 + b" ,7]"
+        _check_prep(dev, doc, f"float scan leaves the staged range ({fill})")
+    # (d) sparse stretches: groups that own no chunk, chunks far longer than a group, then dense again
+    doc = b"[" + b'"' + b"x" * 70000 + b'",' + b" " * 40000 + b"1," * 5000 + b'"' + b"y" * 20000 + b'"' + b" " * 20000 + b",[]]"
+    _check_prep(dev, doc, "sparse and dense")
+    # (e) byte soups of every size around the group size
+    alphabet = np.frombuffer(b'{}[],: "a1\\\n-.e', dtype=np.uint8)
+    for n in (G - 1, G, G + 1, G + H - 1, G + H, G + H + 1, 2 * G + 5, 5 * G + 77):
+        _check_prep(dev, alphabet[rng.integers(0, len(alphabet), n)].tobytes(), f"soup {n}")
+    # (f) the wide stores need aligned arrays: the same through the span call with arrays off the grid
+    _check_spans(dev, b"[" + b'"ab",' * 9000 + b"1]", "spans only")
 
 
 @pytest.mark.gpu
