@@ -270,9 +270,11 @@ __global__ __launch_bounds__(kThreads) void apply_depth(const uint8_t *__restric
                                                         const uint32_t *__restrict__ super_open, int32_t *__restrict__ depth,
                                                         int32_t *__restrict__ min8, int32_t *__restrict__ min64,
                                                         int32_t *__restrict__ min512, const uint32_t *__restrict__ open_start,
-                                                        uint32_t *__restrict__ opens, uint4 *__restrict__ doc_agg) {
+                                                        uint32_t *__restrict__ opens, uint4 *__restrict__ doc_agg,
+                                                        int32_t *__restrict__ block_mm) {
     __shared__ int wave_sum[kThreads / 64];
     __shared__ int wave_no[kThreads / 64];
+    __shared__ int wave_rmn[kThreads / 64], wave_rmx[kThreads / 64];
     __shared__ uint32_t doc_cnt[kThreads / 64], doc_start[kThreads / 64], doc_close[kThreads / 64];
     const uint64_t base = (uint64_t)blockIdx.x * kBlock + (uint64_t)threadIdx.x * kPer;
     uint32_t c[kPer];
@@ -312,10 +314,15 @@ __global__ __launch_bounds__(kThreads) void apply_depth(const uint8_t *__restric
             if (d[k] > 0) opens[slot++] = (uint32_t)(base + k);
     }
     int out[kPer];
+    int rmn = kNone, rmx = -kNone;  // minimum / maximum of the running depth AFTER each of this thread's tokens
 #pragma unroll
     for (int k = 0; k < kPer; k++) {
         out[k] = before - (d[k] < 0 ? 1 : 0);  // a closing bracket sits at the depth of its container
         before += d[k];
+        if (base + k < n) {
+            rmn = min(rmn, before);
+            rmx = max(rmx, before);
+        }
     }
     if (base + kPer <= n) {
         // write-once streams: non-temporal stores (the arrays are far larger than L2 / MALL)
@@ -350,20 +357,32 @@ __global__ __launch_bounds__(kThreads) void apply_depth(const uint8_t *__restric
             ls = (uint32_t)m_ls;
             lc = (uint32_t)(-neg_lc);
         }
+        int w_rmn, w_rmx;
+        wave_min_max(rmn, rmx, w_rmn, w_rmx);
         if (lane == 63) {
             doc_cnt[wave] = cnt;
             doc_start[wave] = ls;
             doc_close[wave] = lc;
+            wave_rmn[wave] = w_rmn;
+            wave_rmx[wave] = w_rmx;
         }
         __syncthreads();
         if (threadIdx.x == 0) {
             uint32_t tc = 0, ts = 0, te = 0;
+            int bmn = kNone, bmx = -kNone;
             for (int w = 0; w < kThreads / 64; w++) {
                 tc += doc_cnt[w];
                 ts = max(ts, doc_start[w]);
                 te = max(te, doc_close[w]);
+                bmn = min(bmn, wave_rmn[w]);
+                bmx = max(bmx, wave_rmx[w]);
             }
             doc_agg[blockIdx.x] = make_uint4(tc, ts, te, 0);
+            // the block's minimum / maximum running depth, into the words of its aggregate the scans are done with:
+            // min_max_depth folds them into the result (one address for 10^5 blocks costs 80 us in atomics or in
+            // the reads that would filter them: every request goes to the same L2 channel)
+            block_mm[4 * (uint64_t)blockIdx.x + 1] = bmn;
+            block_mm[4 * (uint64_t)blockIdx.x + 2] = bmx;
         }
     }
     if (min8) {  // the three lowest levels of the 8-ary min tree used for bracket matching
@@ -380,6 +399,33 @@ __global__ __launch_bounds__(kThreads) void apply_depth(const uint8_t *__restric
         m = min(m, __shfl_xor(m, 16));
         m = min(m, __shfl_xor(m, 32));
         if ((threadIdx.x & 63) == 0 && base < n) min512[base >> 9] = m;  // 512 tokens = this wave
+    }
+}
+
+// (4) minimum / maximum of the running depth over the stream, from the per-block values apply_depth left in the block
+//     aggregates (words 1 and 2): the scan set the result's fields to what ITS aggregates gave -- nothing (kNone /
+//     -kNone) when the kernel in front only counted brackets (token_tiles) -- and this folds the exact values in.
+constexpr uint32_t kMinMaxGroups = 64;
+__global__ __launch_bounds__(256) void min_max_depth(const int32_t *__restrict__ block_mm, uint32_t nblocks, msj_tokens_result *__restrict__ result) {
+    __shared__ int w_mn[4], w_mx[4];
+    int mn = kNone, mx = -kNone;
+    for (uint32_t b = blockIdx.x * 256u + threadIdx.x; b < nblocks; b += gridDim.x * 256u) {
+        const int4 q = *reinterpret_cast<const int4 *>(block_mm + 4 * (uint64_t)b);
+        mn = min(mn, q.y);
+        mx = max(mx, q.z);
+    }
+    int wmn, wmx;
+    wave_min_max(mn, mx, wmn, wmx);
+    if ((threadIdx.x & 63) == 63) {
+        w_mn[threadIdx.x >> 6] = wmn;
+        w_mx[threadIdx.x >> 6] = wmx;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        mn = min(min(w_mn[0], w_mn[1]), min(w_mn[2], w_mn[3]));
+        mx = max(max(w_mx[0], w_mx[1]), max(w_mx[2], w_mx[3]));
+        if (mn != kNone) atomicMin(&result->min_depth, mn);
+        if (mx != -kNone) atomicMax(&result->max_depth, mx);
     }
 }
 
@@ -552,7 +598,8 @@ static int launch_depth_passes(const uint32_t *d_idx, uint64_t n, uint8_t *d_typ
     int32_t *l3 = want_match ? (t.nlev > 3 ? lvl[3] : tree + tree_words(n) + 40) : nullptr;
     if (want_match)  // padding entries of the tree levels must never qualify: 0x7F7F7F7F
         (void)hipMemsetAsync(tree, 0x7F, (tree_words(n) + 64) * sizeof(int32_t), s);
-    if (nb) hipLaunchKernelGGL(apply_depth, dim3(nb), dim3(kThreads), 0, s, d_type, n, start, super_start, super_open, d_depth, l1, l2, l3, open_start, opens, doc_agg);
+    if (nb) hipLaunchKernelGGL(apply_depth, dim3(nb), dim3(kThreads), 0, s, d_type, n, start, super_start, super_open, d_depth, l1, l2, l3, open_start, opens, doc_agg, agg);
+    if (nb) hipLaunchKernelGGL(min_max_depth, dim3(nb < kMinMaxGroups * 256u ? (nb + 255u) / 256u : kMinMaxGroups), dim3(256), 0, s, agg, nb, d_result);
     if (want_match) {
         for (int k = 4; k < t.nlev; k++)
             hipLaunchKernelGGL(build_level, dim3((t.cnt[k] + 255u) / 256u), dim3(256), 0, s, t.lv[k - 1], t.cnt[k - 1], lvl[k], t.cnt[k]);
@@ -1236,7 +1283,8 @@ __global__ __launch_bounds__(kTgThreads) void token_tiles(const uint8_t *__restr
     __shared__ __attribute__((aligned(4))) uint16_t bs_cnt[kTgMapWords];  // set bits of m_bs in front of each word, from the wave's first block
     __shared__ uint32_t bs_blocks[2 * kTgWaves + 2];                      // bit b: block b of the range holds a backslash
     const uint32_t nt = (uint32_t)n, len32 = (uint32_t)len;  // n < 2^31, len < 2^32 (the entry points check)
-    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    // the wave index as a SCALAR: everything derived from it (the chunk, its addresses, the loop) is then scalar code
+    const uint32_t lane = threadIdx.x & 63u, wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const uint32_t base = blockIdx.x * kTgBytes;  // < len
     // the chunks this group owns: those whose first token lies in [base, base + kTgBytes)
     const uint32_t t_lo = tbl[blockIdx.x], t_hi = tbl[blockIdx.x + 1u];
@@ -1259,9 +1307,14 @@ __global__ __launch_bounds__(kTgThreads) void token_tiles(const uint8_t *__restr
     const auto request = [&](uint32_t c, uint32_t &i0, uint32_t &i1, uint32_t &nxt) {
         const uint32_t tok0 = c * kChunk + 2u * lane;
         if ((c + 1u) * kChunk < nt) {  // uniform: all 128 tokens and one behind them exist
-            const uint2 p = *reinterpret_cast<const uint2 *>(idx + tok0);  // idx is 16-byte aligned, tok0 even
-            i0 = p.x, i1 = p.y;
-            nxt = idx[(c + 1u) * kChunk];
+            // scalar base, the lane's pair at a constant offset; three words per lane: the pair and the structural behind
+            // it (the last lane's is the next chunk's first).  One vector load -- a scalar load of idx[128 (c + 1)] would
+            // sit in the same counter as the LDS reads of the evaluation, and every wait for those would wait for it
+            typedef uint32_t u32x3 __attribute__((ext_vector_type(3)));
+            typedef u32x3 u32x3_a4 __attribute__((aligned(4)));
+            const uint32_t *cp = idx + (uint64_t)c * kChunk;
+            const u32x3 p = *reinterpret_cast<const u32x3_a4 *>(cp + 2u * lane);
+            i0 = p.x, i1 = p.y, nxt = p.z;
         } else {
             i0 = idx[min(tok0, last)], i1 = idx[min(tok0 + 1u, last)];
             nxt = len32;
@@ -1339,14 +1392,14 @@ __global__ __launch_bounds__(kTgThreads) void token_tiles(const uint8_t *__restr
         const uint32_t tok0 = c * kChunk + 2u * lane;
         const bool allhere = (c + 1u) * kChunk < nt;  // uniform: 128 tokens and one behind them
         const bool have0 = allhere || tok0 < nt, have1 = allhere || tok0 + 1u < nt;
-        // the structural behind this lane's pair: the next lane's first token, the last lane's is the next chunk's first
-        const uint32_t i2 = (uint32_t)__builtin_amdgcn_update_dpp((int)nxt, (int)i0, 0x130, 0xF, 0xF, false);  // wave_shl:1
+        // the structural behind this lane's pair: loaded with it where all tokens exist, else the next lane's first token
+        const uint32_t i2 = allhere ? nxt : (uint32_t)__builtin_amdgcn_update_dpp((int)nxt, (int)i0, 0x130, 0xF, 0xF, false);  // wave_shl:1
         const uint32_t start0 = have0 ? i0 : 0u, start1 = have1 ? i1 : 0u;
         const uint32_t next1 = (allhere || tok0 + 2u < nt) ? i2 : len32;
         const uint32_t next0 = have1 ? start1 : len32;
         // uniform: the chunk's bytes -- through the byte at the next chunk's first structural -- are staged
         const uint32_t first_pos = (uint32_t)__builtin_amdgcn_readfirstlane((int)i0);
-        const uint32_t hi = allhere ? nxt + 1u : len32;
+        const uint32_t hi = allhere ? (uint32_t)__builtin_amdgcn_readlane((int)nxt, 63) + 1u : len32;
         const bool staged = hi <= base + kTgStage && hi - first_pos <= lds_limit && first_pos >= base;
         uint32_t e0 = 0, f0 = 0, c0 = 0, e1 = 0, f1 = 0, c1 = 0;
         if (kSpans && staged && allhere) {
@@ -1406,13 +1459,14 @@ __global__ __launch_bounds__(kTgThreads) void token_tiles(const uint8_t *__restr
             }
         }
         if (allhere && wide) {
+            const uint64_t cbase = (uint64_t)c * kChunk;  // scalar; the lane's pair at a constant offset
             if (kSpans) {  // write-once streams: non-temporal stores
                 typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
                 const u32x2 ee = {e0, e1};
-                __builtin_nontemporal_store(ee, reinterpret_cast<u32x2 *>(end + tok0));
-                __builtin_nontemporal_store((uint16_t)(f0 | (f1 << 8)), reinterpret_cast<uint16_t *>(flags + tok0));
+                __builtin_nontemporal_store(ee, reinterpret_cast<u32x2 *>(end + cbase) + lane);
+                __builtin_nontemporal_store((uint16_t)(f0 | (f1 << 8)), reinterpret_cast<uint16_t *>(flags + cbase) + lane);
             }
-            if (kFused) *reinterpret_cast<uint16_t *>(type + tok0) = (uint16_t)(c0 | (c1 << 8));
+            if (kFused) reinterpret_cast<uint16_t *>(type + cbase)[lane] = (uint16_t)(c0 | (c1 << 8));
         } else if (have0) {
             if (kSpans) {
                 end[tok0] = e0;
@@ -1428,19 +1482,15 @@ __global__ __launch_bounds__(kTgThreads) void token_tiles(const uint8_t *__restr
             }
         }
         if (kFused) {
-            // ordered reduction of the running-depth monoid over the chunk (see token_spans); the chunk's first token exists.
-            // '[' '{' are 5B 7B, ']' '}' are 5D 7D: one masked compare each, and the compare IS the ballot
+            // the chunk's bracket counts: '[' '{' are 5B 7B, ']' '}' are 5D 7D -- one masked compare each, the compare IS the
+            // ballot, the counts are scalar.  (The minimum and maximum of the running depth, which token_spans reduces
+            // per workgroup with two DPP chains, are folded in by apply_depth, which has every running value in a
+            // register anyway and time to spare: kNone / -kNone = "none from here".)
             const uint32_t k0 = have0 ? (c0 & 0xDFu) : 0u, k1 = have1 ? (c1 & 0xDFu) : 0u;
             const uint64_t up0 = __ballot(k0 == 0x5Bu), dn0 = __ballot(k0 == 0x5Du), up1 = __ballot(k1 == 0x5Bu), dn1 = __ballot(k1 == 0x5Du);
-            const auto add_below = [](uint64_t m, uint32_t acc) { return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, acc)); };
-            const int ups_below = (int)add_below(up1, add_below(up0, 0u)), downs_below = (int)add_below(dn1, add_below(dn0, 0u));
-            const int d0 = (int)(k0 == 0x5Bu) - (int)(k0 == 0x5Du), d1 = (int)(k1 == 0x5Bu) - (int)(k1 == 0x5Du);
-            const int r0 = ups_below - downs_below + d0, r1 = r0 + d1;  // after token 2t / 2t + 1
-            int mn, mx;
-            wave_min_max(min(r0, r1), max(r0, r1), mn, mx);
             if (lane == 0) {
                 const int ups = (int)__popcll(up0) + (int)__popcll(up1), downs = (int)__popcll(dn0) + (int)__popcll(dn1);
-                chunk_agg[c] = make_int4(ups - downs, mn, mx, ups);
+                chunk_agg[c] = make_int4(ups - downs, kNone, -kNone, ups);
             }
         }
         i0 = n_i0, i1 = n_i1, nxt = n_nxt;
