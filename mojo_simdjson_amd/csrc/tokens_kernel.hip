@@ -24,6 +24,7 @@
 
 #include "../../include/msj_stage1.h"
 #include "lane_math.h"
+#include "token_math.h"
 
 #ifndef MSJ_SPAN_ABLATE
 #define MSJ_SPAN_ABLATE 0  // diagnostic builds: 1 no token evaluation, 2 no depth aggregates, 3 no bit-plane transpose (wrong results)
@@ -1189,56 +1190,143 @@ constexpr uint32_t kChunk = 128;                       // tokens per wave iterat
 static_assert(kTgHaloBlocks <= 64 && (kTgHaloBlocks * 64) % 1024 == 0, "the halo is staged by one wave, 1 KiB per instruction");
 static_assert(kBlock % kChunk == 0, "a block of the depth pass is a whole number of chunks");
 
-// staged_token_fast written so that it compiles to straight-line code (the hot loop of token_tiles): every LDS read
-// is unconditional (the positions are inside the staged range whatever the token is), conditions are 0 / 1 words
-// combined with & and | -- `a && b` over an LDS read makes the compiler guard the read with a branch, and the short
-// blocks between such branches expose every LDS round trip.  Same results as staged_token_fast; nonzero return = one
-// round was not enough (the caller takes staged_token for that lane).
-__device__ __forceinline__ uint32_t pair_fast(const uint8_t *stage, const uint32_t *m_num, const uint32_t *m_flt, const uint32_t *m_bs,
-                                              const uint16_t *bs_cnt, const uint32_t *m_ink, uint32_t lo, uint32_t span, uint32_t len,
-                                              uint32_t c, uint32_t is_num, uint32_t rs, uint32_t rn, uint32_t &e_out, uint32_t &f_out) {
-    const uint32_t rlen = min(len - lo, span);  // end of the buffer within the staged range
-    const uint32_t is_str = c == '"';
-    // ---- string
-    const uint32_t vi = bits_before(m_ink, rn);
-    const uint32_t q = (uint32_t)max((int)rn - __clz(vi), (int)rs + 1);
-    const uint32_t more_ink = (uint32_t)(vi == 0u) & (uint32_t)(rn - rs > 33u);
-    const uint32_t bq = stage[q - 1u];
-    const uint32_t isq = (uint32_t)(q > rs + 1u) & (uint32_t)(bq == '"');
-    const uint32_t vb = ~bits_before(m_bs, q - 1u);  // backslashes right in front of that quote
-    const uint32_t closed = isq & (~(uint32_t)__clz(vb) & 1u);
-    const uint32_t more_bs = isq & (uint32_t)(vb == 0u);
-    const uint32_t b0 = rs + 1u, close = q - 1u;  // body = [b0, close)
-    const uint32_t esc = bs_before(m_bs, bs_cnt, close) != bs_before(m_bs, bs_cnt, b0);
-    const uint32_t far = closed & (uint32_t)((b0 >> 12) != (close >> 12));
-    const uint32_t lng = close - b0 > kSpanCap;
-    const uint32_t f_str = MSJ_SPAN_STRING | (closed ? (lng ? MSJ_SPAN_LONG : (esc ? MSJ_SPAN_ESCAPED : 0u)) : MSJ_SPAN_OPEN);
-    const uint32_t e_str = closed ? lo + close : len;
-    // ---- number: parse_number's scan (include/generic/number_parsing.mojo:41-59), see staged_token
-    const uint32_t stop = min(rs + 1u + kSpanCap, rlen);
-    const uint32_t p0 = rs + (uint32_t)(c == '-');
-    const uint32_t wn = ~bits_at(m_num, p0);
-    const uint32_t p = min(p0 + min((uint32_t)(__ffs(wn) - 1), 32u), stop);
-    const uint32_t more_num = (uint32_t)(wn == 0u) & (uint32_t)(p0 + 32u < stop);
-    const uint32_t ends = (uint32_t)(p < stop) | (uint32_t)(lo + p == len);
-    const uint32_t bp = stage[p];  // p <= span: the array has 16 bytes behind the range
-    const uint32_t ch = p < rlen ? bp : 0x20u;
-    const uint32_t flt = ends & ((uint32_t)(ch == '.') | (uint32_t)((ch | 0x20u) == 'e'));
-    const uint32_t wf = bits_at(m_flt, p);
-    const uint32_t bad = ends & (flt ^ 1u) & (uint32_t)(p < rlen) & (~wf & 1u);
-    const uint32_t pe = flt ? min(p + min((uint32_t)(__ffs(wf) - 1), 32u), stop) : p;
-    const uint32_t more_flt = flt & (uint32_t)(wf == 0u) & (uint32_t)(p + 32u < stop);
-    const uint32_t no_end = (uint32_t)(pe == stop) & (uint32_t)(lo + stop < len);
-    const uint32_t f_num = MSJ_SPAN_NUMBER | (flt ? MSJ_SPAN_FLOAT : 0u) | (bad ? MSJ_SPAN_BAD : 0u);
-    const uint32_t e_num = lo + pe;
-    e_out = is_str ? e_str : (is_num ? e_num : 0u);
-    f_out = is_str ? f_str : (is_num ? f_num : 0u);
-    return is_str ? (more_ink | more_bs | far) : (is_num & (more_num | more_flt | no_end));
-}
 // '"', '-' or a digit, as a 0 / 1 word without a compare chain: bit (c - 0x22) of a 24-bit table
 __device__ __forceinline__ uint32_t starts_scalar(uint32_t c) {
     const uint32_t t = c - 0x22u;
     return (uint32_t)(t < 24u) & (0x00FFC801u >> (t & 31u));
+}
+
+// ---- token evaluation of token_tiles.  Its bitmaps (one bit per staged byte, layout as above):
+//   m_num  digit                      m_flt  structural or blank (the reference's table: where a float ends)
+//   m_dot  . e E                      m_ink  not blank
+//   m_q    UNESCAPED quote: the escape scanner of stage 1 (json_escape_scanner.mojo:18-45) run per block with the
+//          carries resolved across the lanes of the tile's wave, the carry into a tile from the bytes in front of it
+//   m_e    unescaped quote with a backslash between it and the unescaped quote in front of it (or the start of its
+//          tile): (backslash + ~quote) & quote -- the carry of the addition runs from a backslash through everything
+//          that is not a quote and is absorbed by the next quote -- again with the carries resolved across the lanes;
+//          co[t] = that carry at the end of tile t ("a backslash since the tile's last quote").
+// With them a string token needs three windows that all END at the next structural (known before anything is read:
+// one LDS round trip): the closing quote is the last non-blank byte in front of the next structural (top set bit of
+// the "ink" window), the string is closed iff the same bit of the m_q window is set, and its body holds a backslash
+// iff the same bit of the m_e window is set (or, where the body crosses into the next tile, co[] of the opening
+// quote's tile is).  A number needs three windows that all START at its first digit.  Both are evaluated for every
+// lane (a wave holds strings and numbers anyway), without a branch.  Nonzero return: a window came up short (32
+// blanks in front of the next structural, 32 digits, no end of a float within the window, the last bytes of the
+// staged range): the lane takes tile_token_slow.
+struct TileMaps {
+    const uint8_t *stage;
+    const uint32_t *m_num, *m_flt, *m_dot, *m_ink, *m_q, *m_e, *co;
+};
+__device__ __forceinline__ uint32_t pair_fast(const TileMaps &t, uint32_t lo, uint32_t span, uint32_t len, uint32_t c, uint32_t is_num,
+                                              uint32_t rs, uint32_t rn, uint32_t &e_out, uint32_t &f_out) {
+    const uint32_t rlen = min(len - lo, span);  // end of the buffer within the staged range
+    const uint32_t is_str = c == '"';
+    // ---- string
+    const uint32_t vi = bits_before(t.m_ink, rn), vq = bits_before(t.m_q, rn), ve = bits_before(t.m_e, rn);
+    const uint32_t cob = t.co[rs >> 12];
+    const uint32_t z = (uint32_t)__clz(vi);                                       // 32 for an empty window
+    const uint32_t q = (uint32_t)max((int)rn - (int)z, (int)rs + 1);              // behind the last non-blank byte
+    const uint32_t more_ink = (uint32_t)(vi == 0u) & (uint32_t)(rn - rs > 33u);
+    const uint32_t top = z & 31u;                                                 // (an empty window: closed = 0 below)
+    const uint32_t closed = (uint32_t)(rn - z > rs + 1u) & (uint32_t)(z < 32u) & ((vq << top) >> 31);
+    const uint32_t close = q - 1u, b0 = rs + 1u;                                  // body = [b0, close)
+    const uint32_t far = (rs >> 12) != (close >> 12);
+    const uint32_t esc = ((ve << top) >> 31) | (far & cob);
+    const uint32_t lng = close - b0 > kSpanCap;
+    const uint32_t f_str = MSJ_SPAN_STRING | (closed ? (lng ? MSJ_SPAN_LONG : (esc ? MSJ_SPAN_ESCAPED : 0u)) : MSJ_SPAN_OPEN);
+    const uint32_t e_str = closed ? lo + close : len;
+    // ---- number: parse_number's scan (include/generic/number_parsing.mojo:41-59), see staged_token
+    const uint32_t p0 = rs + (uint32_t)(c == '-');
+    const uint32_t wn = ~bits_at(t.m_num, p0), wf = bits_at(t.m_flt, p0), wd = bits_at(t.m_dot, p0);
+    const uint32_t nd = min((uint32_t)(__ffs(wn) - 1), 32u);                      // digits
+    const uint32_t sh = nd & 31u;
+    const uint32_t flt = (wd >> sh) & 1u;                                         // the byte behind them is . e E
+    const uint32_t wf2 = wf >> sh;                                                // structural or blank, from that byte on
+    const uint32_t bad = ((flt | wf2) & 1u) ^ 1u;                                   // neither: the reference's NUMBER_ERROR
+    const uint32_t fe = min((uint32_t)(__ffs(wf2) - 1), 32u);
+    const uint32_t pe = p0 + nd + (flt ? fe : 0u);
+    const uint32_t short_num = (uint32_t)(nd == 32u) | (flt & (uint32_t)(wf2 == 0u)) | (uint32_t)(rs + 80u > rlen);
+    const uint32_t f_num = MSJ_SPAN_NUMBER | (flt ? MSJ_SPAN_FLOAT : 0u) | (bad ? MSJ_SPAN_BAD : 0u);
+    e_out = is_str ? e_str : (is_num ? lo + pe : 0u);
+    f_out = is_str ? f_str : (is_num ? f_num : 0u);
+    return is_str ? more_ink : (is_num & short_num);
+}
+
+// One token, any length, from the same maps (rare lanes; the chunks at the end of the input): staged_token with the
+// string branch on m_q / m_e.  Returns true when the staged bytes were not enough (see staged_token).
+__device__ __forceinline__ bool tile_token_slow(const TileMaps &t, uint32_t lo, uint32_t span, uint32_t len, uint32_t c, uint32_t rs,
+                                             uint32_t rn, uint32_t &e_out, uint32_t &f_out) {
+    const uint32_t rlen = min(len - lo, span);
+    uint32_t e = 0, f = 0;
+    if (c == '"') {
+        f = MSJ_SPAN_STRING;
+        uint32_t q = rs + 1u;
+        if (rn > rs + 1u) {
+            uint32_t tt = rn;
+            for (;;) {  // one round unless more than 32 blanks stand in front of the next structural
+                const uint32_t d = tt - (rs + 1u);
+                uint32_t v = bits_before(t.m_ink, tt);
+                if (d < 32u) v &= ~0u << (32u - d);
+                if (v) {
+                    q = tt - __clz(v);
+                    break;
+                }
+                if (d <= 32u) break;
+                tt -= 32u;
+            }
+        }
+        const uint32_t close = q - 1u, b0 = rs + 1u;
+        const bool closed = q > rs + 1u && (bits_at(t.m_q, close) & 1u);
+        if (closed) {
+            if (close - b0 > kSpanCap) {
+                f |= MSJ_SPAN_LONG;
+            } else if ((bits_at(t.m_e, close) & 1u) | (((rs >> 12) != (close >> 12)) ? t.co[rs >> 12] : 0u)) {
+                f |= MSJ_SPAN_ESCAPED;
+            }
+            e = lo + close;
+        } else {
+            f |= MSJ_SPAN_OPEN;  // only the last token can be like this (stage 1 reports UNCLOSED_STRING)
+            e = len;
+        }
+    } else if (c == '-' || c - '0' < 10u) {
+        f = MSJ_SPAN_NUMBER;
+        const uint32_t stop = (rs + 1u + kSpanCap < rlen) ? rs + 1u + kSpanCap : rlen;
+        uint32_t p = rs + (c == '-' ? 1u : 0u);
+        while (p < stop) {
+            const uint32_t run = ~bits_at(t.m_num, p);
+            if (run) {
+                p += __ffs(run) - 1u;
+                break;
+            }
+            p += 32u;
+        }
+        if (p > stop) p = stop;
+        if (p < stop || lo + p == len) {
+            if (p < rlen && (bits_at(t.m_dot, p) & 1u)) {
+                f |= MSJ_SPAN_FLOAT;
+                while (p < stop) {
+                    const uint32_t hit = bits_at(t.m_flt, p);
+                    if (hit) {
+                        p += __ffs(hit) - 1u;
+                        break;
+                    }
+                    p += 32u;
+                }
+                if (p > stop) p = stop;
+            } else if (p < rlen && !(bits_at(t.m_flt, p) & 1u)) {
+                f |= MSJ_SPAN_BAD;
+            }
+        }
+        if (p == stop && lo + stop < len) {
+            if (stop < rs + 1u + kSpanCap) return true;   // not the cap: the staged range ended
+            f = (f & ~MSJ_SPAN_BAD) | MSJ_SPAN_LONG;      // kSpanCap characters and still no end
+        } else {
+            e = lo + p;
+        }
+    }
+    e_out = e;
+    f_out = f;
+    return false;
 }
 
 // tbl[g] = number of structurals in front of byte g * kTgBytes (g = 0 .. ngroups; tbl[ngroups] = n): a binary search
@@ -1273,15 +1361,24 @@ __device__ __noinline__ uint4 chunk16_or_blanks(const uint8_t *buf, uint64_t pos
     return make_uint4(w[0], w[1], w[2], w[3]);
 }
 
+// carries into the lanes of a wave from per-lane generate / propagate ballots and the carry into lane 0: bit l of the
+// result = carry into lane l; *out = carry out of lane 63  (the 64-bit addition does the look-ahead)
+__device__ __forceinline__ uint64_t lane_carries(uint64_t gen, uint64_t prop, uint32_t carry_in, uint32_t *out) {
+    const uint64_t a = gen | prop, b = gen;
+    const uint64_t s = a + b + carry_in;
+    *out = (uint32_t)(((a & b) | ((a | b) & ~s)) >> 63);
+    return s ^ a ^ b;
+}
+
 template <bool kFused, bool kSpans>
 __global__ __launch_bounds__(kTgThreads) void token_tiles(const uint8_t *__restrict__ buf, uint64_t len, const uint32_t *__restrict__ idx,
                                                          uint64_t n, uint32_t *__restrict__ end, uint8_t *__restrict__ flags, uint32_t lds_limit,
                                                          uint8_t *__restrict__ type, int4 *__restrict__ chunk_agg, uint32_t *__restrict__ fix,
                                                          uint32_t fix_cap, const uint32_t *__restrict__ tbl) {
-    __shared__ __attribute__((aligned(16))) uint8_t stage[kTgStage + 16];  // a number may be asked for the byte behind the range
-    __shared__ __attribute__((aligned(8))) uint32_t m_num[kTgMapWords], m_flt[kTgMapWords], m_bs[kTgMapWords], m_ink[kTgMapWords];
-    __shared__ __attribute__((aligned(4))) uint16_t bs_cnt[kTgMapWords];  // set bits of m_bs in front of each word, from the wave's first block
-    __shared__ uint32_t bs_blocks[2 * kTgWaves + 2];                      // bit b: block b of the range holds a backslash
+    __shared__ __attribute__((aligned(16))) uint8_t stage[kTgStage + 16];
+    __shared__ __attribute__((aligned(8))) uint32_t m_num[kTgMapWords], m_flt[kTgMapWords], m_dot[kTgMapWords], m_ink[kTgMapWords],
+        m_q[kTgMapWords], m_e[kTgMapWords];
+    __shared__ uint32_t co[kTgWaves + 1];
     const uint32_t nt = (uint32_t)n, len32 = (uint32_t)len;  // n < 2^31, len < 2^32 (the entry points check)
     // the wave index as a SCALAR: everything derived from it (the chunk, its addresses, the loop) is then scalar code
     const uint32_t lane = threadIdx.x & 63u, wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -1301,6 +1398,12 @@ __global__ __launch_bounds__(kTgThreads) void token_tiles(const uint8_t *__restr
         if (wave == kTgTiles && k >= kHaloInsts) break;  // uniform
         const uint64_t pos = (uint64_t)base + region + 1024u * k;
         v[k] = tail ? chunk16_or_blanks(buf, pos, len) : *reinterpret_cast<const uint4 *>(buf + pos);
+    }
+    // the byte in front of the wave's part, 64 of them: what its first byte's escape state depends on
+    uint32_t wb = 0;
+    if (kSpans && wave > 0) {
+        const uint64_t pos = (uint64_t)base + wave * 4096u - 64u + lane;
+        wb = buf[pos < len ? pos : len - 1u];  // past the buffer: whatever, no tile behind it holds anything but blanks
     }
     // this wave's first chunk: its indices are on their way while the bytes are classified
     const uint32_t last = nt - 1u;
@@ -1335,9 +1438,26 @@ __global__ __launch_bounds__(kTgThreads) void token_tiles(const uint8_t *__restr
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        uint64_t has_bs = 0;
-        uint32_t bs_lo = 0, bs_all = 0;  // backslashes in the low word / in all of this lane's block
-        if (j < kTgBlocks) {
+        // the carry into the wave's first byte: the parity of the run of backslashes that ends in front of it.  A run
+        // that fills the 64-byte window goes on in the window in front -- down to the start of the range at most: a run
+        // that began in front of the range belongs to a string that did, i.e. to a token of an earlier group
+        uint32_t e_in = 0;
+        if (wave > 0) {
+            uint64_t WB = __ballot(wb == 0x5Cu);
+            uint32_t back = 64u, run = 0;
+            while (WB == ~0ull && back < wave * 4096u) {  // uniform, practically never
+                run += 64u;
+                back += 64u;
+                const uint64_t pos = (uint64_t)base + wave * 4096u - back + lane;
+                WB = __ballot(buf[pos < len ? pos : len - 1u] == 0x5Cu);
+            }
+            e_in = (run + msj::top_run(WB)) & 1u;
+        }
+        uint64_t q_mask = 0, bs = 0;
+        msj::SpanClasses cl = {0, ~0ull, 0, ~0ull};
+        msj::TileClasses tc = {0, 0};
+        const bool own = j < kTgBlocks;
+        if (own) {
             uint32_t x[16];
 #pragma unroll
             for (int q = 0; q < 4; q++) {
@@ -1346,43 +1466,51 @@ __global__ __launch_bounds__(kTgThreads) void token_tiles(const uint8_t *__restr
             }
             uint64_t pl[8];
             msj::bitplanes(x, pl);
-            const msj::SpanClasses cl = msj::span_classes(pl);
-            const uint32_t w = kSpanMapFront + 2u * j;
-            *reinterpret_cast<uint2 *>(m_num + w) = make_uint2((uint32_t)cl.digit, (uint32_t)(cl.digit >> 32));
-            *reinterpret_cast<uint2 *>(m_flt + w) = make_uint2((uint32_t)cl.sow, (uint32_t)(cl.sow >> 32));
-            *reinterpret_cast<uint2 *>(m_bs + w) = make_uint2((uint32_t)cl.backslash, (uint32_t)(cl.backslash >> 32));
-            *reinterpret_cast<uint2 *>(m_ink + w) = make_uint2((uint32_t)~cl.blank, (uint32_t)(~cl.blank >> 32));
-            has_bs = cl.backslash;
-            bs_lo = __popc((uint32_t)cl.backslash);
-            bs_all = bs_lo + __popc((uint32_t)(cl.backslash >> 32));
-        } else if (j < kTgBlocks + 2u) {  // zero words behind the maps
-            const uint32_t w = kSpanMapFront + 2u * j;
-            *reinterpret_cast<uint2 *>(m_num + w) = make_uint2(0, 0);
-            *reinterpret_cast<uint2 *>(m_flt + w) = make_uint2(0, 0);
-            *reinterpret_cast<uint2 *>(m_bs + w) = make_uint2(0, 0);
-            *reinterpret_cast<uint2 *>(m_ink + w) = make_uint2(0, 0);
+            cl = msj::span_classes(pl);
+            tc = msj::tile_classes(pl);
+            bs = cl.backslash;
         }
-        if (j == kTgThreads - 1u) {  // ... and in front of them
+        {   // unescaped quotes: a block's last run of backslashes decides the carry into the next block (odd: escaped),
+            // a block of 64 backslashes hands its own carry on
+            const uint32_t r = msj::top_run(bs);
+            uint32_t unused;
+            const uint64_t carries = lane_carries(__ballot(r < 64u && (r & 1u)), __ballot(r == 64u), e_in, &unused);
+            uint32_t lane_out;
+            const uint64_t escaped = msj::escaped_mask(bs, (uint32_t)(carries >> lane) & 1u, &lane_out);
+            q_mask = tc.quote & ~escaped;
+        }
+        uint64_t e_mask;
+        {   // quotes with a backslash since the quote in front of them: (backslash + ~quote) & quote, carries across lanes
+            const uint64_t m = ~q_mask;
+            const uint64_t s0 = bs + m;
+            uint32_t tile_out;
+            const uint64_t carries = lane_carries(__ballot(s0 < bs), __ballot(q_mask == 0ull), 0u, &tile_out);
+            e_mask = (s0 + ((carries >> lane) & 1ull)) & q_mask;
+            if (lane == 0) co[wave] = tile_out;
+        }
+        if (j < kTgBlocks + 2u) {  // the lanes behind the last block write the zero words behind the maps
+            const uint32_t w = kSpanMapFront + 2u * j;
+            const uint64_t z = own ? ~0ull : 0ull;
+            *reinterpret_cast<uint2 *>(m_num + w) = make_uint2((uint32_t)(cl.digit & z), (uint32_t)((cl.digit & z) >> 32));
+            *reinterpret_cast<uint2 *>(m_flt + w) = make_uint2((uint32_t)(cl.sow & z), (uint32_t)((cl.sow & z) >> 32));
+            *reinterpret_cast<uint2 *>(m_dot + w) = make_uint2((uint32_t)(tc.dote & z), (uint32_t)((tc.dote & z) >> 32));
+            *reinterpret_cast<uint2 *>(m_ink + w) = make_uint2((uint32_t)(~cl.blank & z), (uint32_t)((~cl.blank & z) >> 32));
+            *reinterpret_cast<uint2 *>(m_q + w) = make_uint2((uint32_t)(q_mask & z), (uint32_t)((q_mask & z) >> 32));
+            *reinterpret_cast<uint2 *>(m_e + w) = make_uint2((uint32_t)(e_mask & z), (uint32_t)((e_mask & z) >> 32));
+        }
+        if (j == kTgThreads - 1u) {  // ... and the ones in front of them
             *reinterpret_cast<uint2 *>(m_num) = make_uint2(0, 0);
             *reinterpret_cast<uint2 *>(m_flt) = make_uint2(0, 0);
-            *reinterpret_cast<uint2 *>(m_bs) = make_uint2(0, 0);
+            *reinterpret_cast<uint2 *>(m_dot) = make_uint2(0, 0);
             *reinterpret_cast<uint2 *>(m_ink) = make_uint2(0, 0);
-            bs_blocks[2 * kTgWaves] = 0;
-            bs_blocks[2 * kTgWaves + 1] = 0;
-            *reinterpret_cast<uint32_t *>(bs_cnt) = 0;
-        }
-        {   // all lanes: blocks in front of this lane's, within the wave (= within its 4 KiB)
-            const uint32_t upto = wave_incl_sum(bs_all) - bs_all;
-            if (j < kTgBlocks + 2u) *reinterpret_cast<uint32_t *>(bs_cnt + kSpanMapFront + 2u * j) = upto | ((upto + bs_lo) << 16);
-        }
-        const uint64_t bsb = __ballot(has_bs != 0);
-        if (lane == 0) {
-            bs_blocks[2 * wave] = (uint32_t)bsb;
-            bs_blocks[2 * wave + 1] = (uint32_t)(bsb >> 32);
+            *reinterpret_cast<uint2 *>(m_q) = make_uint2(0, 0);
+            *reinterpret_cast<uint2 *>(m_e) = make_uint2(0, 0);
+            co[kTgWaves] = 0;
         }
     }
     __syncthreads();
 
+    const TileMaps maps = {stage, m_num, m_flt, m_dot, m_ink, m_q, m_e, co};
     const bool wide = (reinterpret_cast<uintptr_t>(end) & 7u) == 0 &&
                       ((reinterpret_cast<uintptr_t>(flags) | reinterpret_cast<uintptr_t>(type)) & 1u) == 0;  // uniform
     for (; c < c_hi; c += kTgWaves) {
@@ -1411,15 +1539,11 @@ __global__ __launch_bounds__(kTgThreads) void token_tiles(const uint8_t *__restr
             const uint32_t s0 = starts_scalar(c0), s1 = starts_scalar(c1);
             const uint32_t cs = s0 ? c0 : c1, rs = s0 ? rs0 : rs1, rn = s0 ? rs1 : rn1;
             uint32_t e, f;
-            const uint32_t again = pair_fast(stage, m_num, m_flt, m_bs, bs_cnt, m_ink, base, kTgStage, len32, cs, s0 | s1, rs, rn, e, f);
-            if (__ballot((again | (s0 & s1)) != 0u) != 0ull) {  // rare: a window came up empty, or two scalars in a row
-                if (again && staged_token(stage, m_num, m_flt, m_bs, m_ink, bs_blocks, (uint64_t)base, kTgStage, len, cs, (uint64_t)base + rs,
-                                          (uint64_t)base + rn, e, f))
-                    fix_later(fix, fix_cap, tok0 + (s0 ? 0u : 1u), e, f);
+            const uint32_t again = pair_fast(maps, base, kTgStage, len32, cs, s0 | s1, rs, rn, e, f);
+            if (__ballot((again | (s0 & s1)) != 0u) != 0ull) {  // rare: a window came up short, or two scalars in a row
+                if (again && tile_token_slow(maps, base, kTgStage, len32, cs, rs, rn, e, f)) fix_later(fix, fix_cap, tok0 + (s0 ? 0u : 1u), e, f);
                 if (s0 & s1) {
-                    if (!staged_token_fast(stage, m_num, m_flt, m_bs, bs_cnt, m_ink, base, kTgStage, len32, c1, rs1, rn1, e1, f1) &&
-                        staged_token(stage, m_num, m_flt, m_bs, m_ink, bs_blocks, (uint64_t)base, kTgStage, len, c1, (uint64_t)i1, (uint64_t)i2, e1, f1))
-                        fix_later(fix, fix_cap, tok0 + 1u, e1, f1);
+                    if (tile_token_slow(maps, base, kTgStage, len32, c1, rs1, rn1, e1, f1)) fix_later(fix, fix_cap, tok0 + 1u, e1, f1);
                 }
             }
             e0 = s0 ? e : 0u, f0 = s0 ? f : 0u;
@@ -1433,28 +1557,12 @@ __global__ __launch_bounds__(kTgThreads) void token_tiles(const uint8_t *__restr
                 if (kSpans) span_of(FromGlobal{buf, len}, (uint64_t)start1, (uint64_t)next1, len, e1, f1);
                 if (kFused) c1 = buf[start1];
             }
-        } else if (!kSpans) {  // the type bytes only
-            if (have0) {
-                c0 = stage[start0 - base];
-                c1 = have1 ? (uint32_t)stage[start1 - base] : 0u;
-            }
-        } else if (have0) {
-            const uint32_t rs0 = start0 - base, rn0 = next0 - base;
-            const uint32_t rs1 = have1 ? start1 - base : rs0, rn1 = have1 ? next1 - base : rn0;
-            c0 = stage[rs0];
-            c1 = have1 ? (uint32_t)stage[rs1] : 0u;
-            const bool s0 = c0 == '"' || c0 == '-' || c0 - '0' < 10u;            // a string or a number: something to work out
-            const bool s1 = have1 && (c1 == '"' || c1 == '-' || c1 - '0' < 10u);
-            const uint32_t cs = s0 ? c0 : c1, rs = s0 ? rs0 : rs1, rn = s0 ? rn0 : rn1;
-            uint32_t e, f;
-            if (!staged_token_fast(stage, m_num, m_flt, m_bs, bs_cnt, m_ink, base, kTgStage, len32, cs, rs, rn, e, f) &&
-                staged_token(stage, m_num, m_flt, m_bs, m_ink, bs_blocks, (uint64_t)base, kTgStage, len, cs, (uint64_t)base + rs, (uint64_t)base + rn, e, f))
-                fix_later(fix, fix_cap, tok0 + (s0 ? 0u : 1u), e, f);
-            e0 = s0 ? e : 0u, f0 = s0 ? f : 0u;
-            e1 = s0 ? 0u : e, f1 = s0 ? 0u : f;
-            if (s0 && s1) {  // two scalars in a row (not a valid document)
-                if (!staged_token_fast(stage, m_num, m_flt, m_bs, bs_cnt, m_ink, base, kTgStage, len32, c1, rs1, rn1, e1, f1) &&
-                    staged_token(stage, m_num, m_flt, m_bs, m_ink, bs_blocks, (uint64_t)base, kTgStage, len, c1, (uint64_t)start1, (uint64_t)next1, e1, f1))
+        } else if (have0) {  // staged: the type bytes only (kSpans = false), or the chunk at the end of the index
+            c0 = stage[start0 - base];
+            c1 = have1 ? (uint32_t)stage[start1 - base] : 0u;
+            if (kSpans) {
+                if (tile_token_slow(maps, base, kTgStage, len32, c0, start0 - base, next0 - base, e0, f0)) fix_later(fix, fix_cap, tok0, e0, f0);
+                if (have1 && tile_token_slow(maps, base, kTgStage, len32, c1, start1 - base, next1 - base, e1, f1))
                     fix_later(fix, fix_cap, tok0 + 1u, e1, f1);
             }
         }

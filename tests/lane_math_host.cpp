@@ -5,6 +5,7 @@
 // NOT part of the product: the product path is the HIP kernel.
 #include <cstring>
 #include "../mojo_simdjson_amd/csrc/lane_math.h"
+#include "../mojo_simdjson_amd/csrc/token_math.h"
 
 extern "C" {
 
@@ -65,6 +66,16 @@ void lane_span_classes(const uint8_t *blk64, uint64_t *out4) {
     msj::bitplanes(x, p);
     msj::SpanClasses c = msj::span_classes(p);
     out4[0] = c.digit; out4[1] = c.sow; out4[2] = c.backslash; out4[3] = c.blank;
+}
+
+// quote, dote masks of one 64-byte block (the tile kernel's extra classes)
+void lane_tile_classes(const uint8_t *blk64, uint64_t *out2) {
+    uint32_t x[16];
+    std::memcpy(x, blk64, 64);
+    uint64_t p[8];
+    msj::bitplanes(x, p);
+    msj::TileClasses c = msj::tile_classes(p);
+    out2[0] = c.quote; out2[1] = c.dote;
 }
 
 uint32_t lane_top_run(uint64_t m) { return msj::top_run(m); }

@@ -67,6 +67,7 @@ def test_bitplanes_exhaustive(lane):
 def test_span_classes_exhaustive(lane):
     """the token-span kernel's classes against the reference's tables, every byte value at every position parity"""
     lane.lane_span_classes.argtypes = [ctypes.c_char_p, ctypes.POINTER(ctypes.c_uint64)]
+    lane.lane_tile_classes.argtypes = [ctypes.c_char_p, ctypes.POINTER(ctypes.c_uint64)]
     sow = set(b"\t\n\r ,:[]{}")
     blank = set(b"\t\n\r ")
     want = lambda b, cls: sum(1 << i for i in range(64) if b[i] in cls)
@@ -81,6 +82,10 @@ def test_span_classes_exhaustive(lane):
         assert out[1] == want(b, sow)
         assert out[2] == want(b, set(b"\\"))
         assert out[3] == want(b, blank)
+        out2 = (ctypes.c_uint64 * 2)()
+        lane.lane_tile_classes(b, out2)
+        assert out2[0] == want(b, set(b'"'))
+        assert out2[1] == want(b, set(b".eE"))
 
 
 def test_small_helpers(lane):
