@@ -245,9 +245,8 @@ def main():
     # ---- expected result: the oracle's indices of ONE unit (checker only, outside every timed window)
     u_idx = unit_indices(unit)
     unit_n = int(u_idx.size)
-    cpu = None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        cpu = cpu_baseline(unit)  # timed CPU baseline on rank 0 at N = 1 only
+    cpu = None  # the timed CPU baseline runs BEHIND the GPU windows (below): ten seconds of it in front of them would
+    #             put the GPU into a deeper idle state than anything a caller's process does before its first parse
 
     cap = int(shard_len * 0.75) + 1024  # index slots for this shard (density < 0.75 for every workload here)
     d_idx = torch.empty(cap, dtype=torch.int32, device=device)
@@ -355,6 +354,9 @@ def main():
     stats1 = sh.stats() if sh is not None else None
     if last_timed is not None:
         last = last_timed
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        torch.cuda.synchronize()
+        cpu = cpu_baseline(unit)  # timed CPU baseline on rank 0 at N = 1 only; the GPU is idle meanwhile
 
     # ---- result check (outside the timed region)
     if world == 1:

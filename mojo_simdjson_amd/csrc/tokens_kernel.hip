@@ -1221,9 +1221,17 @@ __device__ __forceinline__ uint32_t pair_fast(const TileMaps &t, uint32_t lo, ui
                                               uint32_t rs, uint32_t rn, uint32_t &e_out, uint32_t &f_out) {
     const uint32_t rlen = min(len - lo, span);  // end of the buffer within the staged range
     const uint32_t is_str = c == '"';
-    // ---- string
-    const uint32_t vi = bits_before(t.m_ink, rn), vq = bits_before(t.m_q, rn), ve = bits_before(t.m_e, rn);
-    const uint32_t cob = t.co[rs >> 12];
+    // every read is issued here, before anything is looked at, and pinned: left to itself the compiler moves the
+    // reads whose results only one kind of token needs behind a branch on that kind -- a second LDS round trip
+    const uint32_t p0 = rs + (uint32_t)(c == '-');
+    const uint32_t wa = (rn >> 5) + kSpanMapFront - 1u, wb = (p0 >> 5) + kSpanMapFront;
+    uint32_t i_lo = t.m_ink[wa], i_hi = t.m_ink[wa + 1u], q_lo = t.m_q[wa], q_hi = t.m_q[wa + 1u], e_lo = t.m_e[wa], e_hi = t.m_e[wa + 1u];
+    uint32_t n_lo = t.m_num[wb], n_hi = t.m_num[wb + 1u], f_lo = t.m_flt[wb], f_hi = t.m_flt[wb + 1u], d_lo = t.m_dot[wb], d_hi = t.m_dot[wb + 1u];
+    uint32_t cob = t.co[rs >> 12];
+    asm volatile("" : "+v"(i_lo), "+v"(i_hi), "+v"(q_lo), "+v"(q_hi), "+v"(e_lo), "+v"(e_hi), "+v"(cob));
+    asm volatile("" : "+v"(n_lo), "+v"(n_hi), "+v"(f_lo), "+v"(f_hi), "+v"(d_lo), "+v"(d_hi));
+    // ---- string: the windows end at the next structural (bit 31 = the byte in front of it)
+    const uint32_t vi = __funnelshift_r(i_lo, i_hi, rn & 31u), vq = __funnelshift_r(q_lo, q_hi, rn & 31u), ve = __funnelshift_r(e_lo, e_hi, rn & 31u);
     const uint32_t z = (uint32_t)__clz(vi);                                       // 32 for an empty window
     const uint32_t q = (uint32_t)max((int)rn - (int)z, (int)rs + 1);              // behind the last non-blank byte
     const uint32_t more_ink = (uint32_t)(vi == 0u) & (uint32_t)(rn - rs > 33u);
@@ -1235,9 +1243,9 @@ __device__ __forceinline__ uint32_t pair_fast(const TileMaps &t, uint32_t lo, ui
     const uint32_t lng = close - b0 > kSpanCap;
     const uint32_t f_str = MSJ_SPAN_STRING | (closed ? (lng ? MSJ_SPAN_LONG : (esc ? MSJ_SPAN_ESCAPED : 0u)) : MSJ_SPAN_OPEN);
     const uint32_t e_str = closed ? lo + close : len;
-    // ---- number: parse_number's scan (include/generic/number_parsing.mojo:41-59), see staged_token
-    const uint32_t p0 = rs + (uint32_t)(c == '-');
-    const uint32_t wn = ~bits_at(t.m_num, p0), wf = bits_at(t.m_flt, p0), wd = bits_at(t.m_dot, p0);
+    // ---- number: parse_number's scan (include/generic/number_parsing.mojo:41-59), see staged_token; the windows start
+    //      at its first digit
+    const uint32_t wn = ~__funnelshift_r(n_lo, n_hi, p0 & 31u), wf = __funnelshift_r(f_lo, f_hi, p0 & 31u), wd = __funnelshift_r(d_lo, d_hi, p0 & 31u);
     const uint32_t nd = min((uint32_t)(__ffs(wn) - 1), 32u);                      // digits
     const uint32_t sh = nd & 31u;
     const uint32_t flt = (wd >> sh) & 1u;                                         // the byte behind them is . e E
@@ -1370,6 +1378,17 @@ __device__ __forceinline__ uint64_t lane_carries(uint64_t gen, uint64_t prop, ui
     return s ^ a ^ b;
 }
 
+#ifdef MSJ_TILE_STAMPS
+// diagnostic build only (scripts/tile_stamps.py): six 100 MHz real-time stamps per wave of token_tiles
+__device__ unsigned long long *g_tile_stamps = nullptr;
+#define MSJ_TSTAMP(k)                                                                                              \
+    do {                                                                                                           \
+        if (lane == 0 && g_tile_stamps) g_tile_stamps[((uint64_t)blockIdx.x * kTgWaves + wave) * 8 + (k)] = __builtin_amdgcn_s_memrealtime(); \
+    } while (0)
+#else
+#define MSJ_TSTAMP(k) do {} while (0)
+#endif
+
 template <bool kFused, bool kSpans>
 __global__ __launch_bounds__(kTgThreads) void token_tiles(const uint8_t *__restrict__ buf, uint64_t len, const uint32_t *__restrict__ idx,
                                                          uint64_t n, uint32_t *__restrict__ end, uint8_t *__restrict__ flags, uint32_t lds_limit,
@@ -1383,7 +1402,11 @@ __global__ __launch_bounds__(kTgThreads) void token_tiles(const uint8_t *__restr
     // the wave index as a SCALAR: everything derived from it (the chunk, its addresses, the loop) is then scalar code
     const uint32_t lane = threadIdx.x & 63u, wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const uint32_t base = blockIdx.x * kTgBytes;  // < len
-    // the chunks this group owns: those whose first token lies in [base, base + kTgBytes)
+    MSJ_TSTAMP(0);
+    // the chunks this group owns: those whose first token lies in [base, base + kTgBytes).  (Asking for the bytes before
+    // the table entry has arrived -- the entry as a vector load, looked at behind the byte loads -- was measured: the
+    // workgroup's first 2.5 us shrink, the kernel as a whole got 13 % slower, scripts/tile_stamps.py and
+    // profiles/r03/prep_tiles_history.txt.)
     const uint32_t t_lo = tbl[blockIdx.x], t_hi = tbl[blockIdx.x + 1u];
     const uint32_t c_lo = (t_lo + kChunk - 1u) / kChunk, c_hi = (t_hi + kChunk - 1u) / kChunk;
     if (c_lo >= c_hi) return;  // uniform: none (sparse input: nothing to stage for)
@@ -1426,12 +1449,17 @@ __global__ __launch_bounds__(kTgThreads) void token_tiles(const uint8_t *__restr
     uint32_t c = c_lo + wave;
     uint32_t i0 = 0, i1 = 0, nxt = 0;
     if (c < c_hi) request(c, i0, i1, nxt);
+    MSJ_TSTAMP(1);
 #pragma unroll
     for (uint32_t k = 0; k < 4; k++) {
         if (wave == kTgTiles && k >= kHaloInsts) break;
         *reinterpret_cast<uint4 *>(stage + region + 1024u * k) = v[k];
     }
     const uint32_t j = threadIdx.x;  // lane j of the workgroup classifies block j of the range
+    MSJ_TSTAMP(2);
+#ifdef MSJ_TILE_PRIO_CLASS
+    __builtin_amdgcn_s_setprio(MSJ_TILE_PRIO_CLASS);
+#endif
     if (kSpans) {
         // LDS written by this wave, read by this wave
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -1454,7 +1482,7 @@ __global__ __launch_bounds__(kTgThreads) void token_tiles(const uint8_t *__restr
             e_in = (run + msj::top_run(WB)) & 1u;
         }
         uint64_t q_mask = 0, bs = 0;
-        msj::SpanClasses cl = {0, ~0ull, 0, ~0ull};
+        msj::SpanClasses cl = {0, 0, 0, ~0ull};  // a lane without a block: nothing set in any map
         msj::TileClasses tc = {0, 0};
         const bool own = j < kTgBlocks;
         if (own) {
@@ -1490,13 +1518,13 @@ __global__ __launch_bounds__(kTgThreads) void token_tiles(const uint8_t *__restr
         }
         if (j < kTgBlocks + 2u) {  // the lanes behind the last block write the zero words behind the maps
             const uint32_t w = kSpanMapFront + 2u * j;
-            const uint64_t z = own ? ~0ull : 0ull;
-            *reinterpret_cast<uint2 *>(m_num + w) = make_uint2((uint32_t)(cl.digit & z), (uint32_t)((cl.digit & z) >> 32));
-            *reinterpret_cast<uint2 *>(m_flt + w) = make_uint2((uint32_t)(cl.sow & z), (uint32_t)((cl.sow & z) >> 32));
-            *reinterpret_cast<uint2 *>(m_dot + w) = make_uint2((uint32_t)(tc.dote & z), (uint32_t)((tc.dote & z) >> 32));
-            *reinterpret_cast<uint2 *>(m_ink + w) = make_uint2((uint32_t)(~cl.blank & z), (uint32_t)((~cl.blank & z) >> 32));
-            *reinterpret_cast<uint2 *>(m_q + w) = make_uint2((uint32_t)(q_mask & z), (uint32_t)((q_mask & z) >> 32));
-            *reinterpret_cast<uint2 *>(m_e + w) = make_uint2((uint32_t)(e_mask & z), (uint32_t)((e_mask & z) >> 32));
+            const uint64_t ink = ~cl.blank;
+            *reinterpret_cast<uint2 *>(m_num + w) = make_uint2((uint32_t)cl.digit, (uint32_t)(cl.digit >> 32));
+            *reinterpret_cast<uint2 *>(m_flt + w) = make_uint2((uint32_t)cl.sow, (uint32_t)(cl.sow >> 32));
+            *reinterpret_cast<uint2 *>(m_dot + w) = make_uint2((uint32_t)tc.dote, (uint32_t)(tc.dote >> 32));
+            *reinterpret_cast<uint2 *>(m_ink + w) = make_uint2((uint32_t)ink, (uint32_t)(ink >> 32));
+            *reinterpret_cast<uint2 *>(m_q + w) = make_uint2((uint32_t)q_mask, (uint32_t)(q_mask >> 32));
+            *reinterpret_cast<uint2 *>(m_e + w) = make_uint2((uint32_t)e_mask, (uint32_t)(e_mask >> 32));
         }
         if (j == kTgThreads - 1u) {  // ... and the ones in front of them
             *reinterpret_cast<uint2 *>(m_num) = make_uint2(0, 0);
@@ -1508,7 +1536,12 @@ __global__ __launch_bounds__(kTgThreads) void token_tiles(const uint8_t *__restr
             co[kTgWaves] = 0;
         }
     }
+    MSJ_TSTAMP(3);
     __syncthreads();
+    MSJ_TSTAMP(4);
+#ifdef MSJ_TILE_PRIO_LOOP
+    __builtin_amdgcn_s_setprio(MSJ_TILE_PRIO_LOOP);
+#endif
 
     const TileMaps maps = {stage, m_num, m_flt, m_dot, m_ink, m_q, m_e, co};
     const bool wide = (reinterpret_cast<uintptr_t>(end) & 7u) == 0 &&
@@ -1603,6 +1636,7 @@ __global__ __launch_bounds__(kTgThreads) void token_tiles(const uint8_t *__restr
         }
         i0 = n_i0, i1 = n_i1, nxt = n_nxt;
     }
+    MSJ_TSTAMP(5);
 }
 
 // the tokens on the work list, from global memory; the last workgroup to finish clears the list for the next call
@@ -1651,6 +1685,33 @@ __global__ __launch_bounds__(256) void merge_sub_aggregates(const int4 *__restri
     }
     *reinterpret_cast<int4 *>(block_agg + 4 * (uint64_t)b) = make_int4(t.sum, t.mn, t.mx, no);
 }
+// the same for token_tiles' chunk aggregates, which carry bracket counts only (kNone / -kNone as minimum / maximum: "none
+// from here", apply_depth supplies them): sixteen chunks make a block, sixteen lanes a DPP row -- one coalesced load per
+// lane, the row's sums by four row_shr additions, the row's last lane writes the block
+static_assert(kBlock / kChunk == 16, "one DPP row per block");
+__global__ __launch_bounds__(256) void merge_chunk_counts(const int4 *__restrict__ sub, uint32_t nsub, int32_t *__restrict__ block_agg,
+                                                          uint32_t nblocks) {
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    const int4 q = i < nsub ? sub[i] : make_int4(0, 0, 0, 0);
+    uint32_t sum = (uint32_t)q.x, no = (uint32_t)q.w;
+    asm volatile(
+        "s_nop 1\n\t"
+        "v_add_u32_dpp %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_u32_dpp %1, %1, %1 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 0\n\t"
+        "v_add_u32_dpp %0, %0, %0 row_shr:2 row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_u32_dpp %1, %1, %1 row_shr:2 row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 0\n\t"
+        "v_add_u32_dpp %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_u32_dpp %1, %1, %1 row_shr:4 row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 0\n\t"
+        "v_add_u32_dpp %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_u32_dpp %1, %1, %1 row_shr:8 row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1"
+        : "+v"(sum), "+v"(no));
+    const uint32_t b = i >> 4;
+    if ((threadIdx.x & 15u) == 15u && b < nblocks) *reinterpret_cast<int4 *>(block_agg + 4 * (uint64_t)b) = make_int4((int)sum, kNone, -kNone, (int)no);
+}
 // 0: by tiles of the buffer (token_tiles); 1: by tokens (token_spans) -- msj_debug_set_span_mode, tests and A/B runs
 static uint32_t g_span_mode = 0;
 }  // namespace msj_tokens
@@ -1660,6 +1721,12 @@ extern "C" void msj_debug_set_span_limits(uint32_t lds_limit_bytes, uint32_t fix
     msj_tokens::g_fix_cap = fix_capacity;
 }
 extern "C" void msj_debug_set_span_mode(uint32_t mode) { msj_tokens::g_span_mode = mode; }
+#ifdef MSJ_TILE_STAMPS
+extern "C" int msj_debug_set_tile_stamps(void *d_stamps) {
+    unsigned long long *p = static_cast<unsigned long long *>(d_stamps);
+    return (int)hipMemcpyToSymbol(HIP_SYMBOL(msj_tokens::g_tile_stamps), &p, sizeof(p));
+}
+#endif
 
 // the work list of span_fixup: zeroed once by the owner (the kernels leave it zeroed)
 extern "C" uint64_t msj_span_fix_bytes(void) { return msj_tokens::kFixWords * sizeof(uint32_t); }
@@ -1724,7 +1791,7 @@ extern "C" int msj_launch_stage2_prep(const uint8_t *d_buf, uint64_t len, const 
     int4 *sub = sub_of(d_ws, n, wm);
     if (n && g_span_mode == 0) {
         launch_token_tiles<true, true>(d_buf, len, d_idx, n, d_end, d_flags, d_type, sub, table_of(d_ws, n, wm), d_fix, s);
-        hipLaunchKernelGGL(merge_sub_aggregates<kChunk>, dim3((nb + 255u) / 256u), dim3(256), 0, s, sub, (uint32_t)chunk_count(n), d_ws, nb);
+        hipLaunchKernelGGL(merge_chunk_counts, dim3((nb * 16u + 255u) / 256u), dim3(256), 0, s, sub, (uint32_t)chunk_count(n), d_ws, nb);
     } else if (n) {
         const uint32_t nsub = (uint32_t)((n + kSpanTokens - 1) / kSpanTokens);
         const uint32_t lds_limit = span_lds_limit();
@@ -1746,7 +1813,7 @@ extern "C" int msj_launch_tokens(const uint8_t *d_buf, uint64_t len, const uint3
     int4 *sub = sub_of(d_ws, n, wm);
     if (n && g_span_mode == 0) {
         launch_token_tiles<true, false>(d_buf, len, d_idx, n, nullptr, nullptr, d_type, sub, table_of(d_ws, n, wm), nullptr, s);
-        hipLaunchKernelGGL(merge_sub_aggregates<kChunk>, dim3((nb + 255u) / 256u), dim3(256), 0, s, sub, (uint32_t)chunk_count(n), d_ws, nb);
+        hipLaunchKernelGGL(merge_chunk_counts, dim3((nb * 16u + 255u) / 256u), dim3(256), 0, s, sub, (uint32_t)chunk_count(n), d_ws, nb);
     } else if (n) {
         const uint32_t nsub = (uint32_t)((n + kSpanTokens - 1) / kSpanTokens);
         hipLaunchKernelGGL((token_spans<true, false>), dim3(nsub), dim3(kSpanThreads), 0, s, d_buf, len, d_idx, n, static_cast<uint32_t *>(nullptr),

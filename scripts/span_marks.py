@@ -22,7 +22,7 @@ mark("        if (kFused) {\n            // the chunk.s bracket counts".replace(
 mark("        i0 = n_i0, i1 = n_i1, nxt = n_nxt;", "LOOPEND")
 src = (src[:i] + t).replace('#include "../../include/msj_stage1.h"', '#include "%s/include/msj_stage1.h"' % ROOT)
 d = tempfile.mkdtemp()
-for h in ("lane_math.h", "stage1_kernel.h"):
+for h in ("lane_math.h", "stage1_kernel.h", "token_math.h"):
     open(os.path.join(d, h), "w").write(open(os.path.join(ROOT, "mojo_simdjson_amd/csrc", h)).read())
 open(os.path.join(d, "tokens_kernel.hip"), "w").write(src)
 subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-save-temps=obj", "-c",
