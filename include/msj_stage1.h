@@ -404,8 +404,9 @@ int32_t msj_token_spans_device(msj_ctx *ctx, const uint8_t *d_buf, uint64_t len,
 /* Test hook (process-wide): stretches of more than lds_limit_bytes take the span kernels' global-memory path, the
  * fix-up list holds fix_capacity entries; 0xFFFFFFFF = the built-in value of either. */
 void msj_debug_set_span_limits(uint32_t lds_limit_bytes, uint32_t fix_capacity);
-/* Test hook (process-wide): 0 (default) = the token calls run the kernel organised by tiles of the buffer, 1 = the one
- * organised by tokens (round 2's, kept as the second implementation the tests and A/B runs compare with). */
+/* Test hook (process-wide): which of their two kernels the token calls run -- 0 (default) by the density of the index
+ * (the kernel organised by tiles of the buffer from one structural per 7 bytes on, the one organised by tokens below
+ * that), 1 = by tokens, 2 = by tiles whatever the density.  Identical results; the tests run both. */
 void msj_debug_set_span_mode(uint32_t mode);
 
 /*

@@ -1712,8 +1712,14 @@ __global__ __launch_bounds__(256) void merge_chunk_counts(const int4 *__restrict
     const uint32_t b = i >> 4;
     if ((threadIdx.x & 15u) == 15u && b < nblocks) *reinterpret_cast<int4 *>(block_agg + 4 * (uint64_t)b) = make_int4((int)sum, kNone, -kNone, (int)no);
 }
-// 0: by tiles of the buffer (token_tiles); 1: by tokens (token_spans) -- msj_debug_set_span_mode, tests and A/B runs
+// Which of the two kernels a token call runs.  0 (default): by the density of the index -- token_tiles pays for every
+// BYTE it stages (classification, escape and carry chains: ~1.6 vector instructions per byte) and little per token,
+// token_spans the other way round; measured on 1 GiB (profiles/r03/stage2_prep_r03_tiles_ab.txt): minified (one
+// structural per 5.2 bytes) 1.03 against 1.15 ms, UTF-8-heavy (1 / 9.6) 0.73 against 0.69, pretty-printed (1 / 10.3)
+// 0.68 against 0.63 -- the tiles from one structural per 7 bytes on.  1: token_spans, 2: token_tiles whatever the
+// density (msj_debug_set_span_mode: the tests run both, A/B runs).
 static uint32_t g_span_mode = 0;
+static bool by_tiles(uint64_t n, uint64_t len) { return g_span_mode == 2u || (g_span_mode == 0u && n * 7u >= len); }
 }  // namespace msj_tokens
 
 extern "C" void msj_debug_set_span_limits(uint32_t lds_limit_bytes, uint32_t fix_capacity) {
@@ -1764,7 +1770,7 @@ extern "C" int msj_launch_token_spans(const uint8_t *d_buf, uint64_t len, const 
     using namespace msj_tokens;
     if (n == 0) return 0;
     hipStream_t s = static_cast<hipStream_t>(stream);
-    if (g_span_mode == 0 && (reinterpret_cast<uintptr_t>(d_idx) & 7u) == 0) {
+    if (by_tiles(n, len) && (reinterpret_cast<uintptr_t>(d_idx) & 7u) == 0) {
         launch_token_tiles<false, true>(d_buf, len, d_idx, n, d_end, d_flags, nullptr, nullptr, table_of(d_ws, n, 0), d_fix, s);
         return (int)hipGetLastError();
     }
@@ -1789,7 +1795,7 @@ extern "C" int msj_launch_stage2_prep(const uint8_t *d_buf, uint64_t len, const 
     // the fused kernel's aggregates live behind the token pre-pass's own workspace (16-byte aligned)
     const int wm = d_match != nullptr;
     int4 *sub = sub_of(d_ws, n, wm);
-    if (n && g_span_mode == 0) {
+    if (n && by_tiles(n, len)) {
         launch_token_tiles<true, true>(d_buf, len, d_idx, n, d_end, d_flags, d_type, sub, table_of(d_ws, n, wm), d_fix, s);
         hipLaunchKernelGGL(merge_chunk_counts, dim3((nb * 16u + 255u) / 256u), dim3(256), 0, s, sub, (uint32_t)chunk_count(n), d_ws, nb);
     } else if (n) {
@@ -1811,7 +1817,7 @@ extern "C" int msj_launch_tokens(const uint8_t *d_buf, uint64_t len, const uint3
     const uint32_t nb = (uint32_t)nb64;
     const int wm = d_match != nullptr;
     int4 *sub = sub_of(d_ws, n, wm);
-    if (n && g_span_mode == 0) {
+    if (n && by_tiles(n, len)) {
         launch_token_tiles<true, false>(d_buf, len, d_idx, n, nullptr, nullptr, d_type, sub, table_of(d_ws, n, wm), nullptr, s);
         hipLaunchKernelGGL(merge_chunk_counts, dim3((nb * 16u + 255u) / 256u), dim3(256), 0, s, sub, (uint32_t)chunk_count(n), d_ws, nb);
     } else if (n) {

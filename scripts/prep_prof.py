@@ -19,7 +19,7 @@ ap.add_argument("--match", action="store_true")
 ap.add_argument("--iters", type=int, default=200)
 ap.add_argument("--warm", type=int, default=200)
 ap.add_argument("--mib", type=int, default=1024)
-ap.add_argument("--mode", type=int, default=0, help="0 = kernel organised by tiles (default), 1 = by tokens (round 2's)")
+ap.add_argument("--mode", type=int, default=0, help="0 = by density (the product), 1 = kernel organised by tokens, 2 = by tiles")
 ap.add_argument("--lib", default=None, help="A/B: load this build of libmsj_stage1.so")
 a = ap.parse_args()
 if a.lib:

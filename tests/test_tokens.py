@@ -188,9 +188,10 @@ def _check(dev, data, where):
 
 @pytest.fixture(params=["tiles", "tokens"])
 def span_mode(dev, request):
-    """The token calls' two kernels: organised by tiles of the buffer (the product's default) and by tokens (round 2's,
-    msj_debug_set_span_mode(1)): the same tests, the same definitions."""
-    dev.lib.msj_debug_set_span_mode(1 if request.param == "tokens" else 0)
+    """The token calls' two kernels, each forced whatever the density of the index (the product picks by density):
+    organised by tiles of the buffer (msj_debug_set_span_mode(2)) and by tokens (1): the same tests, the same
+    definitions."""
+    dev.lib.msj_debug_set_span_mode(1 if request.param == "tokens" else 2)
     request.addfinalizer(lambda: dev.lib.msj_debug_set_span_mode(0))
     return request.param
 
@@ -365,7 +366,8 @@ def test_prep_around_the_tile_groups(dev, lds_limit, request):
     scan runs past the next structural and numbers at the cap are moved across the group border, the end of the halo
     and the end of the buffer byte by byte."""
     dev.lib.msj_debug_set_span_limits(int(lds_limit) if lds_limit else 0xFFFFFFFF, 0xFFFFFFFF)
-    request.addfinalizer(lambda: dev.lib.msj_debug_set_span_limits(0xFFFFFFFF, 0xFFFFFFFF))
+    dev.lib.msj_debug_set_span_mode(2)
+    request.addfinalizer(lambda: (dev.lib.msj_debug_set_span_limits(0xFFFFFFFF, 0xFFFFFFFF), dev.lib.msj_debug_set_span_mode(0)))
     G, H = 16384, 2048
     rng = np.random.default_rng(77)
     # (a) a dense run of short tokens across two borders, shifted byte by byte (chunk grid against byte grid)
