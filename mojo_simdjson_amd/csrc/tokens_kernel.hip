@@ -112,7 +112,7 @@ __device__ __forceinline__ uint32_t wave_incl_sum(uint32_t x) {
 // (1) type bytes + per-block aggregate: the span kernel's type-bytes-only instantiation (token_spans<true, false>
 //     below: the workgroup's stretch of the buffer staged in LDS with coalesced loads, the bytes picked from there;
 //     a kernel that gathered buf[idx[i]] per token through L2 took 0.6 ms per GiB minified where this takes 0.5) and
-//     merge_sub_aggregates.
+//     merge_chunk_counts.
 
 // (2a) many workgroups: exclusive scan of the block aggregates INSIDE each run of kSuper blocks (relative
 //      start depth and start slot per block) and the aggregate of the run.  One workgroup scanning all
@@ -1120,35 +1120,16 @@ __global__ __launch_bounds__(kSpanThreads) void token_spans(const uint8_t *__res
         }
     }
     if (kFused && MSJ_SPAN_ABLATE != 2) {
-        // ordered reduction of the running-depth monoid over the workgroup's tokens: lane t holds tokens 2t and
-        // 2t + 1.  Deltas are -1 / 0 / +1, so the running sum in front of a lane is four counts of ballot bits
-        // below it; min and max by DPP row scans (a lane past the last token repeats the value in front of it:
-        // tokens are contiguous)
-        __shared__ Agg wave_agg[kSpanThreads / 64];
-        __shared__ int wave_opens[kSpanThreads / 64];
-        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-        const int d0 = have0 ? delta_of(c0) : 0, d1 = have1 ? delta_of(c1) : 0;
-        const uint64_t up0 = __ballot(d0 > 0), dn0 = __ballot(d0 < 0), up1 = __ballot(d1 > 0), dn1 = __ballot(d1 < 0);
-        const auto below = [](uint64_t m) { return (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0)); };
-        const int r0 = below(up0) + below(up1) - below(dn0) - below(dn1) + d0, r1 = r0 + d1;  // after token 2t / 2t + 1
-        int mn, mx;
-        wave_min_max(min(r0, r1), max(r0, r1), mn, mx);
-        if (lane == 0) {
-            const bool any = first + 128u * (uint32_t)wave < nt;  // this wave's first token exists
+        // the bracket counts of this wave's 128 tokens = chunk 4 * blockIdx.x + wave of the grid token_tiles uses (same
+        // downstream: merge_chunk_counts, the scans, apply_depth -- which supplies the minimum / maximum of the running
+        // depth that this kernel reduced with two DPP chains, an LDS hand-over and a second barrier per workgroup until
+        // round 3).  '[' '{' are 5B 7B, ']' '}' are 5D 7D: one masked compare each, the compare IS the ballot
+        const uint32_t k0 = have0 ? (c0 & 0xDFu) : 0u, k1 = have1 ? (c1 & 0xDFu) : 0u;
+        const uint64_t up0 = __ballot(k0 == 0x5Bu), dn0 = __ballot(k0 == 0x5Du), up1 = __ballot(k1 == 0x5Bu), dn1 = __ballot(k1 == 0x5Du);
+        const uint32_t chunk = 4u * blockIdx.x + (threadIdx.x >> 6);
+        if ((threadIdx.x & 63u) == 0 && chunk * 128u < nt) {
             const int ups = (int)__popcll(up0) + (int)__popcll(up1), downs = (int)__popcll(dn0) + (int)__popcll(dn1);
-            wave_agg[wave] = Agg{ups - downs, any ? mn : kNone, any ? mx : -kNone};
-            wave_opens[wave] = ups;
-        }
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            Agg t = {0, kNone, -kNone};
-            int no = 0;
-#pragma unroll
-            for (int w = 0; w < (int)kSpanThreads / 64; w++) {
-                t = combine(t, wave_agg[w]);
-                no += wave_opens[w];
-            }
-            sub_agg[blockIdx.x] = make_int4(t.sum, t.mn, t.mx, no);
+            sub_agg[chunk] = make_int4(ups - downs, kNone, -kNone, ups);
         }
     }
 }
@@ -1177,7 +1158,7 @@ static uint32_t span_lds_limit() { return g_lds_limit < kSpanLds ? g_lds_limit :
 // its five waves take them round robin, the next chunk's indices are requested before the present one is worked on.
 // A chunk whose tokens end inside the staged range (the halo is what the group's last chunk usually needs) reads
 // LDS; one that does not (sparse input, long strings) takes the per-token path from global memory, like a long
-// stretch above.  The depth aggregates leave per chunk (merge_sub_aggregates folds 16 of them into a block).
+// stretch above.  The depth aggregates leave per chunk (merge_chunk_counts folds 16 of them into a block).
 constexpr uint32_t kTgTiles = 4;
 constexpr uint32_t kTgWaves = kTgTiles + 1;            // one wave per tile + one for the halo
 constexpr uint32_t kTgThreads = 64 * kTgWaves;
@@ -1665,29 +1646,10 @@ __global__ __launch_bounds__(256) void span_fixup(const uint8_t *__restrict__ bu
     }
 }
 
-// block aggregates of the token pre-pass (kBlock tokens) from those of the fused kernels (kSubTokens tokens each:
-// kSpanTokens from token_spans, kChunk from token_tiles)
-static_assert(kBlock % kSpanTokens == 0, "a block of the depth pass is a whole number of span workgroups");
-template <uint32_t kSubTokens>
-__global__ __launch_bounds__(256) void merge_sub_aggregates(const int4 *__restrict__ sub, uint32_t nsub, int32_t *__restrict__ block_agg,
-                                                            uint32_t nblocks) {
-    constexpr uint32_t kSub = kBlock / kSubTokens;
-    const uint32_t b = blockIdx.x * 256u + threadIdx.x;
-    if (b >= nblocks) return;
-    Agg t = {0, kNone, -kNone};
-    int no = 0;
-    for (uint32_t k = 0; k < kSub; k++) {
-        const uint32_t i = b * kSub + k;
-        if (i >= nsub) break;
-        const int4 q = sub[i];
-        t = combine(t, Agg{q.x, q.y, q.z});
-        no += q.w;
-    }
-    *reinterpret_cast<int4 *>(block_agg + 4 * (uint64_t)b) = make_int4(t.sum, t.mn, t.mx, no);
-}
-// the same for token_tiles' chunk aggregates, which carry bracket counts only (kNone / -kNone as minimum / maximum: "none
-// from here", apply_depth supplies them): sixteen chunks make a block, sixteen lanes a DPP row -- one coalesced load per
-// lane, the row's sums by four row_shr additions, the row's last lane writes the block
+// block aggregates of the token pre-pass (kBlock tokens) from the fused kernels' chunk aggregates (kChunk tokens each),
+// which carry bracket counts only (kNone / -kNone as minimum / maximum: "none from here", apply_depth supplies them):
+// sixteen chunks make a block, sixteen lanes a DPP row -- one coalesced load per lane, the row's sums by four row_shr
+// additions, the row's last lane writes the block
 static_assert(kBlock / kChunk == 16, "one DPP row per block");
 __global__ __launch_bounds__(256) void merge_chunk_counts(const int4 *__restrict__ sub, uint32_t nsub, int32_t *__restrict__ block_agg,
                                                           uint32_t nblocks) {
@@ -1770,7 +1732,9 @@ extern "C" int msj_launch_token_spans(const uint8_t *d_buf, uint64_t len, const 
     using namespace msj_tokens;
     if (n == 0) return 0;
     hipStream_t s = static_cast<hipStream_t>(stream);
-    if (by_tiles(n, len) && (reinterpret_cast<uintptr_t>(d_idx) & 7u) == 0) {
+    // the spans alone: the kernel organised by tokens at every density (1 GiB minified 0.75 against 0.79 ms; what the tile
+    // kernel gains in the fused call is the type bytes and bracket counts it gets for nothing) unless the tiles are asked for
+    if (g_span_mode == 2u && (reinterpret_cast<uintptr_t>(d_idx) & 7u) == 0) {
         launch_token_tiles<false, true>(d_buf, len, d_idx, n, d_end, d_flags, nullptr, nullptr, table_of(d_ws, n, 0), d_fix, s);
         return (int)hipGetLastError();
     }
@@ -1803,7 +1767,7 @@ extern "C" int msj_launch_stage2_prep(const uint8_t *d_buf, uint64_t len, const 
         const uint32_t lds_limit = span_lds_limit();
         hipLaunchKernelGGL(token_spans<true>, dim3(nsub), dim3(kSpanThreads), 0, s, d_buf, len, d_idx, n, d_end, d_flags, lds_limit, d_type, sub, d_fix, fix_cap());
         hipLaunchKernelGGL(span_fixup, dim3(kFixGroups), dim3(256), 0, s, d_buf, len, d_idx, n, d_end, d_flags, d_fix, fix_cap());
-        hipLaunchKernelGGL(merge_sub_aggregates<kSpanTokens>, dim3((nb + 255u) / 256u), dim3(256), 0, s, sub, nsub, d_ws, nb);
+        hipLaunchKernelGGL(merge_chunk_counts, dim3((nb * 16u + 255u) / 256u), dim3(256), 0, s, sub, (uint32_t)chunk_count(n), d_ws, nb);
     }
     return launch_depth_passes(d_idx, n, d_type, d_depth, d_match, d_result, d_ws, s);
 }
@@ -1824,7 +1788,7 @@ extern "C" int msj_launch_tokens(const uint8_t *d_buf, uint64_t len, const uint3
         const uint32_t nsub = (uint32_t)((n + kSpanTokens - 1) / kSpanTokens);
         hipLaunchKernelGGL((token_spans<true, false>), dim3(nsub), dim3(kSpanThreads), 0, s, d_buf, len, d_idx, n, static_cast<uint32_t *>(nullptr),
                            static_cast<uint8_t *>(nullptr), kSpanLds, d_type, sub, static_cast<uint32_t *>(nullptr), 0u);
-        hipLaunchKernelGGL(merge_sub_aggregates<kSpanTokens>, dim3((nb + 255u) / 256u), dim3(256), 0, s, sub, nsub, d_ws, nb);
+        hipLaunchKernelGGL(merge_chunk_counts, dim3((nb * 16u + 255u) / 256u), dim3(256), 0, s, sub, (uint32_t)chunk_count(n), d_ws, nb);
     }
     return launch_depth_passes(d_idx, n, d_type, d_depth, d_match, d_result, d_ws, s);
 }

@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""Rate of the token pre-pass (row f1) on the 1 GiB workloads: type byte + nesting depth per structural."""
+"""Rate of the token pre-pass (row f1) on the 1 GiB workloads: type byte + nesting depth per structural.
+    python3 scripts/tokens_rate.py [span mode]"""
 import os
 import sys
 
@@ -10,6 +11,9 @@ from mojo_simdjson_amd import synth  # noqa: E402
 from mojo_simdjson_amd.device import Stage1Device  # noqa: E402
 
 dev = Stage1Device(0)
+if len(sys.argv) > 1:  # 1 = the kernel organised by tokens, 2 = by tiles; default: the product's choice by density
+    dev.lib.msj_debug_set_span_mode(int(sys.argv[1]))
+    print(f"span mode {sys.argv[1]}")
 torch.cuda.set_device(0)
 for name in ("minified", "utf8", "pretty4"):
     u = synth.workload(name, 64 << 20)
