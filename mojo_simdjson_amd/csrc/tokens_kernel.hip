@@ -1448,8 +1448,11 @@ __global__ __launch_bounds__(kTgThreads) void token_tiles(const uint8_t *__restr
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         // the carry into the wave's first byte: the parity of the run of backslashes that ends in front of it.  A run
-        // that fills the 64-byte window goes on in the window in front -- down to the start of the range at most: a run
-        // that began in front of the range belongs to a string that did, i.e. to a token of an earlier group
+        // that fills the 64-byte window goes on in the window in front -- down to the start of the range at most, and the
+        // carry into the range itself is taken as 0: a run that comes in from the bytes in front of the range belongs to a
+        // token of an earlier group -- inside a string to that string, outside one (a byte soup) to the scalar its first
+        // backslash starts (stage 1 never makes the quote behind such a run a structural) -- and the quotes this
+        // group's tokens look at lie behind an opening quote inside the range (test_prep_around_the_tile_groups, g)
         uint32_t e_in = 0;
         if (wave > 0) {
             uint64_t WB = __ballot(wb == 0x5Cu);

@@ -393,6 +393,26 @@ def test_prep_around_the_tile_groups(dev, lds_limit, request):
     alphabet = np.frombuffer(b'{}[],: "a1\\\n-.e', dtype=np.uint8)
     for n in (G - 1, G, G + 1, G + H - 1, G + H, G + H + 1, 2 * G + 5, 5 * G + 77):
         _check_prep(dev, alphabet[rng.integers(0, len(alphabet), n)].tobytes(), f"soup {n}")
+    # (g) runs of backslashes that cross a group border (or a tile border inside a group) and end right in front of a
+    #     quote, outside a string and inside one.  The tile kernel resolves escapes per block with the carry into a GROUP
+    #     taken as 0: a run that comes in from the bytes in front of the group belongs to a token of an earlier group --
+    #     inside a string to that string, outside one to the scalar the run starts (stage 1 makes the first backslash
+    #     the structural, never the quote behind the run) -- and the quotes the group's own tokens look at lie behind an
+    #     opening quote inside the group
+    for border in (G, G + 4096, 2 * G):
+        for run in (1, 2, 3, 63, 64, 65, 127, 128, 129, 4095, 4096, 4097, 4200, 9001):
+            for off in (0, 1, 2, 33):
+                # 1 408 = 11 x 128 tokens in front: what follows the blanks starts a chunk, which then belongs to the group
+                # behind the border
+                head = b"0," * 704
+                pad = border + off - run - len(head)
+                if pad < 0:
+                    continue
+                for body in (b"ab\\n", b"ab"):  # with and without a backslash of its own
+                    outside = head + b" " * pad + b"\\" * run + b'"' + body + b'" ,"c",' + b"1," * 300 + b"2]"
+                    _check_prep(dev, outside, f"run of {run} in front of a quote at {border}+{off}, outside a string, body {body!r}")
+                inside = head + b" " * (pad - 1) + b'"' + b"\\" * run + b'" ,"d\\"e",' + b"1," * 300 + b"2]"
+                _check_prep(dev, inside, f"run of {run} in front of a quote at {border}+{off}, inside a string")
     # (f) the wide stores need aligned arrays: the same through the span call with arrays off the grid
     _check_spans(dev, b"[" + b'"ab",' * 9000 + b"1]", "spans only")
 
