@@ -1,11 +1,10 @@
 #!/bin/bash
-# the tile-group tests against another build of the library (e.g. one without a fix: they must fail there), then the
-# product build against it on the 1 GiB minified workload:  scripts/check_against_ref.sh <lib.so>
+# the token tests against another build of the library (a variant under test, or one without a fix: they must fail
+# there), then the product build against it on a 1 GiB workload:  scripts/check_against_ref.sh <lib.so> [workload] [pytest -k expression]
 cd "$GRAFT_REPO_ROOT"
-REF=$(readlink -f "$1")
-timeout -k 10 600 python -m pytest tests/test_tokens.py -x -q -m gpu 2>&1 | tail -3 | cut -c1-250
-echo "--- test_prep_around_the_tile_groups against $1:"
-python3 - "$REF" <<'PY'
+REF=$(readlink -f "$1"); W=${2:-minified}; K=${3:-tile_groups or token_spans or stage2_prep or fixtures}
+echo "--- tests/test_tokens.py -k '$K' against $1:"
+python3 - "$REF" "$K" <<'PY'
 import subprocess, sys
 code = f"""
 import sys
@@ -13,9 +12,9 @@ sys.path.insert(0, ".")
 from mojo_simdjson_amd import _lib
 _lib.LIB_PATH = {sys.argv[1]!r}
 import pytest
-sys.exit(pytest.main(["tests/test_tokens.py", "-x", "-q", "-m", "gpu", "-k", "around_the_tile_groups"]))
+sys.exit(pytest.main(["tests/test_tokens.py", "-x", "-q", "-m", "gpu", "-k", {sys.argv[2]!r}]))
 """
 r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True)
-print(r.stdout[-700:])
+print(r.stdout[-900:])
 PY
-bash scripts/prep_lib_ab.sh minified "$1" 2>&1 | grep -v amdgpu | cut -c1-110
+bash scripts/prep_lib_ab.sh $W "$1" 2>&1 | grep -v amdgpu | cut -c1-110
