@@ -405,9 +405,12 @@ int32_t msj_token_spans_device(msj_ctx *ctx, const uint8_t *d_buf, uint64_t len,
  * fix-up list holds fix_capacity entries; 0xFFFFFFFF = the built-in value of either. */
 void msj_debug_set_span_limits(uint32_t lds_limit_bytes, uint32_t fix_capacity);
 /* Test hook (process-wide): which of their two kernels the token calls run -- 0 (default) by the density of the index
- * (the kernel organised by tiles of the buffer from one structural per 7 bytes on, the one organised by tokens below
+ * (the kernel organised by tiles of the buffer from one structural per 11 bytes on, the one organised by tokens below
  * that), 1 = by tokens, 2 = by tiles whatever the density.  Identical results; the tests run both. */
 void msj_debug_set_span_mode(uint32_t mode);
+/* Test hook: bytes of the buffer per workgroup of the kernel organised by tiles (which = 0) and of its halo (which = 1):
+ * what the tests move their tokens across. */
+uint32_t msj_debug_tile_group(int32_t which);
 
 /*
  * msj_stage2_prep_device -- msj_tokens_device and msj_token_spans_device in one go (rows f1 + f2 + f4), with

@@ -149,6 +149,8 @@ def load():
     lib.msj_debug_set_span_limits.argtypes = [ctypes.c_uint32, ctypes.c_uint32]
     lib.msj_debug_set_span_mode.restype = None
     lib.msj_debug_set_span_mode.argtypes = [ctypes.c_uint32]
+    lib.msj_debug_tile_group.restype = ctypes.c_uint32
+    lib.msj_debug_tile_group.argtypes = [ctypes.c_int32]
     lib.msj_fallback_count.restype = ctypes.c_uint64
     lib.msj_fallback_count.argtypes = [ctypes.c_void_p]
     lib.msj_stage1_shard_device.restype = ctypes.c_int32

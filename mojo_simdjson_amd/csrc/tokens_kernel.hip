@@ -1159,11 +1159,22 @@ static uint32_t span_lds_limit() { return g_lds_limit < kSpanLds ? g_lds_limit :
 // A chunk whose tokens end inside the staged range (the halo is what the group's last chunk usually needs) reads
 // LDS; one that does not (sparse input, long strings) takes the per-token path from global memory, like a long
 // stretch above.  The depth aggregates leave per chunk (merge_chunk_counts folds 16 of them into a block).
-constexpr uint32_t kTgTiles = 4;
+// Three tiles and the halo = FOUR waves per workgroup, one per SIMD.  Measured on 1 GiB minified, same box, alternating
+// (profiles/r03/prep_tiles_history.txt): 2 / 3 / 4 / 6 tiles per group = 0.90 / 0.87 / 1.04 / 1.00 ms per call of
+// msj_stage2_prep_device -- five waves (4 tiles) load one SIMD twice as much as the others, and the smaller group's
+// LDS lets a fifth workgroup onto the CU.  Halo 1 KiB against 2 KiB: no difference on minified; the larger one keeps
+// more last chunks of a group on the LDS path where tokens are sparse.
+#ifndef MSJ_TG_TILES
+#define MSJ_TG_TILES 3
+#endif
+#ifndef MSJ_TG_HALO_BLOCKS
+#define MSJ_TG_HALO_BLOCKS 32
+#endif
+constexpr uint32_t kTgTiles = MSJ_TG_TILES;
 constexpr uint32_t kTgWaves = kTgTiles + 1;            // one wave per tile + one for the halo
 constexpr uint32_t kTgThreads = 64 * kTgWaves;
 constexpr uint32_t kTgBytes = kTgTiles * 4096u;        // bytes of the buffer per workgroup
-constexpr uint32_t kTgHaloBlocks = 32;                 // 2 KiB behind them (<= 64: one wave)
+constexpr uint32_t kTgHaloBlocks = MSJ_TG_HALO_BLOCKS;  // 2 KiB behind them (<= 64: one wave)
 constexpr uint32_t kTgBlocks = kTgTiles * 64 + kTgHaloBlocks;
 constexpr uint32_t kTgStage = kTgBlocks * 64;          // bytes staged
 constexpr uint32_t kTgMapWords = kSpanMapFront + 2 * kTgBlocks + 4;
@@ -1679,12 +1690,13 @@ __global__ __launch_bounds__(256) void merge_chunk_counts(const int4 *__restrict
 }
 // Which of the two kernels a token call runs.  0 (default): by the density of the index -- token_tiles pays for every
 // BYTE it stages (classification, escape and carry chains: ~1.6 vector instructions per byte) and little per token,
-// token_spans the other way round; measured on 1 GiB (profiles/r03/stage2_prep_r03_tiles_ab.txt): minified (one
-// structural per 5.2 bytes) 1.03 against 1.15 ms, UTF-8-heavy (1 / 9.6) 0.73 against 0.69, pretty-printed (1 / 10.3)
-// 0.68 against 0.63 -- the tiles from one structural per 7 bytes on.  1: token_spans, 2: token_tiles whatever the
-// density (msj_debug_set_span_mode: the tests run both, A/B runs).
+// token_spans the other way round; measured on 1 GiB, same box, alternating (profiles/r03/stage2_prep_r03_tiles_ab.txt,
+// prep_density_ab.txt), tiles against tokens: minified (one structural per 5.2 bytes) 0.87 against 1.09 ms, tab + CRLF
+// (1 / 7.2) 0.72 / 0.79, indent 2 (1 / 8.0) 0.64 / 0.73, UTF-8-heavy (1 / 9.6) 0.63 / 0.64, indent 4 (1 / 10.3)
+// 0.575 / 0.592, indent 8 (1 / 14.9) 0.51 / 0.43 -- the tiles from one structural per 11 bytes on.  1: token_spans,
+// 2: token_tiles whatever the density (msj_debug_set_span_mode: the tests run both, A/B runs).
 static uint32_t g_span_mode = 0;
-static bool by_tiles(uint64_t n, uint64_t len) { return g_span_mode == 2u || (g_span_mode == 0u && n * 7u >= len); }
+static bool by_tiles(uint64_t n, uint64_t len) { return g_span_mode == 2u || (g_span_mode == 0u && n * 11u >= len); }
 }  // namespace msj_tokens
 
 extern "C" void msj_debug_set_span_limits(uint32_t lds_limit_bytes, uint32_t fix_capacity) {
@@ -1692,6 +1704,8 @@ extern "C" void msj_debug_set_span_limits(uint32_t lds_limit_bytes, uint32_t fix
     msj_tokens::g_fix_cap = fix_capacity;
 }
 extern "C" void msj_debug_set_span_mode(uint32_t mode) { msj_tokens::g_span_mode = mode; }
+// what the tests place their tokens around: bytes of the buffer per workgroup of token_tiles (0) and its halo (1)
+extern "C" uint32_t msj_debug_tile_group(int32_t which) { return which == 0 ? msj_tokens::kTgBytes : msj_tokens::kTgHaloBlocks * 64u; }
 #ifdef MSJ_TILE_STAMPS
 extern "C" int msj_debug_set_tile_stamps(void *d_stamps) {
     unsigned long long *p = static_cast<unsigned long long *>(d_stamps);

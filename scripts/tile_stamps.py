@@ -24,8 +24,10 @@ dv = dev.device
 outs = [torch.empty(n, dtype=torch.uint8, device=dv), torch.empty(n, dtype=torch.int32, device=dv), torch.empty(n, dtype=torch.int32, device=dv),
         torch.empty(n, dtype=torch.uint8, device=dv)]
 d_res = torch.zeros(24, dtype=torch.uint8, device=dv)
-groups = (nbytes + 16383) // 16384
-d_st = torch.zeros(groups * 5 * 8, dtype=torch.int64, device=dv)
+GB = int(dev.lib.msj_debug_tile_group(0))
+WAVES = GB // 4096 + 1
+groups = (nbytes + GB - 1) // GB
+d_st = torch.zeros(groups * WAVES * 8, dtype=torch.int64, device=dv)
 def call():
     rc = dev.lib.msj_stage2_prep_device(dev.ctx, _ptr(d_buf), nbytes, _ptr(d_idx), n, _ptr(outs[0]), _ptr(outs[1]), None, _ptr(outs[2]),
                                         _ptr(outs[3]), _ptr(d_res), dev._stream())
@@ -36,7 +38,7 @@ dev.lib.msj_debug_set_tile_stamps.argtypes = [ctypes.c_void_p]
 assert dev.lib.msj_debug_set_tile_stamps(ctypes.c_void_p(d_st.data_ptr())) == 0
 call()
 torch.cuda.synchronize()
-st = d_st.cpu().numpy().reshape(groups, 5, 8).astype(np.int64)
+st = d_st.cpu().numpy().reshape(groups, WAVES, 8).astype(np.int64)
 ok = st[:, :, 0] != 0
 t0 = st[:, :, 0][ok].min()
 end = st[:, :, 5].max()
@@ -47,7 +49,7 @@ for k in range(5):
     print(f"  {names[k]:38s} median {np.median(d):6.2f} us   mean {d.mean():6.2f}   p90 {np.percentile(d, 90):6.2f}")
 life = (st[:, :, 5].max(axis=1) - st[:, :, 0].min(axis=1)) / 100.0
 print(f"  workgroup lifetime (first entry -> last exit): median {np.median(life):.2f} us, mean {life.mean():.2f}; "
-      f"resident workgroups on average {life.sum() / ((end - t0) / 100.0):.0f} (5 per CU x 256 = 1280 fit)")
+      f"resident workgroups on average {life.sum() / ((end - t0) / 100.0):.0f} (slots: see the first entry of the last line)")
 wl = ((st[:, :, 5] - st[:, :, 0])[ok] / 100.0)
 print(f"  wave lifetime mean {wl.mean():.2f} us; resident waves on average {wl.sum() / ((end - t0) / 100.0):.0f}")
 # gap between a workgroup's exit and the next entry: start times sorted, how many start within the kernel's first microseconds

@@ -361,14 +361,14 @@ def test_stage2_prep_equals_the_separate_calls(dev, lds_limit, request, span_mod
 @pytest.mark.gpu
 @pytest.mark.parametrize("lds_limit", ["", "4096"])
 def test_prep_around_the_tile_groups(dev, lds_limit, request):
-    """The kernel organised by tiles stages 16 KiB of the buffer + a 2 KiB halo per workgroup and hands out tokens in
+    """The kernel organised by tiles stages a group of tiles of the buffer + a 2 KiB halo per workgroup and hands out tokens in
     chunks of 128 that belong to the group their first token lies in: tokens, chunk borders, long strings, floats whose
     scan runs past the next structural and numbers at the cap are moved across the group border, the end of the halo
     and the end of the buffer byte by byte."""
     dev.lib.msj_debug_set_span_limits(int(lds_limit) if lds_limit else 0xFFFFFFFF, 0xFFFFFFFF)
     dev.lib.msj_debug_set_span_mode(2)
     request.addfinalizer(lambda: (dev.lib.msj_debug_set_span_limits(0xFFFFFFFF, 0xFFFFFFFF), dev.lib.msj_debug_set_span_mode(0)))
-    G, H = 16384, 2048
+    G, H = int(dev.lib.msj_debug_tile_group(0)), int(dev.lib.msj_debug_tile_group(1))  # 12 KiB of the buffer per workgroup + 2 KiB
     rng = np.random.default_rng(77)
     # (a) a dense run of short tokens across two borders, shifted byte by byte (chunk grid against byte grid)
     for shift in list(range(0, 9)) + [63, 64, 65, 127, 128, 129]:
