@@ -1749,9 +1749,10 @@ extern "C" int msj_launch_token_spans(const uint8_t *d_buf, uint64_t len, const 
     using namespace msj_tokens;
     if (n == 0) return 0;
     hipStream_t s = static_cast<hipStream_t>(stream);
-    // the spans alone: the kernel organised by tokens at every density (1 GiB minified 0.75 against 0.79 ms; what the tile
-    // kernel gains in the fused call is the type bytes and bracket counts it gets for nothing) unless the tiles are asked for
-    if (g_span_mode == 2u && (reinterpret_cast<uintptr_t>(d_idx) & 7u) == 0) {
+    // the spans alone: the tiles only where the index is dense (1 GiB minified 0.70 against 0.76 ms, UTF-8-heavy 0.53
+    // against 0.49, pretty-printed 0.48 against 0.45: without the type bytes and bracket counts the fused call gets for
+    // nothing, the tile kernel's per-byte work pays off later) -- from one structural per 7 bytes on
+    if ((g_span_mode == 2u || (g_span_mode == 0u && n * 7u >= len)) && (reinterpret_cast<uintptr_t>(d_idx) & 7u) == 0) {
         launch_token_tiles<false, true>(d_buf, len, d_idx, n, d_end, d_flags, nullptr, nullptr, table_of(d_ws, n, 0), d_fix, s);
         return (int)hipGetLastError();
     }
