@@ -1152,10 +1152,10 @@ static uint32_t span_lds_limit() { return g_lds_limit < kSpanLds ? g_lds_limit :
 // group's entry of a small table (`tbl[g]` = number of structurals in front of byte g * kTgBytes: group_table below)
 // and then the first chunk's indices are all requested before anything is waited for; one wave per tile stages and
 // classifies it with all 64 lanes (1 KiB-contiguous wave loads, linear in LDS, the lane's own 64-byte block read back
-// from there), a fifth wave does the same for a halo of kTgHaloBlocks blocks behind the group.  Tokens are handled in
+// from there), one more wave does the same for a halo of kTgHaloBlocks blocks behind the group.  Tokens are handled in
 // CHUNKS of 128 on a global grid (chunk c = tokens [128 c, 128 c + 128), two per lane, the pair evaluated once --
-// staged_token_fast and its fallbacks exactly as above); a group owns the chunks whose FIRST token lies in its 16 KiB,
-// its five waves take them round robin, the next chunk's indices are requested before the present one is worked on.
+// pair_fast and its fallbacks); a group owns the chunks whose FIRST token lies in its kTgBytes,
+// its waves take them round robin, the next chunk's indices are requested before the present one is worked on.
 // A chunk whose tokens end inside the staged range (the halo is what the group's last chunk usually needs) reads
 // LDS; one that does not (sparse input, long strings) takes the per-token path from global memory, like a long
 // stretch above.  The depth aggregates leave per chunk (merge_chunk_counts folds 16 of them into a block).
