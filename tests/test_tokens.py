@@ -455,3 +455,44 @@ def test_tokens_1gib_replicated(dev):
     wd_d = torch.from_numpy(wd).to(dev.device)
     assert torch.equal(t.view(reps, -1), wt_d.expand(reps, -1))
     assert torch.equal(d.view(reps, -1), wd_d.expand(reps, -1))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("workload,mode", [("minified", 0), ("minified", 1), ("utf8", 0), ("utf8", 2), ("pretty8", 0), ("pretty8", 2)])
+def test_stage2_prep_1gib_replicated(dev, workload, mode, request):
+    """msj_stage2_prep_device at full size (BASELINE configs 2-4): every unit is a complete document, so type, depth and
+    span flags repeat unit by unit and span ends repeat shifted by the unit's length -- every token of the 1 GiB stream is
+    compared on the device with the definition's result for ONE unit.  Mode 0 is the product's choice of kernel by the
+    density of the index (tiles for minified and UTF-8-heavy, tokens for indent 8), 1 / 2 force the other one."""
+    import torch
+
+    from mojo_simdjson_amd import synth
+
+    dev.lib.msj_debug_set_span_mode(mode)
+    request.addfinalizer(lambda: dev.lib.msj_debug_set_span_mode(0))
+    u = synth.workload(workload, 64 << 20)
+    oracle = helpers.load_oracle()
+    data = u.tobytes()
+    idx_u = _stage1(oracle, data)
+    wt, wd, (final, mn, mx) = helpers.oracle_tokens(data, idx_u)
+    we, wf = helpers.oracle_token_spans(data, idx_u)
+    assert final == 0 and mn == 0
+    reps = 16
+    nu = len(idx_u)
+    d_buf = torch.from_numpy(u).to(dev.device).repeat(reps)
+    d_idx = torch.empty(nu * reps + 16, dtype=torch.int32, device=dev.device)
+    d_res = dev.new_carry()
+    dev.index(d_buf, d_idx, d_res)
+    n = int(dev.fetch(d_res).count)
+    assert n == nu * reps
+    t, d, res, _, e, f = dev.stage2_prep(d_buf, d_buf.numel(), d_idx, n)
+    assert (res.n, res.final_depth, res.min_depth, res.max_depth) == (n, 0, 0, mx)
+    assert torch.equal(t.view(reps, -1), torch.from_numpy(wt).to(dev.device).expand(reps, -1))
+    assert torch.equal(d.view(reps, -1), torch.from_numpy(wd).to(dev.device).expand(reps, -1))
+    assert torch.equal(f.view(reps, -1), torch.from_numpy(wf).to(dev.device).expand(reps, -1))
+    we_d = torch.from_numpy(we.astype(np.int64)).to(dev.device)
+    shift = torch.arange(reps, device=dev.device, dtype=torch.int64)[:, None] * len(data)
+    # a string / number token's end is an offset into the stream; every other token's is 0.  (The stream's very last
+    # token is the closing bracket of the last unit: no token's span reaches the end of the buffer.)
+    want_e = torch.where(we_d[None, :] == 0, we_d[None, :], we_d[None, :] + shift)
+    assert torch.equal(e.view(reps, -1).to(torch.int64) & 0xFFFFFFFF, want_e)
