@@ -458,12 +458,14 @@ def test_tokens_1gib_replicated(dev):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("workload,mode", [("minified", 0), ("minified", 1), ("utf8", 0), ("utf8", 2), ("pretty8", 0), ("pretty8", 2)])
-def test_stage2_prep_1gib_replicated(dev, workload, mode, request):
+@pytest.mark.parametrize("workload,mode,reps", [("minified", 0, 16), ("minified", 1, 16), ("utf8", 0, 16), ("utf8", 2, 16), ("pretty8", 0, 16),
+                                                ("pretty8", 2, 16), ("minified", 0, 63), ("pretty8", 0, 63)])
+def test_stage2_prep_1gib_replicated(dev, workload, mode, reps, request):
     """msj_stage2_prep_device at full size (BASELINE configs 2-4): every unit is a complete document, so type, depth and
     span flags repeat unit by unit and span ends repeat shifted by the unit's length -- every token of the 1 GiB stream is
     compared on the device with the definition's result for ONE unit.  Mode 0 is the product's choice of kernel by the
-    density of the index (tiles for minified and UTF-8-heavy, tokens for indent 8), 1 / 2 force the other one."""
+    density of the index (tiles for minified and UTF-8-heavy, tokens for indent 8), 1 / 2 force the other one.  63 units
+    = 3.94 GiB: offsets and byte positions at the top of what one uint32 segment holds."""
     import torch
 
     from mojo_simdjson_amd import synth
@@ -477,7 +479,6 @@ def test_stage2_prep_1gib_replicated(dev, workload, mode, request):
     wt, wd, (final, mn, mx) = helpers.oracle_tokens(data, idx_u)
     we, wf = helpers.oracle_token_spans(data, idx_u)
     assert final == 0 and mn == 0
-    reps = 16
     nu = len(idx_u)
     d_buf = torch.from_numpy(u).to(dev.device).repeat(reps)
     d_idx = torch.empty(nu * reps + 16, dtype=torch.int32, device=dev.device)
@@ -491,8 +492,9 @@ def test_stage2_prep_1gib_replicated(dev, workload, mode, request):
     assert torch.equal(d.view(reps, -1), torch.from_numpy(wd).to(dev.device).expand(reps, -1))
     assert torch.equal(f.view(reps, -1), torch.from_numpy(wf).to(dev.device).expand(reps, -1))
     we_d = torch.from_numpy(we.astype(np.int64)).to(dev.device)
-    shift = torch.arange(reps, device=dev.device, dtype=torch.int64)[:, None] * len(data)
     # a string / number token's end is an offset into the stream; every other token's is 0.  (The stream's very last
     # token is the closing bracket of the last unit: no token's span reaches the end of the buffer.)
-    want_e = torch.where(we_d[None, :] == 0, we_d[None, :], we_d[None, :] + shift)
-    assert torch.equal(e.view(reps, -1).to(torch.int64) & 0xFFFFFFFF, want_e)
+    ev = e.view(reps, -1)
+    for k in range(reps):
+        want_e = torch.where(we_d == 0, we_d, we_d + k * len(data))
+        assert torch.equal(ev[k].to(torch.int64) & 0xFFFFFFFF, want_e), k
