@@ -1162,7 +1162,7 @@ static uint32_t span_lds_limit() { return g_lds_limit < kSpanLds ? g_lds_limit :
 // Three tiles and the halo = FOUR waves per workgroup, one per SIMD.  Measured on 1 GiB minified, same box, alternating
 // (profiles/r03/prep_tiles_history.txt): 2 / 3 / 4 / 6 tiles per group = 0.90 / 0.87 / 1.04 / 1.00 ms per call of
 // msj_stage2_prep_device -- five waves (4 tiles) load one SIMD twice as much as the others, and the smaller group's
-// LDS lets a fifth workgroup onto the CU.  Halo 1 KiB against 2 KiB: no difference on minified; the larger one keeps
+// LDS (25 KB) lets six workgroups = 24 waves onto a CU instead of four = 20.  Halo 1 KiB against 2 KiB: no difference on minified; the larger one keeps
 // more last chunks of a group on the LDS path where tokens are sparse.
 #ifndef MSJ_TG_TILES
 #define MSJ_TG_TILES 3
