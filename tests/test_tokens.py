@@ -389,6 +389,11 @@ def test_prep_around_the_tile_groups(dev, lds_limit, request):
     # (d) sparse stretches: groups that own no chunk, chunks far longer than a group, then dense again
     doc = b"[" + b'"' + b"x" * 70000 + b'",' + b" " * 40000 + b"1," * 5000 + b'"' + b"y" * 20000 + b'"' + b" " * 20000 + b",[]]"
     _check_prep(dev, doc, "sparse and dense")
+    # ... and indices far from linear in the byte offset (the group table closes in on its entries by interpolation
+    # before it bisects): all tokens in the first / the last percent of the buffer, a dense island between deserts
+    _check_prep(dev, b"[" + b"1," * 20000 + b" " * 4000000 + b"2]", "all tokens in front")
+    _check_prep(dev, b"[" + b" " * 4000000 + b"1," * 20000 + b"2]", "all tokens behind")
+    _check_prep(dev, b"[" + b" " * 1500000 + b'"a",' * 30000 + b" " * 2500000 + b"3," * 10 + b" " * 700000 + b"4]", "an island")
     # (e) byte soups of every size around the group size
     alphabet = np.frombuffer(b'{}[],: "a1\\\n-.e', dtype=np.uint8)
     for n in (G - 1, G, G + 1, G + H - 1, G + H, G + H + 1, 2 * G + 5, 5 * G + 77):
