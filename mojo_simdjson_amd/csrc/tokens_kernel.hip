@@ -325,13 +325,25 @@ __global__ __launch_bounds__(kThreads) void apply_depth(const uint8_t *__restric
             rmx = max(rmx, before);
         }
     }
-    if (base + kPer <= n) {
-        // write-once streams: non-temporal stores (the arrays are far larger than L2 / MALL)
+    // The depths leave through LDS, so that each store instruction of a wave writes 1 KiB contiguous instead of 16 bytes
+    // per lane at a 32-byte stride (a thread's eight tokens): msj_stage2_prep_device 0.865 -> 0.842 ms per GiB minified,
+    // same box, alternating (plain instead of non-temporal stores: 0.90).  Write-once stream, far larger than L2 / MALL:
+    // non-temporal stores.
+    __shared__ __attribute__((aligned(16))) int s_out[kThreads / 64][512];
+    const uint64_t wave_base = (uint64_t)blockIdx.x * kBlock + (uint64_t)wave * 512u;
+    if (wave_base + 512u <= n) {  // uniform per wave
         typedef int i32x4 __attribute__((ext_vector_type(4)));
-        const i32x4 o0 = {out[0], out[1], out[2], out[3]}, o1 = {out[4], out[5], out[6], out[7]};
-        __builtin_nontemporal_store(o0, reinterpret_cast<i32x4 *>(depth + base));
-        __builtin_nontemporal_store(o1, reinterpret_cast<i32x4 *>(depth + base + 4));
-    } else {
+        *reinterpret_cast<int4 *>(&s_out[wave][8 * lane]) = make_int4(out[0], out[1], out[2], out[3]);
+        *reinterpret_cast<int4 *>(&s_out[wave][8 * lane + 4]) = make_int4(out[4], out[5], out[6], out[7]);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        const int4 a = *reinterpret_cast<const int4 *>(&s_out[wave][4 * lane]);
+        const int4 b = *reinterpret_cast<const int4 *>(&s_out[wave][256 + 4 * lane]);
+        const i32x4 o0 = {a.x, a.y, a.z, a.w}, o1 = {b.x, b.y, b.z, b.w};
+        __builtin_nontemporal_store(o0, reinterpret_cast<i32x4 *>(depth + wave_base + 4 * lane));
+        __builtin_nontemporal_store(o1, reinterpret_cast<i32x4 *>(depth + wave_base + 256 + 4 * lane));
+    } else {  // the stream's last wave
 #pragma unroll
         for (int k = 0; k < kPer; k++)
             if (base + k < n) depth[base + k] = out[k];
