@@ -761,8 +761,32 @@ __device__ __forceinline__ void copy_out(const KernelArgs &a, const EmitU &e, co
     // most two) partial quads at the ends element by element
     uint8_t *out = reinterpret_cast<uint8_t *>(a.idx + (e.base - e.shift));  // out[4v] <-> stage[v]; 16-byte aligned
     const uint8_t *src = reinterpret_cast<const uint8_t *>(stage);
-    const uint32_t q_lo = (e.shift + 3u) >> 2;        // first quad with all four elements valid
-    const uint32_t q_hi = e.vend >> 2;                // one past the last full quad
+    const uint32_t q_lo0 = (e.shift + 3u) >> 2;       // first quad with all four elements valid
+    const uint32_t q_hi0 = e.vend >> 2;               // one past the last full quad
+    // The streaming stores cover whole 128-byte lines only: the quads of the (at most two) lines this tile shares with
+    // its neighbours leave as plain stores, which L2 merges with the neighbour's part -- a partially written line that
+    // leaves as a non-temporal store reaches memory on its own (WRITE_SIZE 0.883 GB for 0.831 GB of indices on the 1 GiB
+    // minified input).  Same box, alternating, 1 500 launches each (profiles/r03/ab_edge_plain.txt): minified 0.3289 ->
+    // 0.3183 ms, 0.3261 -> 0.3199 (+2 .. +3.4 %); pretty-printed +-0.5 %; UTF-8-heavy -0.7 .. -1.1 % -- where the
+    // instruction stream and not the traffic binds, the few extra instructions cost more than the lines save, so the
+    // edges are only taken apart for tiles with many indices (MSJ_EDGE_PLAIN_MIN; 0 = always, ~0 = never).
+#ifndef MSJ_EDGE_PLAIN_MIN
+#define MSJ_EDGE_PLAIN_MIN 512u
+#endif
+    uint32_t q_lo = q_lo0, q_hi = q_hi0;
+    if (e.vend - e.shift >= MSJ_EDGE_PLAIN_MIN) {  // uniform
+        const uint32_t a16 = (uint32_t)(reinterpret_cast<uintptr_t>(out) >> 4);  // the output's address in quads (uniform)
+        const uint32_t over = (a16 + q_hi0) & 7u;
+        q_lo = q_lo0 + ((8u - ((a16 + q_lo0) & 7u)) & 7u);   // first quad that starts a line
+        q_hi = q_hi0 >= over ? q_hi0 - over : 0u;            // one past the last quad that ends one
+        if (q_lo > q_hi0) q_lo = q_hi0;
+        if (q_hi < q_lo) q_hi = q_lo;
+        if (lane_p < 16u) {  // the edges: [q_lo0, q_lo) and [q_hi, q_hi0), at most seven quads each
+            const uint32_t q = lane_p < 8u ? q_lo0 + lane : q_hi + (lane - 8u);
+            const bool ok = lane_p < 8u ? q < q_lo : q < q_hi0;
+            if (ok) *reinterpret_cast<uint4 *>(out + 16u * q) = *reinterpret_cast<const uint4 *>(src + 16u * q);
+        }
+    }
     // at most kStageWords / 256 = 4 rounds of 64 quads: one byte offset per lane, the rounds are
     // immediate offsets of the LDS read and of the store; only the last round is partial
     const uint32_t off = (q_lo + lane) * 16u;
@@ -781,8 +805,8 @@ __device__ __forceinline__ void copy_out(const KernelArgs &a, const EmitU &e, co
     // element per lane of the first eight
     if (lane_p < 8u) {
         const bool head = lane_p < 4u;
-        const uint32_t v = head ? lane : 4u * q_hi + (lane - 4u);
-        const bool ok = head ? (v >= e.shift && v < 4u * q_lo && v < e.vend) : (v < e.vend && v >= 4u * q_lo);
+        const uint32_t v = head ? lane : 4u * q_hi0 + (lane - 4u);
+        const bool ok = head ? (v >= e.shift && v < 4u * q_lo0 && v < e.vend) : (v < e.vend && v >= 4u * q_lo0);
         if (ok) *reinterpret_cast<uint32_t *>(out + 4u * v) = *reinterpret_cast<const uint32_t *>(src + 4u * v);
     }
 }
