@@ -152,6 +152,129 @@ def cpu_baseline(unit, budget_s=10.0):
     return out
 
 
+def end_to_end(unit, lib, n_bytes=256 << 20, runs=5):
+    """"also report (clearly separated) end-to-end including H2D".  msj_stage1 -- the host-pointer
+    entry point the Mojo shim binds -- on `n_bytes` of the same workload in ordinary pageable host memory: PCIe up,
+    kernel, indices down over PCIe, all inside the call.  NEVER the metric: a separate record beside it."""
+    import ctypes
+
+    reps = max(1, n_bytes // int(unit.size))
+    data = np.tile(unit, reps)
+    idx = np.zeros(data.size + 3, dtype=np.uint32)  # touched once, reused: the parser's list (allocate(), :85-89)
+    n, verdict = ctypes.c_uint64(0), ctypes.c_int32(0)
+    ts = []
+    for k in range(runs + 1):
+        t0 = time.perf_counter()
+        rc = lib.msj_stage1(data.ctypes.data, data.size, idx.ctypes.data, idx.size, ctypes.byref(n), ctypes.byref(verdict), 0)
+        ts.append(time.perf_counter() - t0)
+        assert rc == 0, rc
+    ts = sorted(ts[1:])  # the first call sets the pinned rings up
+    med = ts[len(ts) // 2]
+    return {"value": round(data.size / med / 1e9, 2), "unit": "GB/s", "best": round(data.size / ts[0] / 1e9, 2),
+            "ms_median": round(med * 1e3, 3), "bytes": int(data.size), "structurals": int(n.value), "runs": runs,
+            "what": "msj_stage1 (host pointers, pageable caller memory): H2D of the input + kernel + D2H of n + 3 indices per "
+                    "call, median of the runs; NOT the metric (inputs of `value` are resident in HBM)"}
+
+
+def same_box_ceilings(torch_mod, device, d_in, n_bytes, structurals, d_scratch, grid=None):
+    """What the memory system of THIS box gives this launch's bytes when nothing is computed: the trivial kernels of
+    scripts/ubench/hbm_ceilings.hip (built as scripts/bin/libhbm_ceilings.so by __graft_entry__.build()) on the
+    product kernel's persistent grid, the product's tile walk and store shape, in the same process right behind the
+    product's windows (boxes of the pool differ by 3-5 %: a ceiling recorded on another box can sit below the product).
+    Reads the shard once per launch; writes ceil(4 S / tiles) bytes per tile, rounded UP to whole 128-byte lines.
+    Returns GB/s per variant (settled: 300 untimed launches, then 300 timed ones between two HIP events) or None.
+    `same_mix_best` is the fastest way found to move the launch's bytes without computing anything: the best of four
+    trivial read + write kernels and of (best pure read time + best pure write time)."""
+    import ctypes
+
+    path = os.path.join(ROOT, "scripts", "bin", "libhbm_ceilings.so")
+    if not os.path.exists(path):
+        return None
+    L = ctypes.CDLL(path)
+    L.msj_ceiling_launch.restype = ctypes.c_int
+    L.msj_ceiling_launch.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint64, ctypes.c_uint32,
+                                     ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_void_p]
+    ntiles = n_bytes // 4096
+    wquads = min(1024, -(-(-(-4 * structurals // ntiles)) // 128) * 8)  # bytes per tile -> whole lines -> 16-byte quads
+    if d_scratch.numel() * d_scratch.element_size() < ntiles * wquads * 16:
+        return None
+    grid = grid or 4 * torch_mod.cuda.get_device_properties(device).multi_processor_count
+    sink = torch_mod.zeros(64, dtype=torch_mod.uint8, device=device)
+    stream = ctypes.c_void_p(torch_mod.cuda.current_stream(device).cuda_stream)
+    out = {"w_per_r": round(wquads * 16 / 4096, 4), "grid": grid, "launches": 300}
+    n_rd, n_wr = ntiles * 4096, ntiles * wquads * 16
+
+    def ms(wq, policy):
+        def go(reps):
+            rc = L.msj_ceiling_launch(d_in.data_ptr(), d_scratch.data_ptr(), sink.data_ptr(), ntiles, wq, policy, grid, reps, stream)
+            assert rc == 0, rc
+        go(300)
+        e0, e1 = torch_mod.cuda.Event(enable_timing=True), torch_mod.cuda.Event(enable_timing=True)
+        e0.record()
+        go(300)
+        e1.record()
+        torch_mod.cuda.synchronize()
+        return e0.elapsed_time(e1) / 300
+
+    def gbps(nbytes, t_ms):
+        return round(nbytes / (t_ms * 1e-3) / 1e9, 1)
+
+    t_read = {"read_plain": ms(0, 0), "read_nt": ms(0, 1)}
+    for k, t in t_read.items():
+        out[k] = gbps(n_rd, t)
+    if wquads:
+        # the same bytes by trivial kernels: load next / store this (the product's policies: plain loads, non-temporal
+        # whole-line stores; and with non-temporal loads), stores deferred by two ranges like the product's emission
+        t_mix = {"same_mix_plain_nt": ms(wquads, 0), "same_mix_nt_nt": ms(wquads, 1),
+                 "same_mix_deferred_plain_nt": ms(wquads, 8), "same_mix_deferred_nt_nt": ms(wquads, 9)}
+        t_wr = {"write_only_nt": ms(wquads, 4), "write_only_plain": ms(wquads, 6)}
+        for k, t in t_mix.items():
+            out[k] = gbps(n_rd + n_wr, t)
+        for k, t in t_wr.items():
+            out[k] = gbps(n_wr, t)
+        # HBM's data bus is half duplex: a launch cannot take less than its reads at the best pure read rate plus its
+        # writes at the best pure write rate.  The write-only launches of this launch's own (small) output are short
+        # enough for their start and tail to count (0.16 ms; the product pays one start and tail, not two), so the pure
+        # write rate is also taken from a launch that writes 3 N (the whole scratch buffer) and the better one counts
+        wq_big = min(1024, (d_scratch.numel() * d_scratch.element_size() // ntiles // 16) // 8 * 8)
+        if wq_big > wquads:
+            t_big = min(ms(wq_big, 4), ms(wq_big, 6))
+            out["write_only_peak"] = gbps(ntiles * wq_big * 16, t_big)
+            out["write_only_peak_w_per_r"] = round(wq_big * 16 / 4096, 4)
+        wr_rate = max(out.get("write_only_peak", 0.0), out["write_only_nt"], out["write_only_plain"])
+        t_sum = min(t_read.values()) + n_wr / (wr_rate * 1e9) * 1e3
+        out["serial_sum_of_pure_streams"] = gbps(n_rd + n_wr, t_sum)
+        out["same_mix_ms"] = round(min(min(t_mix.values()), t_sum), 4)
+        out["same_mix_best"] = gbps(n_rd + n_wr, min(min(t_mix.values()), t_sum))
+    else:
+        out["same_mix_best"] = max(out["read_plain"], out["read_nt"])
+    return out
+
+
+def ceiling_fields(achieved, ingest, box, recorded, workload):
+    """The roofline record's measured-ceiling fields (GB/s): from this box's own run when there is one."""
+    src = None
+    if isinstance(box, dict) and "read_nt" in box:
+        c, src = box, "this box, this process (scripts/ubench/hbm_ceilings.hip, 300 settled launches per variant)"
+    else:
+        r = (recorded or {}).get("by_workload", {}).get(workload)
+        c = dict(r) if isinstance(r, dict) else None
+        if c:
+            c.update({k: recorded[k] for k in ("read_plain", "read_nt") if k in recorded})
+            src = f"profiles/traffic.json, recorded {recorded.get('date')} on another box of the pool (boxes differ by 3-5 %)"
+    if not c:
+        return {"ceilings": box if isinstance(box, dict) else None, "measured_read_peak": None, "frac_of_measured_read": None,
+                "ingest_frac_of_measured_read": None, "measured_same_mix_peak": None, "frac_of_same_mix": None}
+    read = max(c["read_plain"], c["read_nt"])
+    mix = c["same_mix_best"]  # the fastest of the trivial mixes and of the serial sum of the best pure streams
+    return {"ceilings": {**c, "source": src},
+            "measured_read_peak": read,
+            "frac_of_measured_read": round(achieved / read, 4),
+            "ingest_frac_of_measured_read": round(ingest / read, 4),
+            "measured_same_mix_peak": mix,
+            "frac_of_same_mix": round(achieved / mix, 4)}
+
+
 def self_launch(args):
     """`python bench.py --gpus N` from a plain command line: start the N ranks as a child process tree
     (torch.distributed.run, one process per GPU) BEFORE anything in this process touches a GPU, relay their
@@ -245,6 +368,7 @@ def main():
     # ---- expected result: the oracle's indices of ONE unit (checker only, outside every timed window)
     u_idx = unit_indices(unit)
     unit_n = int(u_idx.size)
+    e2e = None
     cpu = None  # the timed CPU baseline runs BEHIND the GPU windows (below): ten seconds of it in front of them would
     #             put the GPU into a deeper idle state than anything a caller's process does before its first parse
 
@@ -300,9 +424,18 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    per_step = []  # N > 1: (kernel-only ns, kernel end -> reports in ns) of every result, from the slot's HIP events
+
+    def collect(ticket):
+        r = sh.result(ticket)
+        st = sh.stats()
+        per_step.append((st["last_kernel_ns"], st["last_stitch_ns"]))
+        return r
+
     def timed_window():
         """EXACTLY K steps between two barriers; returns (wall seconds, HIP-event ms, last result)."""
         last = None
+        per_step.clear()
         barrier()
         ev0 = torch.cuda.Event(enable_timing=True)
         ev1 = torch.cuda.Event(enable_timing=True)
@@ -312,17 +445,17 @@ def main():
             for _ in range(args.steps):
                 last = step()
         else:
-            # steps are independent passes: keep up to two submissions in flight, so that the stitch of
-            # step k (the RCCL all-gather, which may only get compute units once the persistent kernel of
-            # step k+1 drains, then the host-side verification) overlaps with the kernels of steps k+1 and
-            # k+2; all K results are in hand before the closing barrier
+            # steps are independent passes: up to DEPTH submissions in flight.  result(k) waits for the event behind
+            # ITS read-back only (csrc/sharded.cpp), and the all-gather + read-back of step k sit on the library's
+            # high-priority side stream behind kernel k's event: kernel k+1 starts behind kernel k, the stitch of
+            # step k and the host's verification run beside it.  All K results are in hand before the closing barrier
             pending = []
             for _ in range(args.steps):
                 pending.append(submit())
                 if len(pending) >= sh.DEPTH:
-                    last = sh.result(pending.pop(0))
+                    last = collect(pending.pop(0))
             while pending:
-                last = sh.result(pending.pop(0))
+                last = collect(pending.pop(0))
         ev1.record()
         barrier()
         return time.perf_counter() - t0, ev0.elapsed_time(ev1), last
@@ -354,9 +487,56 @@ def main():
     stats1 = sh.stats() if sh is not None else None
     if last_timed is not None:
         last = last_timed
+    timed_per_step = list(per_step)
+
+    # ---- "median / min of >= 10 runs".  A second window right behind the timed one (same
+    #      clocks), every step bracketed by its own pair of HIP events; `ms_per_step` stays the K-step window's mean
+    def quantiles(ms):
+        a = np.sort(np.asarray(ms, dtype=np.float64))
+        return {"n": int(a.size), "median": round(float(np.median(a)), 4), "min": round(float(a[0]), 4),
+                "p95": round(float(a[min(a.size - 1, int(np.ceil(0.95 * a.size)) - 1)]), 4),
+                "max": round(float(a[-1]), 4), "mean": round(float(a.mean()), 4)}
+
+    step_dist = None
+    standalone = None
+    if world == 1:
+        n_dist = max(args.steps, 50)
+        evs = [torch.cuda.Event(enable_timing=True) for _ in range(n_dist + 1)]
+        evs[0].record()
+        for k in range(n_dist):
+            step()
+            evs[k + 1].record()
+        torch.cuda.synchronize()
+        step_dist = quantiles([evs[k].elapsed_time(evs[k + 1]) for k in range(n_dist)])
+    else:
+        # this rank's shard WITHOUT the stitch (the exact carry its last result proved, no exchange, no host turn):
+        # what the rank's GPU does alone -- the basis of `scaling_efficiency` below
+        s_in, e_in, ps_in = sh.last_spec
+        d_exact = dev.make_carry(s_in, e_in, ps_in)
+        d_alone = dev.new_carry()
+
+        def alone():
+            dev.shard(d_shard, shard_len, d_idx, d_exact, d_alone, segments=d_seg, has_prefix=(rank > 0),
+                      is_final=(rank == world - 1), trailer_len=total_len, flags=flags)
+
+        for _ in range(2):
+            alone()
+        barrier()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(args.steps):
+            alone()
+        e1.record()
+        torch.cuda.synchronize()
+        standalone = e0.elapsed_time(e1) / args.steps  # ms per pass of this rank's shard, nothing else on the GPU
+        barrier()
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         torch.cuda.synchronize()
         cpu = cpu_baseline(unit)  # timed CPU baseline on rank 0 at N = 1 only; the GPU is idle meanwhile
+        try:
+            e2e = end_to_end(unit, dev.lib)
+        except Exception as exc:  # a measurement extra: never fails the bench
+            e2e = {"error": repr(exc)}
 
     # ---- result check (outside the timed region)
     if world == 1:
@@ -418,11 +598,20 @@ def main():
     elif not count_ok:
         verified = f"FAILED (code {code}, count {total_count} want {unit_n * reps})"
 
+    # ---- the box's own ceilings for this launch's bytes (N = 1; the index array is verified: its buffer is scratch now)
+    ceil_box = None
+    if world == 1 and rank == 0 and not args.no_emit:
+        try:
+            ceil_box = same_box_ceilings(torch, device, d_shard, min(shard_len, 0xFFFF0000) // 4096 * 4096,
+                                         int(total_count * (min(shard_len, 0xFFFF0000) / shard_len)), d_idx)
+        except Exception as exc:  # a measurement extra: never fails the bench
+            ceil_box = {"error": repr(exc)}
+
     t = torch.tensor([dt], dtype=torch.float64, device=device if backend == "nccl" else "cpu")
     if dist is not None:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     dt_max = float(t.item())
-    stitch = None
+    stitch, scaling_eff = None, None
     if sh is not None:
         # the stitch over the timed window, max over ranks where it is a latency
         st = {k: stats1[k] - stats0[k] for k in stats1}
@@ -432,13 +621,46 @@ def main():
         vmax = v.clone()
         dist.all_reduce(v, op=dist.ReduceOp.SUM)
         dist.all_reduce(vmax, op=dist.ReduceOp.MAX)
+        # per step and rank: the kernel alone (event pair around the shard's launches) and kernel end -> reports in.
+        # The rank whose kernel ends last sees the bare latency of the exchange, every other rank that + its lead:
+        # the spread of the second figure over the ranks of one step is the skew of the ranks' kernel ends
+        ps = torch.tensor(timed_per_step if len(timed_per_step) == args.steps else [(0, 0)] * args.steps,
+                          dtype=torch.float64, device=device if backend == "nccl" else "cpu")
+        alone_t = torch.tensor([standalone, float(shard_len)], dtype=torch.float64, device=ps.device)
+        all_ps = [torch.empty_like(ps) for _ in range(world)]
+        all_alone = [torch.empty_like(alone_t) for _ in range(world)]
+        dist.all_gather(all_ps, ps)
+        dist.all_gather(all_alone, alone_t)
+        kern = np.stack([t.cpu().numpy()[:, 0] for t in all_ps]) / 1e6    # [rank, step] ms
+        arrive = np.stack([t.cpu().numpy()[:, 1] for t in all_ps]) / 1e3  # [rank, step] us
+        skew = arrive.max(axis=0) - arrive.min(axis=0)
+        alone_ms = [float(t[0].item()) for t in all_alone]
+        alone_rate = sum(float(t[1].item()) / (float(t[0].item()) * 1e-3) for t in all_alone) / 1e9  # GB/s, all ranks
         stitch = {"exchange": sh.exchange_used, "rccl_ranks": sh.rccl_ranks, "reruns": int(v[0].item()),
+                  "reruns_behind_queue": int(stats1["reruns_behind_queue"] - stats0["reruns_behind_queue"]),
                   "allgather_rounds": int(vmax[1].item()),
+                  "in_flight": sh.DEPTH,
                   "stitch_us_per_round": round(float(vmax[2].item()) / 1e3, 2),
                   "result_wait_us_per_step": round(float(vmax[3].item()) / 1e3, 2),
+                  "kernel_only_ms": [round(float(x), 4) for x in np.median(kern, axis=1)],
+                  "kernel_only_ms_max_step": round(float(kern.max()), 4),
+                  "reports_in_us": {"min_rank_median": round(float(np.median(arrive, axis=1).min()), 2),
+                                    "max_rank_median": round(float(np.median(arrive, axis=1).max()), 2)},
+                  "rank_skew_us": {"median": round(float(np.median(skew)), 2), "max": round(float(skew.max()), 2)},
+                  "standalone_ms": [round(x, 4) for x in alone_ms],
                   "note": "timed window only; reruns summed over ranks; stitch = HIP-event time from the end of a round's "
                           "kernel to the gathered reports' arrival in pinned host memory (max over ranks); result_wait = host "
-                          "time blocked in msj_stage1_sharded_result per step (max over ranks, with up to 3 steps in flight)"}
+                          "time blocked in msj_stage1_sharded_result per step (max over ranks, with up to 3 steps in flight); "
+                          "kernel_only_ms = per rank, median over the steps, HIP events around the shard's launches alone; "
+                          "reports_in_us = kernel end -> reports in, per rank (median over steps): the smallest is the "
+                          "exchange's bare latency; rank_skew_us = per step, max - min of that figure over the ranks = how "
+                          "far apart the ranks' kernels end; standalone_ms = each rank's shard through msj_stage1_shard_device "
+                          "with its exact carry, no exchange, no host turn (K steps after the timed window)"}
+        scaling_eff = {"value": round(total_len / dt_max / 1e9 / alone_rate, 4),
+                       "basis": f"whole-job GB/s / sum over the {world} ranks of (shard bytes / standalone_ms): the same "
+                                f"{args.gib_per_gpu:g} GiB/GPU shards on the same GPUs in the same process without the stitch "
+                                f"(= {world} x the N = 1 configuration at this size per GPU, measured here rather than assumed)",
+                       "standalone_aggregate": round(alone_rate, 2)}
 
     if rank == 0:
         ms_per_step = dt_max / args.steps * 1e3
@@ -478,6 +700,9 @@ def main():
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 4),
+            **({"ms_per_step_median": step_dist["median"], "ms_per_step_min": step_dist["min"],
+                "ms_per_step_p95": step_dist["p95"]} if step_dist else {}),
+            **({"scaling_efficiency": scaling_eff} if scaling_eff else {}),
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
@@ -502,6 +727,8 @@ def main():
                 "verified": verified,
                 **({"verify": verify_detail} if verify_detail else {}),
                 **({"stitch": stitch} if stitch else {}),
+                **({"per_step_ms": {**step_dist, "note": "a second window right behind the timed one, every step between "
+                                    "its own pair of HIP events; ms_per_step is the K-step window's mean"}} if step_dist else {}),
                 "library": version + (f" [--lib {args.lib}]" if args.lib else ""),
             },
             "roofline": {
@@ -515,19 +742,16 @@ def main():
                 "kernel": "stage1_kernel",
                 "algorithmic_bytes_per_launch": alg_bytes,
                 "kernel_ms": round(k_ms, 4),
-                # north_star's target is quoted against MEASURED read bandwidth (trivial read
-                # kernel on the same box, scripts/ubench/hbm_bw.hip), reported beside the contract's
-                # vendor-peak fraction above
-                "measured_read_peak": measured.get("read_4gib"),
-                "frac_of_measured_read": (round(achieved / measured["read_4gib"], 4)
-                                          if measured.get("read_4gib") else None),
-                # ... and the stricter reading of the same target: input bytes only over the measured read bandwidth
-                # (at density d it cannot exceed the same-mix ceiling / (1 + 4 d))
-                "ingest_frac_of_measured_read": (round(value / world / measured["read_4gib"], 4)
-                                                 if measured.get("read_4gib") else None),
-                "measured_same_mix_peak": measured.get("mix_r1_w0775_1gib"),
+                # north_star's target is quoted against MEASURED read bandwidth: the trivial kernels of
+                # scripts/ubench/hbm_ceilings.hip on the product's grid, walk and store shape -- on this box in this
+                # process when the helper library is there (N = 1), else the figures recorded in profiles/traffic.json
+                # (another box: +-3-5 %).  Both readings of the target: (N + 4S)/t and the input bytes alone, over the
+                # measured read bandwidth; and (N + 4S)/t over what a trivial kernel moves the SAME bytes at
+                # (same read : write mix), which no kernel on this grid can exceed.
+                **ceiling_fields(achieved, value / world, ceil_box, measured, args.workload),
             },
             "cpu_baseline": cpu,
+            **({"end_to_end": e2e} if e2e else {}),
         }
         if unsettled is not None:
             # the same K steps timed right after the W warm-up steps, before the clocks have settled

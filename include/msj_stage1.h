@@ -130,6 +130,7 @@ const char *msj_version(void);
  * the reference (one parser = one synchronous call). */
 int32_t msj_ctx_create(int32_t device, msj_ctx **out);
 void msj_ctx_destroy(msj_ctx *ctx);
+int32_t msj_ctx_device(const msj_ctx *ctx); /* the HIP device the context was created on (-1: NULL) */
 
 /*
  * msj_stage1 -- host-pointer form; replaces
@@ -288,6 +289,20 @@ typedef struct msj_sharded_ops {
                          const msj_carry *d_carry_in, msj_carry *d_carry_out, msj_segment *d_segments,
                          uint32_t max_segments, int32_t has_prefix, int32_t is_final, uint64_t trailer_len,
                          void *stream, uint32_t flags);
+    /* Optional -- the first five together or not at all (all NULL: operations that complete before they return, the
+     * CPU tests' kind; msj_stage1_sharded_result then drains the submission's stream with `sync`).  With them a
+     * result waits for the event behind ITS submission's read-back only, so that later submissions keep the GPU
+     * busy meanwhile, and the exchange + read-back go to `side_stream` behind an event at the end of the kernel,
+     * so that the next kernel starts behind the kernel, not behind the collective.  The default HIP operations have
+     * all of them (hipEvent_t, a non-blocking stream of the highest priority). */
+    int32_t (*event_create)(void *user, void **event_out);
+    void (*event_destroy)(void *user, void *event);
+    int32_t (*event_record)(void *user, void *event, void *stream);
+    int32_t (*event_wait)(void *user, void *event);                /* the host blocks until the event has happened */
+    int32_t (*stream_wait)(void *user, void *stream, void *event); /* what is enqueued on `stream` from now on waits */
+    int32_t (*event_query)(void *user, void *event);               /* optional: 1 happened, 0 not yet, < 0 error */
+    int32_t (*event_elapsed_ns)(void *user, void *from, void *to, uint64_t *ns_out); /* optional: statistics only */
+    void *side_stream; /* custom operations: the stream of the exchange and the read-back (NULL: the submission's) */
 } msj_sharded_ops;
 
 typedef struct msj_sharded msj_sharded;
@@ -302,17 +317,35 @@ uint64_t msj_sharded_rounds(const msj_sharded *sh); /* all-gathers so far */
 typedef struct msj_sharded_stats {
     uint64_t results, rounds, reruns;
     uint64_t stitch_device_ns, result_wait_ns;
+    uint64_t kernel_device_ns;    /* cumulative event time of this rank's shard launches alone (the carry's 64-byte upload
+                                     + the kernel chain), no exchange in it: the rank's kernel-only time */
+    uint64_t last_kernel_ns;      /* ... of the last completed result's launch */
+    uint64_t last_stitch_ns;      /* end of that launch -> gathered reports in pinned memory.  The rank whose kernel ends
+                                     last sees the exchange's bare latency here, every other rank that + its lead: the
+                                     spread of this figure over the ranks of one step is the ranks' skew */
+    uint64_t reruns_behind_queue; /* second launches (refuted guesses) that were enqueued behind the kernels of LATER
+                                     submissions on the same stream (launches of one context are stream-ordered) */
     uint64_t reserved[3];
 } msj_sharded_stats;
 int32_t msj_sharded_get_stats(const msj_sharded *sh, msj_sharded_stats *out);
+/* Where a submission is, without waiting: a set of MSJ_SHARDED_* bits (both set with operations that have no events:
+ * everything completed inside submit), < 0 on error / a ticket that is not in flight. */
+#define MSJ_SHARDED_KERNEL_DONE 1 /* the round's kernel (and what was in front of it on its stream) has finished */
+#define MSJ_SHARDED_REPORTS_IN 2  /* the gathered reports have arrived: msj_stage1_sharded_result will not block */
+int32_t msj_sharded_ticket_state(msj_sharded *sh, uint32_t ticket);
 /* Gives back what msj_exchange_rccl allocated when the exchange is NOT handed to msj_sharded_create after all. */
 void msj_exchange_release(msj_exchange *x);
 
-/* Enqueue this rank's shard: kernel, all-gather of the reports, pinned read-back; returns at once with a ticket
- * (up to 3 submissions may be in flight).  d_shard: 16-byte aligned device pointer; with has_prefix the 64 bytes
- * in front of it must be readable stream bytes.  speculation: the carry to assume (e.g. what msj_shard_speculate
- * gave for host copies of the bytes, or the carry a previous result reported as used), NULL = derived here from
- * the device bytes (one small blocking read).  d_segments / max_segments as in msj_stage1_shard_device. */
+/* Enqueue this rank's shard: the kernel on `stream`; the all-gather of the reports and the pinned read-back on the
+ * library's own high-priority stream behind an event at the kernel's end (so the kernel of the NEXT submission on
+ * `stream` runs beside them); returns at once with a ticket (up to 3 submissions may be in flight, all launches of
+ * one msj_sharded on ONE stream: a context's launches are stream-ordered).  d_shard: 16-byte aligned device pointer;
+ * with has_prefix the 64 bytes in front of it must be readable stream bytes.  speculation: the carry to assume (what
+ * msj_shard_speculate gave for host copies of the bytes, or -- resubmitting an unchanged shard -- the carry its last
+ * result reported as used: then nothing is read here).  NULL = derived here from the device bytes: one blocking
+ * 4 KiB read of `stream` per call, plus a 64 KiB and a 1 MiB read while the bytes decide nothing (strings of digits
+ * or literals) unless the shard's last verified result already settled it for the same bytes.
+ * d_segments / max_segments as in msj_stage1_shard_device. */
 int32_t msj_stage1_sharded_submit(msj_sharded *sh, const uint8_t *d_shard, uint64_t shard_len, uint32_t *d_idx,
                                   uint64_t idx_capacity, uint64_t total_len, int32_t has_prefix,
                                   const msj_carry *speculation, msj_segment *d_segments, uint32_t max_segments,
@@ -327,7 +360,8 @@ typedef struct msj_shard_placement {
     uint64_t count;       /* this shard's structurals */
     uint64_t bytes;       /* this shard's bytes */
 } msj_shard_placement;
-/* Wait for a submission; collective (every rank calls it for its matching ticket).  *code_out: the reference's
+/* Wait for a submission -- for ITS gathered reports only: later submissions keep running on the GPU meanwhile
+ * (msj_sharded_ticket_state tells) -- ; collective (every rank calls it for its matching ticket).  *code_out: the reference's
  * return code for the whole stream; *total_count_out: structurals of the whole stream (n_structural_indexes,
  * json_structural_indexer.mojo:160-165); *local_out: this shard's msj_carry (count = its own structurals);
  * *used_out: the exact carry at its first byte; *placement_out: the stitched offsets.  Any out pointer may be NULL.

@@ -587,6 +587,8 @@ int32_t msj_ctx_create(int32_t device, msj_ctx **out) {
     return MSJ_SUCCESS;
 }
 
+int32_t msj_ctx_device(const msj_ctx *ctx) { return ctx ? ctx->device : -1; }
+
 void msj_ctx_destroy(msj_ctx *ctx) {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);

@@ -31,6 +31,7 @@
 namespace {
 
 constexpr uint32_t kDepth = 3;  // submissions that may be in flight per rank
+constexpr uint64_t kLook = 64 + 4096;  // the first look at a shard the caller gave no carry for: halo + head
 
 bool is_nonscalar(uint8_t c) {
     // op | ws, haswell.mojo:22-74 (effective sets): {09,0A,0D,20} and {0C,1A,2C,3A,5B,5D,7B,7D}
@@ -88,6 +89,41 @@ int32_t hip_copy(void *, void *dst, const void *src, uint64_t bytes, int to_host
 int32_t hip_sync(void *, void *stream) {
     return hipStreamSynchronize(static_cast<hipStream_t>(stream)) == hipSuccess ? MSJ_SUCCESS : MSJ_ERR_HIP;
 }
+// events (optional part of msj_sharded_ops): what lets a result wait for ITS submission only
+int32_t hip_event_create(void *, void **out) {
+    hipEvent_t e = nullptr;
+    if (hipEventCreate(&e) != hipSuccess) return MSJ_ERR_HIP;
+    *out = e;
+    return MSJ_SUCCESS;
+}
+void hip_event_destroy(void *, void *e) {
+    if (e) (void)hipEventDestroy(static_cast<hipEvent_t>(e));
+}
+int32_t hip_event_record(void *, void *e, void *stream) {
+    return hipEventRecord(static_cast<hipEvent_t>(e), static_cast<hipStream_t>(stream)) == hipSuccess ? MSJ_SUCCESS : MSJ_ERR_HIP;
+}
+int32_t hip_event_wait(void *, void *e) {
+    return hipEventSynchronize(static_cast<hipEvent_t>(e)) == hipSuccess ? MSJ_SUCCESS : MSJ_ERR_HIP;
+}
+int32_t hip_stream_wait(void *, void *stream, void *e) {
+    return hipStreamWaitEvent(static_cast<hipStream_t>(stream), static_cast<hipEvent_t>(e), 0) == hipSuccess ? MSJ_SUCCESS
+                                                                                                            : MSJ_ERR_HIP;
+}
+int32_t hip_event_query(void *, void *e) {
+    const hipError_t r = hipEventQuery(static_cast<hipEvent_t>(e));
+    if (r == hipSuccess) return 1;
+    if (r == hipErrorNotReady) {
+        (void)hipGetLastError();  // "not ready" is an answer, not a sticky error
+        return 0;
+    }
+    return MSJ_ERR_HIP;
+}
+int32_t hip_event_elapsed_ns(void *, void *a, void *b, uint64_t *out) {
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, static_cast<hipEvent_t>(a), static_cast<hipEvent_t>(b)) != hipSuccess) return MSJ_ERR_HIP;
+    *out = ms > 0.f ? (uint64_t)((double)ms * 1e6) : 0;
+    return MSJ_SUCCESS;
+}
 int32_t hip_run_shard(void *user, const uint8_t *d_shard, uint64_t len, uint32_t *d_idx, uint64_t cap,
                       const msj_carry *d_in, msj_carry *d_out, msj_segment *d_segments, uint32_t max_segments,
                       int32_t has_prefix, int32_t is_final, uint64_t trailer_len, void *stream, uint32_t flags) {
@@ -113,9 +149,13 @@ struct Slot {
     msj_shard_report *h_gathered = nullptr;  // pinned host copy of d_gathered
     msj_carry *h_spec = nullptr;             // pinned host: the carry this rank's launch used
     bool busy = false;
-    // default HIP operations only: the end of the round's kernel / the arrival of the gathered reports (stats)
-    hipEvent_t ev_kernel = nullptr, ev_stitch = nullptr;
-    bool timed = false;
+    // with event operations (the default HIP ones have them): the start and the end of the round's kernel on the
+    // submission's stream, the arrival of the gathered reports in pinned memory on the exchange's stream.  A result
+    // waits for ev_stitch of ITS slot and for nothing else.
+    void *ev_start = nullptr, *ev_kernel = nullptr, *ev_stitch = nullptr;
+    bool kernel_ran = false;  // this round launched a kernel (a round in which only the other ranks index again does not)
+    uint64_t looked = 0;      // bytes of `look` the submission read to guess its carry (0: the caller gave one)
+    uint8_t look[kLook];
     // the call, for re-runs
     const uint8_t *d_shard;
     uint64_t shard_len, idx_capacity, total_len;
@@ -133,10 +173,23 @@ struct msj_sharded {
     msj_exchange x;
     Slot slots[kDepth];
     uint32_t next = 0;
-    uint64_t reruns = 0, rounds = 0, results = 0;
-    uint64_t stitch_device_ns = 0, result_wait_ns = 0;
-    bool hip_ops = false;  // the default operations: HIP events time the stitch
+    uint64_t reruns = 0, rounds = 0, results = 0, reruns_behind_queue = 0;
+    uint64_t stitch_device_ns = 0, result_wait_ns = 0, kernel_device_ns = 0;
+    uint64_t last_kernel_ns = 0, last_stitch_ns = 0;
+    bool events = false;      // ops has the event operations: per-slot waits, exchange beside the next kernel
+    void *side = nullptr;     // the stream the exchange and the read-back are enqueued on (NULL: the submission's own)
+    bool owns_side = false;   // created here (default HIP operations)
     RcclExchange *owned_rccl = nullptr;
+    // What the last verified result proved about a shard the library had to look at itself (no `speculation`), kept
+    // with the bytes it looked at first (64-byte halo + 4 KiB head): when the same placed shard comes again, those
+    // bytes are unchanged and they decide nothing by themselves, the proven carry is the guess and the longer looks
+    // (64 KiB, 1 MiB) are not repeated.  Only ever a guess: the chain check decides.
+    struct {
+        const uint8_t *d_shard = nullptr;
+        uint64_t shard_len = 0, n = 0;
+        msj_carry carry;
+        uint8_t bytes[kLook];
+    } proven;
 };
 
 extern "C" {
@@ -350,30 +403,55 @@ int32_t msj_sharded_create(msj_ctx *ctx, const msj_exchange *xchg, const msj_sha
     if (!sh) return MSJ_MEMALLOC;
     if (ops) {
         sh->ops = *ops;
+        sh->side = ops->side_stream;
     } else {
+        sh->ops = msj_sharded_ops{};
         sh->ops.user = ctx;
         sh->ops.alloc = hip_alloc;
         sh->ops.free = hip_free;
         sh->ops.copy = hip_copy;
         sh->ops.sync = hip_sync;
         sh->ops.run_shard = hip_run_shard;
-        sh->hip_ops = true;
+        sh->ops.event_create = hip_event_create;
+        sh->ops.event_destroy = hip_event_destroy;
+        sh->ops.event_record = hip_event_record;
+        sh->ops.event_wait = hip_event_wait;
+        sh->ops.stream_wait = hip_stream_wait;
+        sh->ops.event_query = hip_event_query;
+        sh->ops.event_elapsed_ns = hip_event_elapsed_ns;
+        // the exchange's own stream, at the highest priority the device has: the all-gather and the read-back of
+        // submission k become ready at the same moment as the kernel of submission k + 1 (both wait for kernel k)
+        // and must not queue behind it.  Without it (creation failed) they share the submission's stream.
+        int least = 0, greatest = 0;
+        hipStream_t side = nullptr;
+        if (hipSetDevice(msj_ctx_device(ctx)) == hipSuccess &&
+            hipDeviceGetStreamPriorityRange(&least, &greatest) == hipSuccess &&
+            hipStreamCreateWithPriority(&side, hipStreamNonBlocking, greatest) == hipSuccess) {
+            sh->side = side;
+            sh->owns_side = true;
+        } else {
+            (void)hipGetLastError();
+        }
     }
+    const msj_sharded_ops &o = sh->ops;
+    sh->events = o.event_create && o.event_destroy && o.event_record && o.event_wait && o.stream_wait;
+    if (!sh->events) sh->side = nullptr;  // nothing could order a second stream behind the kernel
     sh->x = *xchg;
     if (xchg->owns_comm) sh->owned_rccl = static_cast<RcclExchange *>(xchg->comm);
     const uint64_t wb = (uint64_t)xchg->world * sizeof(msj_shard_report);
     for (Slot &sl : sh->slots) {
         void *p = nullptr;
-        bool ok = sh->ops.alloc(sh->ops.user, sizeof(msj_shard_report), 0, &p) == MSJ_SUCCESS;
+        bool ok = o.alloc(o.user, sizeof(msj_shard_report), 0, &p) == MSJ_SUCCESS;
         sl.d_mine = static_cast<msj_shard_report *>(p);
-        ok = ok && sh->ops.alloc(sh->ops.user, wb, 0, &p) == MSJ_SUCCESS;
+        ok = ok && o.alloc(o.user, wb, 0, &p) == MSJ_SUCCESS;
         if (ok) sl.d_gathered = static_cast<msj_shard_report *>(p);
-        ok = ok && sh->ops.alloc(sh->ops.user, wb, 1, &p) == MSJ_SUCCESS;
+        ok = ok && o.alloc(o.user, wb, 1, &p) == MSJ_SUCCESS;
         if (ok) sl.h_gathered = static_cast<msj_shard_report *>(p);
-        ok = ok && sh->ops.alloc(sh->ops.user, sizeof(msj_carry), 1, &p) == MSJ_SUCCESS;
+        ok = ok && o.alloc(o.user, sizeof(msj_carry), 1, &p) == MSJ_SUCCESS;
         if (ok) sl.h_spec = static_cast<msj_carry *>(p);
-        if (ok && sh->hip_ops)  // without the events the stitch is simply not timed
-            sl.timed = hipEventCreate(&sl.ev_kernel) == hipSuccess && hipEventCreate(&sl.ev_stitch) == hipSuccess;
+        if (ok && sh->events)
+            ok = o.event_create(o.user, &sl.ev_start) == MSJ_SUCCESS && o.event_create(o.user, &sl.ev_kernel) == MSJ_SUCCESS &&
+                 o.event_create(o.user, &sl.ev_stitch) == MSJ_SUCCESS;
         if (!ok) {
             msj_sharded_destroy(sh);
             return MSJ_MEMALLOC;
@@ -383,16 +461,29 @@ int32_t msj_sharded_create(msj_ctx *ctx, const msj_exchange *xchg, const msj_sha
     return MSJ_SUCCESS;
 }
 
+// best effort: nothing of this slot is in flight any more (error paths and destruction)
+static void drain_slot(msj_sharded *sh, Slot &sl) {
+    const msj_sharded_ops &o = sh->ops;
+    (void)o.sync(o.user, sl.stream);
+    if (sh->side) (void)o.sync(o.user, sh->side);
+}
+
 void msj_sharded_destroy(msj_sharded *sh) {
     if (!sh) return;
+    const msj_sharded_ops &o = sh->ops;
     for (Slot &sl : sh->slots) {
-        sh->ops.free(sh->ops.user, sl.d_mine, 0);
-        sh->ops.free(sh->ops.user, sl.d_gathered, 0);
-        sh->ops.free(sh->ops.user, sl.h_gathered, 1);
-        sh->ops.free(sh->ops.user, sl.h_spec, 1);
-        if (sl.ev_kernel) (void)hipEventDestroy(sl.ev_kernel);
-        if (sl.ev_stitch) (void)hipEventDestroy(sl.ev_stitch);
+        if (sl.busy) drain_slot(sh, sl);  // a submission nobody asked the result of
+        o.free(o.user, sl.d_mine, 0);
+        o.free(o.user, sl.d_gathered, 0);
+        o.free(o.user, sl.h_gathered, 1);
+        o.free(o.user, sl.h_spec, 1);
+        if (sh->events) {
+            if (sl.ev_start) o.event_destroy(o.user, sl.ev_start);
+            if (sl.ev_kernel) o.event_destroy(o.user, sl.ev_kernel);
+            if (sl.ev_stitch) o.event_destroy(o.user, sl.ev_stitch);
+        }
     }
+    if (sh->owns_side) (void)hipStreamDestroy(static_cast<hipStream_t>(sh->side));
     delete sh->owned_rccl;
     delete sh;
 }
@@ -407,13 +498,33 @@ int32_t msj_sharded_get_stats(const msj_sharded *sh, msj_sharded_stats *out) {
     out->reruns = sh->reruns;
     out->stitch_device_ns = sh->stitch_device_ns;
     out->result_wait_ns = sh->result_wait_ns;
+    out->kernel_device_ns = sh->kernel_device_ns;
+    out->last_kernel_ns = sh->last_kernel_ns;
+    out->last_stitch_ns = sh->last_stitch_ns;
+    out->reruns_behind_queue = sh->reruns_behind_queue;
     return MSJ_SUCCESS;
 }
 
-// kernel (with the carry in sl.h_spec) -> all-gather of the reports -> pinned host copy; nothing waits here
+int32_t msj_sharded_ticket_state(msj_sharded *sh, uint32_t ticket) {
+    if (!sh || ticket >= kDepth || !sh->slots[ticket].busy) return MSJ_ERR_BAD_ARGUMENT;
+    const msj_sharded_ops &o = sh->ops;
+    if (!sh->events || !o.event_query) return MSJ_SHARDED_KERNEL_DONE | MSJ_SHARDED_REPORTS_IN;  // synchronous operations
+    const Slot &sl = sh->slots[ticket];
+    const int32_t k = o.event_query(o.user, sl.ev_kernel), r = o.event_query(o.user, sl.ev_stitch);
+    if (k < 0 || r < 0) return MSJ_ERR_HIP;
+    return (k ? MSJ_SHARDED_KERNEL_DONE : 0) | (r ? MSJ_SHARDED_REPORTS_IN : 0);
+}
+
+// kernel (with the carry in sl.h_spec) on the submission's stream -> all-gather of the reports -> pinned host copy,
+// both on the exchange's stream behind the kernel's event; nothing waits here
 static int32_t launch_round(msj_sharded *sh, Slot &sl, bool run_kernel, uint32_t extra_flags) {
     const msj_sharded_ops &o = sh->ops;
     int32_t rc;
+    sl.kernel_ran = run_kernel;
+    if (sh->events) {
+        rc = o.event_record(o.user, sl.ev_start, sl.stream);
+        if (rc != MSJ_SUCCESS) return rc;
+    }
     if (run_kernel) {
         rc = o.copy(o.user, &sl.d_mine->used, sl.h_spec, sizeof(msj_carry), 0, sl.stream);
         if (rc != MSJ_SUCCESS) return rc;
@@ -423,12 +534,21 @@ static int32_t launch_round(msj_sharded *sh, Slot &sl, bool run_kernel, uint32_t
                          sl.flags | extra_flags);
         if (rc != MSJ_SUCCESS) return rc;
     }
-    if (sl.timed) (void)hipEventRecord(sl.ev_kernel, static_cast<hipStream_t>(sl.stream));
-    rc = sh->x.allgather(sh->x.comm, sl.d_mine, sl.d_gathered, sizeof(msj_shard_report), sl.stream);
+    void *xs = sl.stream;  // the stream of the exchange
+    if (sh->events) {
+        rc = o.event_record(o.user, sl.ev_kernel, sl.stream);
+        if (rc != MSJ_SUCCESS) return rc;
+        if (sh->side) {
+            xs = sh->side;
+            rc = o.stream_wait(o.user, xs, sl.ev_kernel);
+            if (rc != MSJ_SUCCESS) return rc;
+        }
+    }
+    rc = sh->x.allgather(sh->x.comm, sl.d_mine, sl.d_gathered, sizeof(msj_shard_report), xs);
     if (rc != MSJ_SUCCESS) return rc;
     sh->rounds++;
-    rc = o.copy(o.user, sl.h_gathered, sl.d_gathered, (uint64_t)sh->x.world * sizeof(msj_shard_report), 1, sl.stream);
-    if (rc == MSJ_SUCCESS && sl.timed) (void)hipEventRecord(sl.ev_stitch, static_cast<hipStream_t>(sl.stream));
+    rc = o.copy(o.user, sl.h_gathered, sl.d_gathered, (uint64_t)sh->x.world * sizeof(msj_shard_report), 1, xs);
+    if (rc == MSJ_SUCCESS && sh->events) rc = o.event_record(o.user, sl.ev_stitch, xs);
     return rc;
 }
 
@@ -440,6 +560,7 @@ int32_t msj_stage1_sharded_submit(msj_sharded *sh, const uint8_t *d_shard, uint6
     Slot &sl = sh->slots[sh->next];
     if (sl.busy) return MSJ_CAPACITY;  // more than kDepth submissions without a result
     const msj_sharded_ops &o = sh->ops;
+    uint64_t looked = 0;
     if (speculation) {
         // only the three carry bits are the caller's to assume: counts, bytes and sticky flags start at zero
         std::memset(sl.h_spec, 0, sizeof(msj_carry));
@@ -452,14 +573,15 @@ int32_t msj_stage1_sharded_submit(msj_sharded *sh, const uint8_t *d_shard, uint6
         // from the shard's own bytes: the 64 stream bytes in front of it and its first 4 KiB -- or, while those
         // contradict neither hypothesis (strings made of digits, blanks or the letters of the literals), its first
         // 64 KiB, then its first MiB: a refuted guess costs the whole shard a second launch, a longer look one more
-        // small read, once per placed shard
+        // small blocking read.  A shard whose first look is what it was when its last result was verified takes
+        // that result's carry instead of the longer looks.  A caller that resubmits an unchanged shard should pass
+        // the carry its last result reported as used (`speculation`): then nothing is read here at all.
         static const uint64_t kHeads[] = {4096, 65536, 1048576};
-        uint8_t small[64 + 4096];
         uint8_t *big = nullptr;
         int32_t rc = MSJ_SUCCESS;
         for (const uint64_t want : kHeads) {
             const uint64_t head = shard_len < want ? shard_len : want;
-            uint8_t *ctx_bytes = small;
+            uint8_t *ctx_bytes = sl.look;
             if (head > 4096) {
                 if (!big) big = new (std::nothrow) uint8_t[64 + kHeads[2]];
                 if (!big) break;  // keep the guess from the shorter head
@@ -470,10 +592,22 @@ int32_t msj_stage1_sharded_submit(msj_sharded *sh, const uint8_t *d_shard, uint6
             int32_t decided = 0;
             if (rc == MSJ_SUCCESS) rc = msj_shard_speculate_ex(ctx_bytes, 64, ctx_bytes + 64, head, sl.h_spec, &decided);
             if (rc != MSJ_SUCCESS || decided || head == shard_len) break;
+            if (head <= 4096) {
+                looked = 64 + head;
+                if (sh->proven.d_shard == d_shard && sh->proven.shard_len == shard_len && sh->proven.n == looked &&
+                    std::memcmp(sh->proven.bytes, sl.look, looked) == 0) {
+                    std::memset(sl.h_spec, 0, sizeof(msj_carry));
+                    sl.h_spec->in_string = sh->proven.carry.in_string & 1u;
+                    sl.h_spec->next_is_escaped = sh->proven.carry.next_is_escaped & 1u;
+                    sl.h_spec->prev_scalar = sh->proven.carry.prev_scalar & 1u;
+                    break;
+                }
+            }
         }
         delete[] big;
         if (rc != MSJ_SUCCESS) return rc;
     }
+    sl.looked = looked;
     sl.d_shard = d_shard;
     sl.shard_len = shard_len;
     sl.d_idx = d_idx;
@@ -485,7 +619,12 @@ int32_t msj_stage1_sharded_submit(msj_sharded *sh, const uint8_t *d_shard, uint6
     sl.stream = stream;
     sl.flags = flags;
     const int32_t rc = launch_round(sh, sl, true, 0);
-    if (rc != MSJ_SUCCESS) return rc;
+    if (rc != MSJ_SUCCESS) {
+        // part of the round may be queued (the carry's copy, the kernel, an exchange that failed behind them) and
+        // reads or writes this slot's buffers: nothing of it may be pending when the slot is handed out again
+        drain_slot(sh, sl);
+        return rc;
+    }
     sl.busy = true;
     *ticket_out = sh->next;
     sh->next = (sh->next + 1) % kDepth;
@@ -499,20 +638,35 @@ int32_t msj_stage1_sharded_result(msj_sharded *sh, uint32_t ticket, int32_t *cod
     const msj_sharded_ops &o = sh->ops;
     const uint32_t world = sh->x.world, rank = sh->x.rank;
     msj_carry exact[64];
-    // whatever goes wrong below, the ticket is free again afterwards (the submission is lost, not the slot)
+    // whatever goes wrong below, the ticket is free again afterwards (the submission is lost, not the slot) -- and
+    // nothing of it is still queued: an error return leaves with the slot's streams drained, so that the next
+    // submission that is given this slot cannot overwrite h_spec / h_gathered under a pending copy
     struct Release {
+        msj_sharded *sh;
         Slot &sl;
-        ~Release() { sl.busy = false; }
-    } release{sl};
+        bool failed = true;
+        ~Release() {
+            if (failed) drain_slot(sh, sl);
+            sl.busy = false;
+        }
+    } release{sh, sl};
     for (;;) {
         const auto t0 = std::chrono::steady_clock::now();
-        int32_t rc = o.sync(o.user, sl.stream);
+        // THIS submission's reports only: later submissions on the same stream keep running (with synchronous
+        // operations -- no events -- the stream is drained as before)
+        int32_t rc = sh->events ? o.event_wait(o.user, sl.ev_stitch) : o.sync(o.user, sl.stream);
         sh->result_wait_ns += (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count();
         if (rc != MSJ_SUCCESS) return rc;
-        if (sl.timed) {
-            float ms = 0.f;
-            if (hipEventElapsedTime(&ms, sl.ev_kernel, sl.ev_stitch) == hipSuccess && ms > 0.f)
-                sh->stitch_device_ns += (uint64_t)((double)ms * 1e6);
+        if (sh->events && o.event_elapsed_ns) {
+            uint64_t ns = 0;
+            if (sl.kernel_ran && o.event_elapsed_ns(o.user, sl.ev_start, sl.ev_kernel, &ns) == MSJ_SUCCESS) {
+                sh->kernel_device_ns += ns;
+                sh->last_kernel_ns = ns;
+            }
+            if (o.event_elapsed_ns(o.user, sl.ev_kernel, sl.ev_stitch, &ns) == MSJ_SUCCESS) {
+                sh->stitch_device_ns += ns;
+                sh->last_stitch_ns = ns;
+            }
         }
         uint64_t mask = 0;
         const int32_t known = msj_shard_verify(sl.h_gathered, world, exact, &mask);
@@ -529,11 +683,27 @@ int32_t msj_stage1_sharded_result(msj_sharded *sh, uint32_t ticket, int32_t *cod
             sl.h_spec->count = 0;  // index arrays stay shard-local: every shard counts from 0 ...
             sl.h_spec->bytes = 0;  // ... its own bytes (the stitched offsets come back as msj_shard_placement)
             sh->reruns++;
+            // the second launch goes to the END of the submission's stream: behind the kernels of the submissions
+            // made since (one context = one workspace: launches of a context are stream-ordered).  Counted, so that
+            // a caller sees it; a caller that passes the carry its last result proved never gets here twice.
+            for (const Slot &other : sh->slots)
+                if (&other != &sl && other.busy && other.stream == sl.stream) {
+                    sh->reruns_behind_queue++;
+                    break;
+                }
         }
         rc = launch_round(sh, sl, mine, extra);
         if (rc != MSJ_SUCCESS) return rc;
     }
+    release.failed = false;
     sh->results++;
+    if (sl.looked) {  // an undecided first look: remember what the chain proved for these bytes
+        sh->proven.d_shard = sl.d_shard;
+        sh->proven.shard_len = sl.shard_len;
+        sh->proven.n = sl.looked;
+        sh->proven.carry = sl.h_gathered[rank].used;
+        std::memcpy(sh->proven.bytes, sl.look, sl.looked);
+    }
     uint64_t total = 0;
     const int32_t code = msj_shard_global_code(sl.h_gathered, world, sl.flags, &total);
     if (code_out) *code_out = code;

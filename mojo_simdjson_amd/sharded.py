@@ -55,7 +55,14 @@ class MsjShardPlacement(ctypes.Structure):
 class MsjShardedStats(ctypes.Structure):
     _fields_ = [("results", ctypes.c_uint64), ("rounds", ctypes.c_uint64), ("reruns", ctypes.c_uint64),
                 ("stitch_device_ns", ctypes.c_uint64), ("result_wait_ns", ctypes.c_uint64),
+                ("kernel_device_ns", ctypes.c_uint64), ("last_kernel_ns", ctypes.c_uint64),
+                ("last_stitch_ns", ctypes.c_uint64), ("reruns_behind_queue", ctypes.c_uint64),
                 ("reserved", ctypes.c_uint64 * 3)]
+
+
+STATS_FIELDS = ("results", "rounds", "reruns", "stitch_device_ns", "result_wait_ns", "kernel_device_ns",
+                "last_kernel_ns", "last_stitch_ns", "reruns_behind_queue")
+KERNEL_DONE, REPORTS_IN = 1, 2  # MSJ_SHARDED_* bits of msj_sharded_ticket_state
 
 
 class MsjShardedOps(ctypes.Structure):
@@ -69,6 +76,16 @@ class MsjShardedOps(ctypes.Structure):
         ("run_shard", ctypes.CFUNCTYPE(ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint64, ctypes.c_void_p,
                                        ctypes.c_uint64, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint32,
                                        ctypes.c_int32, ctypes.c_int32, ctypes.c_uint64, ctypes.c_void_p, ctypes.c_uint32)),
+        # optional (NULL: operations that complete before they return): events and the exchange's own stream
+        ("event_create", ctypes.CFUNCTYPE(ctypes.c_int32, ctypes.c_void_p, ctypes.POINTER(ctypes.c_void_p))),
+        ("event_destroy", ctypes.CFUNCTYPE(None, ctypes.c_void_p, ctypes.c_void_p)),
+        ("event_record", ctypes.CFUNCTYPE(ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p)),
+        ("event_wait", ctypes.CFUNCTYPE(ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p)),
+        ("stream_wait", ctypes.CFUNCTYPE(ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p)),
+        ("event_query", ctypes.CFUNCTYPE(ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p)),
+        ("event_elapsed_ns", ctypes.CFUNCTYPE(ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
+                                              ctypes.POINTER(ctypes.c_uint64))),
+        ("side_stream", ctypes.c_void_p),
     ]
 
 
@@ -105,6 +122,8 @@ def lib():
                                                 ctypes.POINTER(MsjCarry), ctypes.POINTER(MsjShardPlacement)]
         L.msj_sharded_get_stats.restype = i32
         L.msj_sharded_get_stats.argtypes = [vp, ctypes.POINTER(MsjShardedStats)]
+        L.msj_sharded_ticket_state.restype = i32
+        L.msj_sharded_ticket_state.argtypes = [vp, u32]
         L.msj_exchange_release.restype = None
         L.msj_exchange_release.argtypes = [ctypes.POINTER(MsjExchange)]
         L.msj_debug_set_segment_bytes.restype = i32
@@ -309,11 +328,21 @@ class ShardedStage1:
         return int(lib().msj_sharded_rounds(self._h)) if self._h else 0
 
     def stats(self):
-        """``msj_sharded_get_stats`` as a dict (cumulative): results, rounds, reruns, stitch_device_ns, result_wait_ns."""
+        """``msj_sharded_get_stats`` as a dict: cumulative results, rounds, reruns, stitch_device_ns, result_wait_ns,
+        kernel_device_ns, reruns_behind_queue; last_kernel_ns / last_stitch_ns of the last completed result."""
         st = MsjShardedStats()
         if self._h:
             lib().msj_sharded_get_stats(self._h, ctypes.byref(st))
-        return {k: int(getattr(st, k)) for k in ("results", "rounds", "reruns", "stitch_device_ns", "result_wait_ns")}
+        return {k: int(getattr(st, k)) for k in STATS_FIELDS}
+
+    def ticket_state(self, ticket):
+        """``msj_sharded_ticket_state``: KERNEL_DONE | REPORTS_IN bits of a submission in flight, without waiting."""
+        if "single" in ticket:
+            return KERNEL_DONE | REPORTS_IN
+        rc = lib().msj_sharded_ticket_state(self._h, ticket["ticket"])
+        if rc < 0:
+            raise RuntimeError(f"msj_sharded_ticket_state failed: {rc}")
+        return rc
 
     # ---- speculation from local bytes only (host logic; compute once per placed shard)
     def speculate(self, has_prefix, d_shard=None, shard_len=0, d_halo=None, host_halo=None, host_head=None):

@@ -22,6 +22,8 @@
 #include <random>
 #include <string>
 #include <thread>
+#include <deque>
+#include <functional>
 #include <vector>
 
 #include "../../include/msj_stage1.h"
@@ -43,6 +45,15 @@ hipError_t hipEventCreate(hipEvent_t *) { std::abort(); }
 hipError_t hipEventDestroy(hipEvent_t) { std::abort(); }
 hipError_t hipEventRecord(hipEvent_t, hipStream_t) { std::abort(); }
 hipError_t hipEventElapsedTime(float *, hipEvent_t, hipEvent_t) { std::abort(); }
+hipError_t hipEventSynchronize(hipEvent_t) { std::abort(); }
+hipError_t hipEventQuery(hipEvent_t) { std::abort(); }
+hipError_t hipStreamWaitEvent(hipStream_t, hipEvent_t, unsigned int) { std::abort(); }
+hipError_t hipGetLastError(void) { std::abort(); }
+hipError_t hipSetDevice(int) { std::abort(); }
+hipError_t hipDeviceGetStreamPriorityRange(int *, int *) { std::abort(); }
+hipError_t hipStreamCreateWithPriority(hipStream_t *, unsigned int, int) { std::abort(); }
+hipError_t hipStreamDestroy(hipStream_t) { std::abort(); }
+int32_t msj_ctx_device(const msj_ctx *) { std::abort(); }
 int32_t msj_stage1_shard_device(msj_ctx *, const uint8_t *, uint64_t, uint32_t *, uint64_t, const msj_carry *, msj_carry *,
                                 msj_segment *, uint32_t, uint32_t *, int32_t, int32_t, int32_t, uint64_t, void *, uint32_t) {
     std::abort();
@@ -155,17 +166,47 @@ struct World {
     std::vector<const void *> sends;
     explicit World(unsigned w) : world(w), bar(w), sends(w) {}
 };
+// An asynchronous fake device (the optional event operations of msj_sharded_ops): a stream is a queue of closures
+// that run only when somebody waits -- sync drains a stream, waiting for an event runs its stream up to the record.
+// Stream NULL = the submissions' stream, &side_tag = the exchange's.
+struct FakeDev {
+    unsigned launches = 0;
+    std::deque<std::function<void()>> q[2];
+    struct Ev {
+        bool done = false;
+        int stream = -1;
+        unsigned gen = 0;
+    };
+    char side_tag = 0;
+    int qi(void *stream) const { return stream == &side_tag ? 1 : 0; }
+    void drive(int stream, const Ev *until) {
+        while (!q[stream].empty() && !(until && until->done)) {
+            auto f = std::move(q[stream].front());
+            q[stream].pop_front();
+            f();
+        }
+    }
+};
+
 struct RankComm {
     World *w;
     unsigned rank;
+    FakeDev *async = nullptr;  // non-null: the collective is enqueued, like ncclAllGather on a stream
 };
 
-int32_t loop_allgather(void *comm, const void *d_send, void *d_recv, uint64_t bytes, void *) {
-    RankComm *c = static_cast<RankComm *>(comm);
+void gather_now(RankComm *c, const void *d_send, void *d_recv, uint64_t bytes) {
     c->w->sends[c->rank] = d_send;
     c->w->bar.wait();
     for (unsigned g = 0; g < c->w->world; g++) std::memcpy(static_cast<uint8_t *>(d_recv) + g * bytes, c->w->sends[g], bytes);
     c->w->bar.wait();
+}
+
+int32_t loop_allgather(void *comm, const void *d_send, void *d_recv, uint64_t bytes, void *stream) {
+    RankComm *c = static_cast<RankComm *>(comm);
+    if (c->async)
+        c->async->q[c->async->qi(stream)].push_back([=] { gather_now(c, d_send, d_recv, bytes); });
+    else
+        gather_now(c, d_send, d_recv, bytes);
     return MSJ_SUCCESS;
 }
 
@@ -200,6 +241,53 @@ int32_t h_run(void *user, const uint8_t *d, uint64_t len, uint32_t *idx, uint64_
     return MSJ_SUCCESS;
 }
 
+// ... and the same operations on the asynchronous fake device
+int32_t a_copy(void *user, void *dst, const void *src, uint64_t bytes, int, void *stream) {
+    FakeDev *d = static_cast<FakeDev *>(user);
+    d->q[d->qi(stream)].push_back([=] { std::memcpy(dst, src, bytes); });
+    return MSJ_SUCCESS;
+}
+int32_t a_sync(void *user, void *stream) {
+    FakeDev *d = static_cast<FakeDev *>(user);
+    d->drive(d->qi(stream), nullptr);
+    return MSJ_SUCCESS;
+}
+int32_t a_run(void *user, const uint8_t *p, uint64_t len, uint32_t *idx, uint64_t cap, const msj_carry *cin, msj_carry *cout,
+              msj_segment *seg, uint32_t ms, int32_t hp, int32_t is_final, uint64_t trailer_len, void *stream, uint32_t flags) {
+    FakeDev *d = static_cast<FakeDev *>(user);
+    d->q[d->qi(stream)].push_back([=] { (void)h_run(&d->launches, p, len, idx, cap, cin, cout, seg, ms, hp, is_final, trailer_len, stream, flags); });
+    return MSJ_SUCCESS;
+}
+int32_t a_event_create(void *, void **out) {
+    *out = new FakeDev::Ev();
+    return MSJ_SUCCESS;
+}
+void a_event_destroy(void *, void *e) { delete static_cast<FakeDev::Ev *>(e); }
+int32_t a_event_record(void *user, void *e, void *stream) {
+    FakeDev *d = static_cast<FakeDev *>(user);
+    FakeDev::Ev *ev = static_cast<FakeDev::Ev *>(e);
+    ev->done = false;
+    ev->stream = d->qi(stream);
+    const unsigned gen = ++ev->gen;
+    d->q[ev->stream].push_back([=] {
+        if (ev->gen == gen) ev->done = true;
+    });
+    return MSJ_SUCCESS;
+}
+int32_t a_event_wait(void *user, void *e) {
+    FakeDev *d = static_cast<FakeDev *>(user);
+    FakeDev::Ev *ev = static_cast<FakeDev::Ev *>(e);
+    if (ev->stream >= 0) d->drive(ev->stream, ev);
+    CHECK(ev->done, "waited for an event nothing records");
+    return MSJ_SUCCESS;
+}
+int32_t a_stream_wait(void *user, void *stream, void *e) {
+    FakeDev *d = static_cast<FakeDev *>(user);
+    d->q[d->qi(stream)].push_back([=] { (void)a_event_wait(user, e); });
+    return MSJ_SUCCESS;
+}
+int32_t a_event_query(void *, void *e) { return static_cast<FakeDev::Ev *>(e)->done ? 1 : 0; }
+
 struct RankOut {
     int32_t code = -99;
     uint64_t total = 0;
@@ -209,7 +297,7 @@ struct RankOut {
     uint64_t reruns = 0;
 };
 
-uint64_t g_reruns = 0, g_clipped = 0;
+uint64_t g_reruns = 0, g_clipped = 0, g_async = 0, g_async_reruns = 0;
 
 void protocol_case(std::mt19937_64 &rng, const std::string &doc, const std::vector<uint64_t> &cuts, int short_rank) {
     const unsigned world = (unsigned)cuts.size() - 1;
@@ -217,12 +305,18 @@ void protocol_case(std::mt19937_64 &rng, const std::string &doc, const std::vect
     std::vector<RankOut> out(world);
     std::vector<std::thread> th;
     const bool given = rng() & 1;  // the speculation: handed in by the caller, or derived by the library from the bytes
+    const bool async = rng() & 2;  // the operations: complete before they return, or the asynchronous fake device
     for (unsigned rank = 0; rank < world; rank++)
         th.emplace_back([&, rank] {
-            RankComm comm{&w, rank};
+            FakeDev dev;
+            RankComm comm{&w, rank, async ? &dev : nullptr};
             msj_exchange x{&comm, loop_allgather, rank, world, 0, 0};
             unsigned launches = 0;
-            msj_sharded_ops ops{&launches, h_alloc, h_free, h_copy, h_sync, h_run};
+            msj_sharded_ops ops{&launches, h_alloc, h_free, h_copy, h_sync, h_run};  // no events: synchronous
+            if (async)
+                ops = msj_sharded_ops{&dev,           h_alloc,        h_free,       a_copy,        a_sync,
+                                      a_run,          a_event_create, a_event_destroy, a_event_record, a_event_wait,
+                                      a_stream_wait,  a_event_query,  nullptr,      &dev.side_tag};
             msj_sharded *sh = nullptr;
             CHECK(msj_sharded_create(nullptr, &x, &ops, &sh) == MSJ_SUCCESS, "create");
             const uint64_t lo = cuts[rank], hi = cuts[rank + 1], len = hi - lo;
@@ -234,15 +328,31 @@ void protocol_case(std::mt19937_64 &rng, const std::string &doc, const std::vect
             uint32_t *idx = static_cast<uint32_t *>(std::malloc((cap ? cap : 1) * sizeof(uint32_t)));
             msj_carry spec;
             if (given && rank) CHECK(msj_shard_speculate(buf.p + pad.size(), 64 - pad.size(), buf.p + 64, len < 4096 ? len : 4096, &spec) == 0, "speculate");
-            for (int round = 0; round < 2; round++) {  // twice: slots are reused
-                uint32_t ticket = 99;
+            // twice: slots are reused.  Asynchronous device: both submissions in flight before the first result
+            uint32_t tickets[2] = {99, 99};
+            auto submit = [&](int round) {
                 const int32_t src = msj_stage1_sharded_submit(sh, buf.p + halo, len, idx, cap, doc.size(), rank > 0,
-                                                              (given && rank) ? &spec : nullptr, nullptr, 0, nullptr, 0, &ticket);
+                                                              (given && rank) ? &spec : nullptr, nullptr, 0, nullptr, 0, &tickets[round]);
                 CHECK(src == MSJ_SUCCESS, "submit: %d (rank %u, len %llu)", src, rank, (unsigned long long)len);
+            };
+            auto result = [&](int round) {
                 msj_carry local, used;
-                CHECK(msj_stage1_sharded_result(sh, ticket, &out[rank].code, &out[rank].total, &local, &used, &out[rank].place) == MSJ_SUCCESS,
+                CHECK(msj_stage1_sharded_result(sh, tickets[round], &out[rank].code, &out[rank].total, &local, &used, &out[rank].place) == MSJ_SUCCESS,
                       "result");
                 CHECK(local.count == out[rank].place.count && out[rank].place.bytes == len, "placement counts");
+            };
+            if (async) {
+                submit(0);
+                submit(1);
+                CHECK(given && rank ? msj_sharded_ticket_state(sh, tickets[1]) == 0 : true, "nothing has run before anybody waits");
+                result(0);
+                result(1);
+                launches = dev.launches;
+            } else {
+                for (int round = 0; round < 2; round++) {
+                    submit(round);
+                    result(round);
+                }
             }
             out[rank].idx.assign(idx, idx + (out[rank].place.count < cap ? out[rank].place.count : cap));
             out[rank].launches = launches;
@@ -271,6 +381,10 @@ void protocol_case(std::mt19937_64 &rng, const std::string &doc, const std::vect
     }
     CHECK(begin == all.idx.size(), "counts add up");
     for (const RankOut &r : out) g_reruns += r.reruns;
+    if (async) {
+        g_async++;
+        for (const RankOut &r : out) g_async_reruns += r.reruns;
+    }
     g_clipped += clipped;
     if (want == MSJ_SUCCESS || want == MSJ_EMPTY) want = clipped ? MSJ_CAPACITY : want;
     for (unsigned rank = 0; rank < world; rank++) CHECK(out[rank].code == want, "rank %u: code %d, want %d", rank, out[rank].code, want);
@@ -320,6 +434,8 @@ int main(int argc, char **argv) {
     }
     CHECK(g_reruns > 0 && g_clipped > 0, "the re-run loop and the capacity flag were exercised (%llu, %llu)", (unsigned long long)g_reruns,
           (unsigned long long)g_clipped);
+    CHECK(g_async > 0 && g_async_reruns > 0, "the event operations (two submissions in flight) and re-runs under them were exercised (%llu, %llu)",
+          (unsigned long long)g_async, (unsigned long long)g_async_reruns);
     {  // shards whose first 4 KiB (and first 64 KiB) decide nothing: the library reads a longer head, never past the shard
         std::string d = "[\"";
         for (int i = 0; i < 30000; i++) d += "1 2 3 ";

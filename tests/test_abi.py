@@ -41,8 +41,38 @@ def test_struct_layouts():
     assert ctypes.sizeof(_lib.MsjSegment) == 32
     from mojo_simdjson_amd import sharded
 
-    assert ctypes.sizeof(sharded.MsjShardPlacement) == 32 and ctypes.sizeof(sharded.MsjShardedStats) == 64
+    assert ctypes.sizeof(sharded.MsjShardPlacement) == 32 and ctypes.sizeof(sharded.MsjShardedStats) == 96
     assert ctypes.sizeof(sharded.MsjShardReport) == 128  # what one rank contributes to the all-gather
+    # the ctypes mirrors against the header itself: a C program prints sizeof / offsetof of what the bindings restate
+    import subprocess
+
+    out = os.path.join(helpers.ROOT, "tests", "_build")
+    os.makedirs(out, exist_ok=True)
+    src = os.path.join(out, "layout.c")
+    probes = [("msj_carry", _lib.MsjCarry, ["count", "in_string", "code", "capacity_error"]),
+              ("msj_segment", _lib.MsjSegment, ["count"]),
+              ("msj_tokens_result", _lib.MsjTokensResult, ["max_depth"]),
+              ("msj_documents_result", _lib.MsjDocumentsResult, ["resume_offset"]),
+              ("msj_shard_report", sharded.MsjShardReport, ["out"]),
+              ("msj_exchange", sharded.MsjExchange, ["allgather", "rank", "owns_comm"]),
+              ("msj_shard_placement", sharded.MsjShardPlacement, ["bytes"]),
+              ("msj_sharded_stats", sharded.MsjShardedStats, ["kernel_device_ns", "last_stitch_ns", "reruns_behind_queue"]),
+              ("msj_sharded_ops", sharded.MsjShardedOps, ["run_shard", "event_create", "stream_wait", "event_elapsed_ns",
+                                                          "side_stream"])]
+    with open(src, "w") as f:
+        f.write('#include <stddef.h>\n#include <stdio.h>\n#include "msj_stage1.h"\nint main(void) {\n')
+        for name, _, fields in probes:
+            f.write(f'printf("%zu", sizeof({name}));')
+            for fld in fields:
+                f.write(f'printf(" %zu", offsetof({name}, {fld}));')
+            f.write('printf("\\n");\n')
+        f.write("return 0; }\n")
+    exe = os.path.join(out, "layout")
+    subprocess.check_call(["gcc", "-std=c11", "-I" + os.path.join(helpers.ROOT, "include"), src, "-o", exe])
+    lines = subprocess.check_output([exe], text=True).split("\n")
+    for (name, cls, fields), line in zip(probes, lines):
+        want = [ctypes.sizeof(cls)] + [getattr(cls, fld).offset for fld in fields]
+        assert [int(x) for x in line.split()] == want, (name, line, want)
 
 
 def test_no_environment_switches():

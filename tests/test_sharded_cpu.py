@@ -9,6 +9,7 @@ import os
 import random
 import socket
 
+import pytest
 import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
@@ -163,7 +164,7 @@ class _HostOps:
         self.copy = f["copy"](self._copy)
         self.sync = f["sync"](lambda user, stream: 0)
         self.run_shard = f["run_shard"](self._run)
-        self.ops = O(None, self.alloc, self.free, self.copy, self.sync, self.run_shard)
+        self.ops = O(None, self.alloc, self.free, self.copy, self.sync, self.run_shard)  # no events: synchronous
 
     def _alloc(self, user, nbytes, pinned, out):
         b = ctypes.create_string_buffer(int(nbytes))
@@ -201,20 +202,188 @@ class _HostOps:
         return 0
 
 
-def _live_worker(rank, world, port, cases, q):
+class _DeferredOps(_HostOps):
+    """The same 'device', but ASYNCHRONOUS like the real one: a stream is a FIFO of closures that run only when
+    somebody waits (sync drains a stream; waiting for an event runs its stream up to the record and no further), with
+    events and a second stream for the exchange -- the optional part of msj_sharded_ops.  What ran, and when, is
+    what the tests of the per-slot waits look at."""
+
+    MAIN, SIDE = 0x1000, 0x2000
+
+    def __init__(self):
+        super().__init__()
+        self.queues = {self.MAIN: [], self.SIDE: [], None: []}
+        self.events = {}
+        self.log = []  # ("kernel", n) / ("exchange", n) in execution order
+        O = sharded.MsjShardedOps
+        f = dict(O._fields_)
+        self.sync = f["sync"](self._sync)
+        self.cbs = [f["event_create"](self._ev_create), f["event_destroy"](self._ev_destroy),
+                    f["event_record"](self._ev_record), f["event_wait"](self._ev_wait), f["stream_wait"](self._stream_wait),
+                    f["event_query"](self._ev_query)]
+        self.ops = O(None, self.alloc, self.free, self.copy, self.sync, self.run_shard, *self.cbs,
+                     f["event_elapsed_ns"](), self.SIDE)
+
+    # every operation with a stream argument is only QUEUED
+    def _copy(self, user, dst, src, nbytes, to_host, stream):
+        self.queues[stream].append(lambda: ctypes.memmove(dst, src, nbytes))
+        return 0
+
+    def _run(self, user, *a):
+        stream = a[11]
+        if self.fail_at == self.launches + 1:  # a launch failure is reported at enqueue time
+            self.launches += 1
+            return -3
+
+        def go():
+            rc = _HostOps._run(self, user, *a)
+            assert rc == 0
+            self.log.append(("kernel", self.launches))
+        self.queues[stream].append(go)
+        return 0
+
+    def enqueue_exchange(self, stream, fn):
+        def go():
+            fn()
+            self.log.append(("exchange", sum(1 for k, _ in self.log if k == "exchange") + 1))
+        self.queues[stream].append(go)
+
+    def _drive(self, stream, until=None):
+        q = self.queues[stream]
+        while q and not (until is not None and self.events[until]["done"]):
+            q.pop(0)()
+
+    def _sync(self, user, stream):
+        self._drive(stream)
+        return 0
+
+    def _ev_create(self, user, out):
+        h = 0x100 + len(self.events)
+        self.events[h] = {"done": False, "stream": None, "gen": 0}
+        out[0] = h
+        return 0
+
+    def _ev_destroy(self, user, ev):
+        self.events.pop(ev, None)
+
+    def _ev_record(self, user, ev, stream):
+        e = self.events[ev]
+        e["done"], e["stream"] = False, stream
+        e["gen"] += 1
+        gen = e["gen"]
+
+        def go():
+            if e["gen"] == gen:
+                e["done"] = True
+        self.queues[stream].append(go)
+        return 0
+
+    def _ev_wait(self, user, ev):
+        e = self.events[ev]
+        if e["stream"] is not None or e["gen"]:
+            self._drive(e["stream"], until=ev)
+        assert e["done"], "waited for an event nothing records"
+        return 0
+
+    def _stream_wait(self, user, stream, ev):
+        self.queues[stream].append(lambda: self._ev_wait(None, ev))
+        return 0
+
+    def _ev_query(self, user, ev):
+        return int(self.events[ev]["done"])
+
+
+def test_result_waits_for_its_own_submission_only():
+    """msj_stage1_sharded_result used to drain the whole stream, so that with three
+    submissions in flight result(0) returned when submission 2 had finished.  With event operations it waits for
+    the arrival of ITS reports: on an asynchronous fake device (nothing runs until somebody waits) exactly submission
+    0's kernel and exchange have run when result(0) returns; the exchange is on the side stream, behind the kernel's
+    event; a refuted guess indexes again behind the kernels submitted since, and is counted."""
+    L = sharded.lib()
+    host = _DeferredOps()
+
+    def allgather(comm, d_send, d_recv, nbytes, stream):
+        assert stream == host.SIDE  # the exchange's own stream, not the kernels'
+        host.enqueue_exchange(stream, lambda: ctypes.memmove(d_recv, d_send, nbytes))
+        return 0
+
+    cb = sharded.ALLGATHER_FN(allgather)
+    x = sharded.MsjExchange(None, cb, 0, 1, 0, 0)
+    h = ctypes.c_void_p()
+    assert L.msj_sharded_create(None, ctypes.byref(x), ctypes.byref(host.ops), ctypes.byref(h)) == 0
+    docs = [b'["abc",1]', b'{"k":[1,2,3],"s":"x y"}', b"[true,false,null,12.5]"]
+    bufs = [ctypes.create_string_buffer(d, len(d)) for d in docs]
+    idxs = [(ctypes.c_uint32 * (len(d) + 3))() for d in docs]
+
+    def submit(k, spec=None):
+        t = ctypes.c_uint32()
+        assert L.msj_stage1_sharded_submit(h, ctypes.addressof(bufs[k]), len(docs[k]), ctypes.addressof(idxs[k]), len(docs[k]) + 3,
+                                           len(docs[k]), 0, ctypes.byref(spec) if spec else None, None, 0, host.MAIN, 0,
+                                           ctypes.byref(t)) == 0
+        return t.value
+
+    def result(t):
+        code, total = ctypes.c_int32(), ctypes.c_uint64()
+        assert L.msj_stage1_sharded_result(h, t, ctypes.byref(code), ctypes.byref(total), None, None, None) == 0
+        return code.value, total.value
+
+    tickets = [submit(k) for k in range(3)]
+    assert host.log == [] and host.launches == 0  # nothing has run: submit only enqueues
+    assert [L.msj_sharded_ticket_state(h, t) for t in tickets] == [0, 0, 0]
+    for k in range(3):
+        want = serial_run(docs[k])[0]
+        assert result(tickets[k]) == (0, len(want)) and list(idxs[k][:len(want)]) == want
+        # exactly the submissions up to k have run; the later ones are still queued
+        assert host.log == [(kind, j + 1) for j in range(k + 1) for kind in ("kernel", "exchange")], (k, host.log)
+        assert [L.msj_sharded_ticket_state(h, t) for t in tickets[k + 1:]] == [0] * (2 - k)
+        assert L.msj_sharded_ticket_state(h, tickets[k]) == -1  # the ticket is gone
+    # a refuted guess with two later submissions in flight: the second launch queues behind their kernels
+    wrong = MsjCarry()
+    wrong.in_string = 1
+    host.log.clear()
+    tickets = [submit(0, wrong), submit(1), submit(2)]
+    want = serial_run(docs[0])[0]
+    assert result(tickets[0]) == (0, len(want)) and list(idxs[0][:len(want)]) == want
+    kinds = [k for k, _ in host.log]
+    # its own round first; the second launch is the LAST kernel: the two submissions made since ran in front of it
+    assert kinds == ["kernel", "exchange"] * 4, kinds
+    for k in (1, 2):
+        want_k = serial_run(docs[k])[0]
+        assert list(idxs[k][:len(want_k)]) == want_k
+    st = sharded.MsjShardedStats()
+    assert L.msj_sharded_get_stats(h, ctypes.byref(st)) == 0
+    assert (st.reruns, st.reruns_behind_queue) == (1, 1)
+    for k in (1, 2):
+        want = serial_run(docs[k])[0]
+        assert result(tickets[k]) == (0, len(want)) and list(idxs[k][:len(want)]) == want
+    # destroying with a submission nobody asked the result of drains it first (nothing is freed under pending work)
+    t = submit(1)
+    assert L.msj_sharded_ticket_state(h, t) == 0
+    before = len(host.log)
+    L.msj_sharded_destroy(h)
+    assert len(host.log) == before + 2 and not host.queues[host.MAIN] and not host.queues[host.SIDE]
+
+
+def _live_worker(rank, world, port, cases, q, deferred=False):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         L = sharded.lib()
-        host = _HostOps()
+        host = _DeferredOps() if deferred else _HostOps()
 
-        def allgather(comm, d_send, d_recv, nbytes, stream):
+        def gather_now(d_send, d_recv, nbytes):
             mine = torch.frombuffer(bytearray(ctypes.string_at(d_send, nbytes)), dtype=torch.uint8)
             gathered = torch.empty(world * nbytes, dtype=torch.uint8)
             dist.all_gather_into_tensor(gathered, mine)
             blob = gathered.numpy().tobytes()
             ctypes.memmove(d_recv, blob, len(blob))
+
+        def allgather(comm, d_send, d_recv, nbytes, stream):
+            if deferred:  # the collective runs when the fake device gets there, like an enqueued ncclAllGather
+                host.enqueue_exchange(stream, lambda: gather_now(d_send, d_recv, nbytes))
+            else:
+                gather_now(d_send, d_recv, nbytes)
             return 0
 
         cb = sharded.ALLGATHER_FN(allgather)
@@ -222,6 +391,21 @@ def _live_worker(rank, world, port, cases, q):
         h = ctypes.c_void_p()
         assert L.msj_sharded_create(None, ctypes.byref(x), ctypes.byref(host.ops), ctypes.byref(h)) == 0
         results = []
+        pending = []  # (ticket, lo, hi, cap, idx, alloc, launches before): deferred = up to three submissions in flight
+
+        def collect(ticket, lo, hi, cap, idx, alloc, before):
+            code, total = ctypes.c_int32(), ctypes.c_uint64()
+            local, used, place = MsjCarry(), MsjCarry(), sharded.MsjShardPlacement()
+            assert L.msj_stage1_sharded_result(h, ticket, ctypes.byref(code), ctypes.byref(total), ctypes.byref(local),
+                                               ctypes.byref(used), ctypes.byref(place)) == 0
+            n = int(local.count)
+            assert (int(place.byte_base), int(place.count), int(place.bytes)) == (lo, n, hi - lo)
+            results.append((code.value, int(total.value), [int(idx[k]) + lo for k in range(min(n, cap))],
+                            (used.next_is_escaped, used.in_string, used.prev_scalar),
+                            None if deferred else host.launches - before,  # in flight together: not attributable
+                            [int(idx[n + k]) for k in range(3)] if rank == world - 1 and n + 3 <= cap else None,
+                            int(place.index_begin)))
+
         for case in cases:
             data_hex, cuts = case[0], case[1]
             short = case[2] if len(case) > 2 else None  # (rank, capacity): that rank's index buffer is too small
@@ -239,16 +423,13 @@ def _live_worker(rank, world, port, cases, q):
             rc = L.msj_stage1_sharded_submit(h, d_shard, hi - lo, ctypes.addressof(idx), cap, len(data), int(rank > 0),
                                              None, None, 0, None, 0, ctypes.byref(ticket))
             assert rc == 0 and halo in (0, 64)
-            code, total = ctypes.c_int32(), ctypes.c_uint64()
-            local, used, place = MsjCarry(), MsjCarry(), sharded.MsjShardPlacement()
-            assert L.msj_stage1_sharded_result(h, ticket.value, ctypes.byref(code), ctypes.byref(total), ctypes.byref(local),
-                                               ctypes.byref(used), ctypes.byref(place)) == 0
-            n = int(local.count)
-            assert (int(place.byte_base), int(place.count), int(place.bytes)) == (lo, n, hi - lo)
-            results.append((code.value, int(total.value), [int(idx[k]) + lo for k in range(min(n, cap))],
-                            (used.next_is_escaped, used.in_string, used.prev_scalar), host.launches - before,
-                            [int(idx[n + k]) for k in range(3)] if rank == world - 1 and n + 3 <= cap else None,
-                            int(place.index_begin)))
+            pending.append((ticket.value, lo, hi, cap, idx, alloc, before))
+            if len(pending) == (3 if deferred else 1):
+                collect(*pending.pop(0))
+        while pending:
+            collect(*pending.pop(0))
+        if deferred:
+            assert host.launches == len(cases) + L.msj_sharded_reruns(h)
         st = sharded.MsjShardedStats()
         assert L.msj_sharded_get_stats(h, ctypes.byref(st)) == 0
         assert (st.results, st.rounds, st.reruns) == (len(cases), L.msj_sharded_rounds(h), L.msj_sharded_reruns(h))
@@ -315,10 +496,13 @@ def test_failed_rerun_frees_the_ticket():
     L.msj_sharded_destroy(h)
 
 
-def test_gloo_world2_live_protocol():
+@pytest.mark.parametrize("deferred", [False, True], ids=["synchronous_ops", "events_three_in_flight"])
+def test_gloo_world2_live_protocol(deferred):
     """The library's submit / result loop under gloo, world 2, on CPU: right guesses take one launch and one
     all-gather; a refuted guess makes exactly that rank launch again (the other one only re-contributes its
-    report); results equal the serial spec of the whole stream, error codes included."""
+    report); results equal the serial spec of the whole stream, error codes included.  Once with operations that
+    complete before they return, once on the asynchronous fake device (_DeferredOps: events, the exchange on its own
+    stream, per-slot waits) with three submissions in flight the way bench.py runs the GPUs."""
     rng = random.Random(8)
     alpha = b'\\\\\\""a1 ,:[]{}'
     cases = []
@@ -353,7 +537,7 @@ def test_gloo_world2_live_protocol():
     q = ctx.Queue()
     port = _free_port()
     payload = [(c[0].hex(),) + tuple(c[1:]) for c in cases]
-    procs = [ctx.Process(target=_live_worker, args=(r, 2, port, payload, q)) for r in range(2)]
+    procs = [ctx.Process(target=_live_worker, args=(r, 2, port, payload, q, deferred)) for r in range(2)]
     for p in procs:
         p.start()
     res = dict((r[0], r[1:]) for r in (q.get(timeout=180) for _ in range(2)))
@@ -376,11 +560,17 @@ def test_gloo_world2_live_protocol():
         assert r0[2] + r1[2] == idx, f"case {k}"
         e, s, ps = serial_state(data[:cuts[1]])
         assert r1[3] == (e, s, ps) and r0[3] == (0, 0, 0)
-        assert r0[4] == 1 and r1[4] in (1, 2)  # rank 0 never launches twice
-        if k == long_case:
-            assert r1[4] == 1 and r1[3] == (0, 1, 0), r1[3:5]  # the longer look got it right: one launch
-        total_reruns += r1[4] - 1
+        if deferred:
+            if k == long_case:
+                assert r1[3] == (0, 1, 0), r1[3]
+        else:
+            assert r0[4] == 1 and r1[4] in (1, 2)  # rank 0 never launches twice
+            if k == long_case:
+                assert r1[4] == 1 and r1[3] == (0, 1, 0), r1[3:5]  # the longer look got it right: one launch
+            total_reruns += r1[4] - 1
         if want_code in (0, 13):
             assert r1[5] == [len(data), len(data), 0]
+    if deferred:
+        total_reruns = res[1][1]
     assert res[0][1] == 0 and res[1][1] == total_reruns and total_reruns >= 2  # the refuted-guess cases did re-run
     assert res[0][2] == res[1][2] == len(cases) + total_reruns  # one all-gather per launch round, on every rank

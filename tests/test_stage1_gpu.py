@@ -1009,6 +1009,7 @@ def _rccl_single_rank_worker(port, q, exchange="rccl"):
         st = sh.stats()
         assert sh.exchange_used == exchange and sh.rccl_ranks == (1 if exchange == "rccl" else 0)
         assert st["results"] == 6 and st["rounds"] == 6 and st["reruns"] == 0 and st["stitch_device_ns"] > 0
+        assert st["kernel_device_ns"] > 0 and st["last_kernel_ns"] > 0 and st["reruns_behind_queue"] == 0
         assert sh.last_placement == (0, 0, total, len(data))
         q.put(([(o[0], o[1]) for o in out], got))
         dev.close()
@@ -1034,6 +1035,78 @@ def test_sharded_rccl_plumbing_single_rank(oracle, exchange):
     assert all(r == (code, n) for r in res), res
     want = np.concatenate([idx[:n], np.array([len(data), len(data), 0], dtype=np.uint32)]).astype(np.uint32)
     assert got == want.tobytes()
+
+
+def _rccl_overlap_worker(port, q):
+    """world 1 over the real RCCL backend, the library's own ncclAllGather, three
+    submissions of a 3 GiB shard in flight: when result(0) returns, the kernel of submission 2 has not finished
+    (msj_stage1_sharded_result used to hipStreamSynchronize the stream all three sit on)."""
+    import time
+
+    import torch
+    import torch.distributed as dist
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        from mojo_simdjson_amd import sharded, synth
+        from mojo_simdjson_amd.device import Stage1Device
+
+        dev = Stage1Device(0)
+        unit = synth.workload("minified", 32 << 20)
+        reps = (3 << 30) // unit.size
+        d_buf = torch.from_numpy(unit).to(dev.device).repeat(reps)
+        n_bytes = int(d_buf.numel())
+        sh = sharded.ShardedStage1(dev, 0, 1, always_gather=True, exchange="rccl")
+        d_idx = torch.empty(n_bytes // 2, dtype=torch.int32, device=dev.device)
+
+        def three():
+            tickets = [sh.submit(d_buf, n_bytes, d_idx, n_bytes, has_prefix=False) for _ in range(3)]
+            t0 = time.perf_counter()
+            r0 = sh.result(tickets[0])
+            states = [sh.ticket_state(t) for t in tickets[1:]]
+            t1 = time.perf_counter()
+            rest = [sh.result(t) for t in tickets[1:]]
+            t2 = time.perf_counter()
+            return r0, states, rest, (t1 - t0) * 1e3, (t2 - t1) * 1e3
+
+        three()  # warm-up: communicator, streams, clocks
+        torch.cuda.synchronize()
+        r0, states, rest, ms_first, ms_rest = three()
+        st = sh.stats()
+        q.put(dict(exchange=sh.exchange_used, states=states, codes=[r0[0]] + [r[0] for r in rest],
+                   counts=[r0[1]] + [r[1] for r in rest], unit=unit.tobytes(), reps=reps, ms_first=ms_first, ms_rest=ms_rest,
+                   last_kernel_ms=st["last_kernel_ns"] / 1e6, last_stitch_us=st["last_stitch_ns"] / 1e3, stats=st))
+        sh.close()
+        dev.close()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_sharded_result_does_not_drain_later_submissions(oracle):
+    import multiprocessing as mp
+
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_rccl_overlap_worker, args=(29500 + (os.getpid() % 400) + 433, q))
+    p.start()
+    r = q.get(timeout=300)
+    p.join(timeout=60)
+    assert p.exitcode == 0
+    assert r["exchange"] == "rccl"
+    code, n, _ = helpers.run_oracle(oracle.msj_oracle_stage1, r["unit"])
+    assert r["codes"] == [0, 0, 0] and code == 0 and r["counts"] == [n * r["reps"]] * 3
+    from mojo_simdjson_amd import sharded
+
+    # submission 2's kernel is still running (or queued) when result(0) has returned; the time result(0) blocked is
+    # about one kernel, and the two later results cost the host about two kernels more -- not zero, as they did when
+    # result(0) had drained the stream
+    assert not (r["states"][1] & sharded.KERNEL_DONE), r
+    assert r["ms_rest"] > 0.8 * r["last_kernel_ms"], r
+    print(f"result(0) blocked {r['ms_first']:.3f} ms, results 1+2 {r['ms_rest']:.3f} ms more; kernel {r['last_kernel_ms']:.3f} ms, "
+          f"kernel end -> reports in {r['last_stitch_us']:.1f} us")
 
 
 def _shared_gpu_worker(k, barrier, q):
