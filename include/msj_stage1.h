@@ -104,8 +104,11 @@ typedef struct msj_carry {
     uint32_t capacity_error;  /* sticky: the index buffer could not hold every index so far (+ the 3 trailer words
                                  on a FINAL segment); writes were clipped.  A FINAL segment also reports it as
                                  code = MSJ_CAPACITY, a non-final shard only here (msj_shard_global_code reads it) */
-    uint32_t reserved[4];
+    uint32_t reserved[4];     /* [0], written by every shard call into its carry_out: bit 31 set, bits 0..2 the in_string /
+                                 next_is_escaped / prev_scalar the call STARTED from (handed down the chain of a shard of
+                                 several segments): what a rank of a sharded stream reports as the carry it used; [1..3] 0 */
 } msj_carry;
+#define MSJ_CARRY_ECHO_VALID 0x80000000u
 
 /* One <= 4 GiB piece of a larger input: offsets in
  * idx[index_begin .. index_begin+count) are relative to byte_base. */
@@ -214,6 +217,16 @@ int32_t msj_stage1_shard_device(msj_ctx *ctx, const uint8_t *d_buf, uint64_t len
                                 uint32_t max_segments, uint32_t *n_segments_out,
                                 int32_t has_prefix, int32_t is_final, int32_t no_emit,
                                 uint64_t trailer_len, void *stream, uint32_t flags);
+
+/* The same with the state at the shard's first byte given BY VALUE -- carry_bits: bit 0 in_string, bit 1
+ * next_is_escaped, bit 2 prev_scalar; structurals, bytes and the sticky flags start at zero -- instead of a device
+ * msj_carry: the start of a shard whose carries the host knows (or assumes: msj_shard_speculate).  Nothing has to be
+ * copied to the device in front of the launch. */
+int32_t msj_stage1_shard_device_cv(msj_ctx *ctx, const uint8_t *d_buf, uint64_t len, uint32_t *d_idx,
+                                   uint64_t idx_capacity, uint32_t carry_bits, msj_carry *d_carry_out,
+                                   msj_segment *d_segments, uint32_t max_segments, uint32_t *n_segments_out,
+                                   int32_t has_prefix, int32_t is_final, int32_t no_emit, uint64_t trailer_len,
+                                   void *stream, uint32_t flags);
 
 /*
  * ---- N-GPU form: one contiguous byte-range shard of one stream per rank (SURVEY.md section 8b

@@ -72,6 +72,7 @@ struct msj_ctx {
         const uint8_t *d_buf; uint64_t len; uint32_t *d_idx; uint64_t idx_capacity;
         const msj_carry *d_carry_in; msj_carry *d_carry_out; msj_segment *d_segments; uint32_t max_segments;
         bool has_prefix, is_final, no_emit; uint64_t trailer_len; hipStream_t stream; uint32_t flags;
+        bool by_value; uint32_t carry_bits;  // msj_stage1_shard_device_cv
     } last;
     struct HostRange { const uint8_t *base; uint64_t bytes; };
     std::vector<HostRange> pinned;  // msj_host_register: caller-owned host ranges the DMA engines can reach directly
@@ -134,8 +135,10 @@ int32_t enqueue_shard(msj_ctx *ctx, const uint8_t *d_buf, uint64_t len, uint32_t
                       uint64_t idx_capacity, const msj_carry *d_carry_in, msj_carry *d_carry_out,
                       msj_segment *d_segments, uint32_t max_segments, uint32_t *n_segments_out,
                       bool has_prefix, bool is_final, bool no_emit, uint64_t trailer_len,
-                      hipStream_t stream, uint32_t flags, uint32_t index_bias = 0) {
-    if (!ctx || !d_buf || !d_carry_in || !d_carry_out || len == 0) return MSJ_ERR_BAD_ARGUMENT;
+                      hipStream_t stream, uint32_t flags, uint32_t index_bias = 0, const uint32_t *carry_bits = nullptr) {
+    // carry_bits: the state at the shard's first byte by value (bit 0 in_string, 1 next_is_escaped, 2 prev_scalar;
+    // counts and sticky flags zero) instead of d_carry_in
+    if (!ctx || !d_buf || (!d_carry_in && !carry_bits) || !d_carry_out || len == 0) return MSJ_ERR_BAD_ARGUMENT;
     if ((reinterpret_cast<uintptr_t>(d_buf) & 15u) != 0) return MSJ_ERR_BAD_ARGUMENT;
     if (!no_emit && !d_idx) return MSJ_ERR_BAD_ARGUMENT;
     if ((reinterpret_cast<uintptr_t>(d_idx) & 15u) != 0) return MSJ_ERR_BAD_ARGUMENT;  // 16-B stores
@@ -149,6 +152,7 @@ int32_t enqueue_shard(msj_ctx *ctx, const uint8_t *d_buf, uint64_t len, uint32_t
     ctx->last.d_carry_in = d_carry_in; ctx->last.d_carry_out = d_carry_out; ctx->last.d_segments = d_segments;
     ctx->last.max_segments = max_segments; ctx->last.has_prefix = has_prefix; ctx->last.is_final = is_final;
     ctx->last.no_emit = no_emit; ctx->last.trailer_len = trailer_len; ctx->last.stream = stream; ctx->last.flags = flags;
+    ctx->last.by_value = carry_bits != nullptr; ctx->last.carry_bits = carry_bits ? *carry_bits : 0u;
 
     const uint64_t first_len = len < seg_bytes ? len : seg_bytes;
     const uint32_t max_tiles = (uint32_t)((first_len + msj::kTileBytes - 1) / msj::kTileBytes);
@@ -166,6 +170,8 @@ int32_t enqueue_shard(msj_ctx *ctx, const uint8_t *d_buf, uint64_t len, uint32_t
         const uint32_t wb = ctx->ws_toggle, wo = wb ^ 1u;
         a.ws = ctx->ws + (uint64_t)wb * ctx->ws_words;
         a.carry_in = (s == 0) ? d_carry_in : &ctx->carries[s];
+        a.carry_bits = 0;
+        a.reserved0 = 0;
         a.carry_out = (s + 1 == nseg) ? d_carry_out : &ctx->carries[s + 1];
         a.segment = d_segments ? &d_segments[s] : nullptr;
         a.segment_byte_base = base;
@@ -176,6 +182,12 @@ int32_t enqueue_shard(msj_ctx *ctx, const uint8_t *d_buf, uint64_t len, uint32_t
         if (has_prefix || s > 0) a.flags |= msj::kFlagHasPrefix;
         if (no_emit) a.flags |= msj::kFlagNoEmit;
         if (s == 0) a.flags |= flags & (15u << msj::kFlagSkipShift);
+        if (s > 0) a.flags |= msj::kFlagEchoThrough;
+        if (s == 0 && carry_bits) {
+            a.flags |= msj::kFlagCarryByValue;
+            a.carry_bits = *carry_bits & 7u;
+            a.carry_in = nullptr;
+        }
         a.stamps = g_stamps;
         a.wait_ticks = ctx->wait_ticks;
         // without a segment table nothing tells the caller where a later segment's offsets start: they stay
@@ -631,6 +643,17 @@ int32_t msj_stage1_shard_device(msj_ctx *ctx, const uint8_t *d_buf, uint64_t len
                          trailer_len, static_cast<hipStream_t>(stream), flags);
 }
 
+int32_t msj_stage1_shard_device_cv(msj_ctx *ctx, const uint8_t *d_buf, uint64_t len, uint32_t *d_idx,
+                                   uint64_t idx_capacity, uint32_t carry_bits, msj_carry *d_carry_out,
+                                   msj_segment *d_segments, uint32_t max_segments, uint32_t *n_segments_out,
+                                   int32_t has_prefix, int32_t is_final, int32_t no_emit, uint64_t trailer_len,
+                                   void *stream, uint32_t flags) {
+    if (carry_bits > 7u) return MSJ_ERR_BAD_ARGUMENT;
+    return enqueue_shard(ctx, d_buf, len, d_idx, idx_capacity, nullptr, d_carry_out, d_segments, max_segments,
+                         n_segments_out, has_prefix != 0, is_final != 0, no_emit != 0, trailer_len,
+                         static_cast<hipStream_t>(stream), flags, 0, &carry_bits);
+}
+
 extern "C" uint64_t msj_tokens_workspace_bytes(uint64_t n, int with_match);
 
 extern "C" int msj_launch_tokens(const uint8_t *d_buf, uint64_t len, const uint32_t *d_idx, uint64_t n, uint8_t *d_type,
@@ -803,7 +826,8 @@ int32_t msj_carry_fetch(msj_ctx *ctx, const msj_carry *d_carry, msj_carry *host_
         ctx->ws_dirty[0] = ctx->ws_dirty[1] = kAllDirty;  // the poisoned launch may have left anything behind
         const int32_t rc = enqueue_shard(ctx, L.d_buf, L.len, L.d_idx, L.idx_capacity, L.d_carry_in, L.d_carry_out,
                                          L.d_segments, L.max_segments, nullptr, L.has_prefix, L.is_final, L.no_emit,
-                                         L.trailer_len, L.stream, L.flags | MSJ_FLAG_TWO_PASS);
+                                         L.trailer_len, L.stream, L.flags | MSJ_FLAG_TWO_PASS, 0,
+                                         L.by_value ? &L.carry_bits : nullptr);
         if (rc != MSJ_SUCCESS) return rc;
         if (!hip_ok(hipStreamSynchronize(L.stream))) return MSJ_ERR_HIP;
         if (!hip_ok(hipMemcpyAsync(host_out, d_carry, sizeof(msj_carry), hipMemcpyDeviceToHost, s)) ||

@@ -176,6 +176,8 @@ struct msj_sharded {
     uint64_t reruns = 0, rounds = 0, results = 0, reruns_behind_queue = 0;
     uint64_t stitch_device_ns = 0, result_wait_ns = 0, kernel_device_ns = 0;
     uint64_t last_kernel_ns = 0, last_stitch_ns = 0;
+    bool hip_default = false; // the default HIP operations: the carry goes into the launch by value, the report's `used`
+                              // comes back as the echo in carry_out.reserved[0] -- no copy in front of the kernel
     bool events = false;      // ops has the event operations: per-slot waits, exchange beside the next kernel
     void *side = nullptr;     // the stream the exchange and the read-back are enqueued on (NULL: the submission's own)
     bool owns_side = false;   // created here (default HIP operations)
@@ -419,6 +421,7 @@ int32_t msj_sharded_create(msj_ctx *ctx, const msj_exchange *xchg, const msj_sha
         sh->ops.stream_wait = hip_stream_wait;
         sh->ops.event_query = hip_event_query;
         sh->ops.event_elapsed_ns = hip_event_elapsed_ns;
+        sh->hip_default = true;
         // the exchange's own stream, at the highest priority the device has: the all-gather and the read-back of
         // submission k become ready at the same moment as the kernel of submission k + 1 (both wait for kernel k)
         // and must not queue behind it.  Without it (creation failed) they share the submission's stream.
@@ -526,12 +529,23 @@ static int32_t launch_round(msj_sharded *sh, Slot &sl, bool run_kernel, uint32_t
         if (rc != MSJ_SUCCESS) return rc;
     }
     if (run_kernel) {
-        rc = o.copy(o.user, &sl.d_mine->used, sl.h_spec, sizeof(msj_carry), 0, sl.stream);
-        if (rc != MSJ_SUCCESS) return rc;
         const int32_t last = sh->x.rank + 1 == sh->x.world;
-        rc = o.run_shard(o.user, sl.d_shard, sl.shard_len, sl.d_idx, sl.idx_capacity, &sl.d_mine->used, &sl.d_mine->out,
-                         sl.d_segments, sl.max_segments, sl.has_prefix, last, sl.total_len, sl.stream,
-                         sl.flags | extra_flags);
+        if (sh->hip_default) {
+            // the three bits travel in the kernel's arguments and come back in carry_out.reserved[0] (the report's
+            // `used` half is rebuilt from that echo on the host): a 64-byte upload in front of every launch cost the
+            // stream ~9 us per step (profiles/r04/stitch_overlap.txt)
+            const uint32_t bits = (sl.h_spec->in_string & 1u) | ((sl.h_spec->next_is_escaped & 1u) << 1) |
+                                  ((sl.h_spec->prev_scalar & 1u) << 2);
+            rc = msj_stage1_shard_device_cv(static_cast<msj_ctx *>(o.user), sl.d_shard, sl.shard_len, sl.d_idx, sl.idx_capacity,
+                                            bits, &sl.d_mine->out, sl.d_segments, sl.max_segments, nullptr, sl.has_prefix,
+                                            last, 0, sl.total_len, sl.stream, sl.flags | extra_flags);
+        } else {
+            rc = o.copy(o.user, &sl.d_mine->used, sl.h_spec, sizeof(msj_carry), 0, sl.stream);
+            if (rc != MSJ_SUCCESS) return rc;
+            rc = o.run_shard(o.user, sl.d_shard, sl.shard_len, sl.d_idx, sl.idx_capacity, &sl.d_mine->used, &sl.d_mine->out,
+                             sl.d_segments, sl.max_segments, sl.has_prefix, last, sl.total_len, sl.stream,
+                             sl.flags | extra_flags);
+        }
         if (rc != MSJ_SUCCESS) return rc;
     }
     void *xs = sl.stream;  // the stream of the exchange
@@ -666,6 +680,17 @@ int32_t msj_stage1_sharded_result(msj_sharded *sh, uint32_t ticket, int32_t *cod
             if (o.event_elapsed_ns(o.user, sl.ev_kernel, sl.ev_stitch, &ns) == MSJ_SUCCESS) {
                 sh->stitch_device_ns += ns;
                 sh->last_stitch_ns = ns;
+            }
+        }
+        // a launch that echoes the carry it started from (carry_out.reserved[0], every launch of this library does)
+        // is taken at its word: its report's `used` half may never have been written
+        for (uint32_t g = 0; g < world; g++) {
+            const uint32_t echo = sl.h_gathered[g].out.reserved[0];
+            if (echo & MSJ_CARRY_ECHO_VALID) {
+                std::memset(&sl.h_gathered[g].used, 0, sizeof(msj_carry));
+                sl.h_gathered[g].used.in_string = echo & 1u;
+                sl.h_gathered[g].used.next_is_escaped = (echo >> 1) & 1u;
+                sl.h_gathered[g].used.prev_scalar = (echo >> 2) & 1u;
             }
         }
         uint64_t mask = 0;

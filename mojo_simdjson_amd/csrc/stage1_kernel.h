@@ -36,6 +36,11 @@ constexpr uint32_t kFlagFinal = 4u;        // last segment of the stream: traile
 constexpr uint32_t kFlagHasPrefix = 8u;    // buf[-64..0) holds the preceding stream bytes
 constexpr uint32_t kFlagNoEmit = 16u;      // summary pass: no index writes
 constexpr uint32_t kFlagDebugStall = 32u;  // test hook (MSJ_FLAG_DEBUG_STALL): the resolver idles ~2 ms before it starts
+constexpr uint32_t kFlagCarryByValue = 64u; // the state at the launch's first byte is KernelArgs.carry_bits (count, bytes and the
+                                            // sticky flags zero), not *carry_in: the start of a shard whose carries the host
+                                            // knows (msj_stage1_shard_device_cv) -- nothing has to be copied to the device first
+constexpr uint32_t kFlagEchoThrough = 128u; // a later segment of a chained shard: carry_out.reserved[0] = carry_in.reserved[0] (the
+                                            // echo of the carry the SHARD started from travels down the chain)
 constexpr uint32_t kFlagSkipShift = 24u;   // bits 24..27 == MSJ_FLAG_SKIP(n): the first n < 16 bytes of the launch read as blanks
 
 struct KernelArgs {
@@ -46,7 +51,7 @@ struct KernelArgs {
     uint64_t *ws;             // zeroed workspace: ticket + one descriptor per tile
     uint64_t *ws_clean;       // optional: the OTHER workspace buffer, dirtied by the previous launch with the
                               // same ntiles; this launch zeroes it word for word (no memset between launches)
-    const msj_carry *carry_in;
+    const msj_carry *carry_in; // (ignored with kFlagCarryByValue)
     msj_carry *carry_out;
     msj_segment *segment;     // optional: segment-table entry to fill
     uint64_t segment_byte_base;
@@ -56,6 +61,8 @@ struct KernelArgs {
     uint32_t index_bias;      // added to every index: byte offset of this launch's buffer inside the document
                               // (host-pointer pipeline: one launch per uploaded chunk, offsets stay absolute)
     uint32_t wait_ticks;      // bound of every wait in the kernel, in s_memrealtime ticks (10 ns); expiry poisons the launch
+    uint32_t carry_bits;      // kFlagCarryByValue: bit 0 in_string, bit 1 next_is_escaped, bit 2 prev_scalar
+    uint32_t reserved0;
     uint64_t *stamps;         // diagnostic builds only (-DMSJ_STAMPS): 16 words per tile, else null
     uint64_t *tp;             // two-pass path only: 2 * ntiles words (tile aggregates, tile prefixes)
 };

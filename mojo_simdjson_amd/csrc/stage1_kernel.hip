@@ -190,6 +190,35 @@ struct Shared {
     uint32_t pend_meta[kWaves][kPendSlots][4] __attribute__((aligned(16)));  // tile (~0 = empty), tile_cnt, in_cnt, in_s
 };
 
+// The state at the launch's first byte: *carry_in, or -- kFlagCarryByValue -- three bits of the kernel arguments
+// (everything else zero).  All scalar loads / scalar code.
+__device__ __forceinline__ uint64_t cin_count(const KernelArgs &a) {
+    return (a.flags & kFlagCarryByValue) ? 0ull : a.carry_in->count;
+}
+// next_is_escaped | prev_scalar << 1
+__device__ __forceinline__ uint32_t cin_carry0(const KernelArgs &a) {
+    return (a.flags & kFlagCarryByValue) ? (a.carry_bits >> 1) & 3u
+                                         : (a.carry_in->next_is_escaped & 1u) | ((a.carry_in->prev_scalar & 1u) << 1);
+}
+__device__ __forceinline__ uint32_t cin_in_string(const KernelArgs &a) {
+    return (a.flags & kFlagCarryByValue) ? a.carry_bits & 1u : a.carry_in->in_string & 1u;
+}
+__device__ __forceinline__ uint32_t cin_internal_error(const KernelArgs &a) {
+    return (a.flags & kFlagCarryByValue) ? 0u : a.carry_in->internal_error & 1u;
+}
+__device__ __forceinline__ msj_carry cin_all(const KernelArgs &a) {
+    if (!(a.flags & kFlagCarryByValue)) return *a.carry_in;
+    msj_carry c;
+    c.count = c.bytes = 0;
+    c.in_string = a.carry_bits & 1u;
+    c.next_is_escaped = (a.carry_bits >> 1) & 1u;
+    c.prev_scalar = (a.carry_bits >> 2) & 1u;
+    c.unescaped_error = c.utf8_error = c.internal_error = c.capacity_error = 0;
+    c.code = 0;
+    for (int k = 0; k < 4; k++) c.reserved[k] = 0;
+    return c;
+}
+
 // Waits are bounded by WALL TIME (s_memrealtime: a constant 100 MHz counter), not by a number
 // of polls: a.wait_ticks (default 2 s; tests lower it to force the expiry path).  The clock is read
 // once per 16 polls, for the first time after 16 (a short wait never reads it).  Expiry poisons
@@ -474,7 +503,7 @@ __device__ __forceinline__ TileCarry window_carries(const KernelArgs &a, const u
 // ---- one tile: masks, carries, counts; returns the tile aggregate in agg_word ------------
 // Written for latency as much as for instruction count: the wave-level decisions (a block starts
 // escaped? any byte >= 0x80?) are taken from ballots issued long before the branch that needs
-// them, and there is ONE rare branch (redo the escape scanner) instead of one per special case.
+// them, and there is ONE uniform branch for the blocks that start escaped instead of one per special case.
 __device__ __forceinline__ Pending compute_tile(const KernelArgs &a, const uint32_t tile,
                                                 const uint32_t lane, const Block &blk, const uint32_t carry0,
                                                 uint32_t &timeout, uint64_t &agg_word, const uint32_t exact = 0u) {
@@ -527,27 +556,28 @@ __device__ __forceinline__ Pending compute_tile(const KernelArgs &a, const uint3
     // ---- escapes (json_escape_scanner.mojo:18-45).  Per lane for carry-in 0: tt, and the carry the
     //      block would hand on (g).  Wave level: ballot g and "all 64 bytes are backslashes" (the
     //      carry propagates); the carries of the 64-bit addition (G|P) + G + carry_in are exactly
-    //      the per-lane carries (carry-lookahead).  A block that starts escaped is rare (the byte
+    //      the per-lane carries (carry-lookahead).  A block that starts escaped is the exception (the byte
     //      before it ends an odd run of backslashes): quotes and strings are computed for carry-in 0
     //      first, and only a tile that has such a block redoes them with the lanes' carries.
     // A tile without a quote or a backslash (the inside of a long string, a run of blanks, a column of numbers)
     // has no escape or string work at all: its in-string state is its predecessor's, for every byte.
     const uint64_t qb = cls.quote_chr | cls.backslash;
     const bool quiet = __ballot(((uint32_t)qb | (uint32_t)(qb >> 32)) != 0u) == 0ull && !partial && tc.resolved;  // uniform
-    uint64_t quote = 0, in_string0 = 0, escaped = 0;  // escaped: only needed (and only right) on the rare path
+    uint64_t quote = 0, in_string0 = 0, escaped = 0;  // escaped: only needed (and only right) where the scanner is redone
     uint32_t tile_e_out = 0, tile_par = 0;
     if (!quiet) {
         const uint64_t tt = escape_tt0(cls.backslash);
         const uint64_t G = __ballot(escape_out0(tt, cls.backslash) != 0u);
         const uint64_t Pm = __ballot(((uint32_t)cls.backslash & (uint32_t)(cls.backslash >> 32)) == 0xFFFFFFFFu);
         quote = unescaped_quotes0(cls.quote_chr, tt);  // eq['"'] & ~escaped  (json_string_scanner.mojo:58)
-        // ---- strings (json_string_scanner.mojo:55-69)
-        uint64_t S0 = prefix_xor(quote);  // in_string if the lane started outside a string
         const uint64_t add_a = G | Pm, add_b = G;
         uint64_t add_s = add_a + add_b + tc.e_in;
         uint64_t carries = add_s ^ add_a ^ add_b;
         MSJ_STAMP(tile, 3);
-        if (carries != 0ull || partial || !tc.resolved) {  // uniform, rare
+        if (carries != 0ull || partial || !tc.resolved) {
+            // Uniform, and NOT rare: a block starts escaped when the byte in front of it is an unescaped backslash, and
+            // with 7 .. 13 backslashes per KiB (the BASELINE workloads: `\/` in URLs, `\"`, `\uXXXX`) one of a tile's 64
+            // blocks does in 36 % (pretty-printed), 43 % (UTF-8-heavy), 58 % (minified) of the tiles.
             if (!tc.resolved) {
                 // >= 63 consecutive backslashes in front of the tile: exact carries from the predecessor
                 uint32_t to = 0;
@@ -558,11 +588,23 @@ __device__ __forceinline__ Pending compute_tile(const KernelArgs &a, const uint3
                 add_s = add_a + add_b + tc.e_in;
                 carries = add_s ^ add_a ^ add_b;
             }
-            uint32_t lane_e_out;
-            escaped = escaped_mask(cls.backslash, (uint32_t)(carries >> lane) & 1u, &lane_e_out);
-            quote = cls.quote_chr & ~escaped;
-            S0 = prefix_xor(quote);
+            // What the carry changes in a block whose first byte is NOT a backslash: that byte is escaped and nothing
+            // else (pe = backslash & ~1 = backslash, json_escape_scanner.mojo:39-45) -- a quote there is no quote.  Two
+            // operations on the lanes the carries name.  Only where an escaped block STARTS with a backslash (the
+            // run it opens changes parity: `\\\\` across a block border) is the scanner redone with the lanes' carries.
+            const uint64_t B0 = __ballot(((uint32_t)cls.backslash & 1u) != 0u);
+            if ((carries & B0) == 0ull && !partial) {  // uniform
+                const bool starts_escaped = __builtin_amdgcn_inverse_ballot_w64(carries);
+                const uint32_t qlo = (uint32_t)quote;
+                quote = u64(starts_escaped ? qlo & ~1u : qlo, (uint32_t)(quote >> 32));
+            } else {
+                uint32_t lane_e_out;
+                escaped = escaped_mask(cls.backslash, (uint32_t)(carries >> lane) & 1u, &lane_e_out);
+                quote = cls.quote_chr & ~escaped;
+            }
         }
+        // ---- strings (json_string_scanner.mojo:55-69): in_string if the lane started outside a string
+        const uint64_t S0 = prefix_xor(quote);
         tile_e_out = (uint32_t)(((add_a & add_b) | ((add_a | add_b) & ~add_s)) >> 63);
         const uint64_t PM = __ballot((int32_t)(uint32_t)(S0 >> 32) < 0);
         const uint32_t lane_par = lanes_below(PM);  // bit 0: parity of the lanes before me in the tile
@@ -1034,8 +1076,8 @@ __device__ __forceinline__ void worker_wave(const KernelArgs &a, Shared &sh, con
     MSJ_RSTAMP(a.ntiles + 4096u + blockIdx.x, 2, tid == 0);
     // LDS words every lane reads identically: uniform (tile indices and all control flow stay scalar)
     uint32_t lo_cur = uniform32(sh.first_lo);
-    const uint64_t count0 = uniform64(a.carry_in->count);  // launch invariants: read once
-    const uint32_t carry0 = uniform32((a.carry_in->next_is_escaped & 1u) | ((a.carry_in->prev_scalar & 1u) << 1));
+    const uint64_t count0 = uniform64(cin_count(a));  // launch invariants: read once
+    const uint32_t carry0 = uniform32(cin_carry0(a));
     uint32_t timeout = 0;
 
     Block blk[kBatch];
@@ -1275,7 +1317,7 @@ __device__ __forceinline__ void worker_wave(const KernelArgs &a, Shared &sh, con
 __device__ __forceinline__ void finish_launch(const KernelArgs &a, const uint32_t cs, const uint32_t cc,
                                               const uint32_t ce, const uint32_t cu, const uint32_t cx,
                                               const uint64_t *tile_agg = nullptr, const bool late_poison = false) {
-    const msj_carry cin = *a.carry_in;
+    const msj_carry cin = cin_all(a);
     if (!tile_agg) tile_agg = a.ws + kDescOffset;
     const uint64_t last = ld_desc(&tile_agg[a.ntiles - 1u]);  // last TILE's carries
     const bool do_utf8 = !(a.flags & kFlagNoUtf8);
@@ -1320,7 +1362,12 @@ __device__ __forceinline__ void finish_launch(const KernelArgs &a, const uint32_
         }
     }
     out.code = code;
-    for (int k = 0; k < 4; k++) out.reserved[k] = 0;
+    // reserved[0]: the three carry bits this launch STARTED from, with bit 31 set (msj_carry.reserved in
+    // include/msj_stage1.h): what a rank of a sharded stream reports as "used" without a copy of its own
+    out.reserved[0] = (a.flags & kFlagEchoThrough)
+                          ? cin.reserved[0]  // a later segment of a chained shard hands the shard's echo on
+                          : 0x80000000u | (cin.in_string & 1u) | ((cin.next_is_escaped & 1u) << 1) | ((cin.prev_scalar & 1u) << 2);
+    for (int k = 1; k < 4; k++) out.reserved[k] = 0;
     if (late_poison) {
         // single-pass kernel: workers may still OR a late timeout into internal_error (worker_wave), before
         // or after this store: every other field is stored, this one is ORed
@@ -1334,7 +1381,7 @@ __device__ __forceinline__ void finish_launch(const KernelArgs &a, const uint32_
         o->utf8_error = out.utf8_error;
         o->code = out.code;
         o->capacity_error = out.capacity_error;
-        for (int k = 0; k < 4; k++) o->reserved[k] = 0;
+        for (int k = 0; k < 4; k++) o->reserved[k] = out.reserved[k];
         if (out.internal_error) atomicOr(&o->internal_error, 1u);
     } else {
         *a.carry_out = out;
@@ -1385,9 +1432,9 @@ __device__ void resolver(const KernelArgs &a, Shared &sh) {
     }
     if (tid == 0) {
         // sticky from the stream so far; workers OR late timeouts into it (worker_wave), finish() ORs its own
-        a.carry_out->internal_error = a.carry_in->internal_error & 1u;
+        a.carry_out->internal_error = cin_internal_error(a);
         sh.rs_seq = 0;
-        sh.rs_s = a.carry_in->in_string & 1u;
+        sh.rs_s = cin_in_string(a);
         sh.rs_cnt = 0;
         sh.rs_err = 0;
         sh.rs_u8 = 0;
@@ -1587,7 +1634,7 @@ __global__ __launch_bounds__(kThreads) void twopass_summary_kernel(const KernelA
     if (tile >= a.ntiles) return;
     const uint32_t lane64 = lane * 64u;
     const uint32_t lane_off[4] = {lane64, lane64 + 16u, lane64 + 32u, lane64 + 48u};
-    const uint32_t carry0 = uniform32((a.carry_in->next_is_escaped & 1u) | ((a.carry_in->prev_scalar & 1u) << 1));
+    const uint32_t carry0 = uniform32(cin_carry0(a));
     Block blk;
     load_block<false>(a, tile, lane_off, lane, blk);
     uint64_t *tp = a.tp;
@@ -1607,9 +1654,9 @@ __global__ __launch_bounds__(64) void twopass_scan_kernel(const KernelArgs a) {
     uint64_t *agg = a.tp, *pre = a.tp + ntiles;
     const uint32_t lane64 = lane * 64u;
     const uint32_t lane_off[4] = {lane64, lane64 + 16u, lane64 + 32u, lane64 + 48u};
-    const uint32_t carry0 = uniform32((a.carry_in->next_is_escaped & 1u) | ((a.carry_in->prev_scalar & 1u) << 1));
+    const uint32_t carry0 = uniform32(cin_carry0(a));
     const uint64_t below = (1ull << lane) - 1ull;
-    uint32_t cs = uniform32(a.carry_in->in_string & 1u), cc = 0, ce = 0, cu = 0;
+    uint32_t cs = uniform32(cin_in_string(a)), cc = 0, ce = 0, cu = 0;
     uint32_t e_prev = carry0 & 1u, ps_prev = (carry0 >> 1) & 1u;  // carries out of the tile before
     for (uint32_t base = 0; base < ntiles; base += 64u) {  // uniform
         const uint32_t t = base + lane;
@@ -1670,8 +1717,8 @@ __global__ __launch_bounds__(kThreads) void twopass_emit_kernel(const KernelArgs
     if (tile >= a.ntiles) return;
     const uint32_t lane64 = lane * 64u;
     const uint32_t lane_off[4] = {lane64, lane64 + 16u, lane64 + 32u, lane64 + 48u};
-    const uint32_t carry0 = uniform32((a.carry_in->next_is_escaped & 1u) | ((a.carry_in->prev_scalar & 1u) << 1));
-    const uint64_t count0 = uniform64(a.carry_in->count);
+    const uint32_t carry0 = uniform32(cin_carry0(a));
+    const uint64_t count0 = uniform64(cin_count(a));
     Block blk;
     load_block<false>(a, tile, lane_off, lane, blk);
     const uint64_t pw = uniform64(a.tp[a.ntiles + tile]);  // state and count in front of the tile (scan pass)

@@ -2,7 +2,7 @@
 # Short form of valu_probe.sh: the three BASELINE workloads only (MSJ_LIB=path selects the build: passed to bench.py as --lib).
 cd "$(dirname "$0")/.."
 TAG=${1:-quick}
-OUT=gpurun_out/valu_probe/$TAG; rm -rf $OUT; mkdir -p $OUT
+OUT=/tmp/valu_probe/$TAG; rm -rf $OUT; mkdir -p $OUT  # raw counter files stay on the box (gpurun_out/ is limited to 64 MiB): the summary lines go to stdout
 export TMPDIR=/tmp
 run() {
   name=$1; shift

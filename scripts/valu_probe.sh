@@ -4,7 +4,7 @@
 # One rocprofv3 --pmc pass per configuration; prints per-tile means and the kernel's average duration.
 cd "$(dirname "$0")/.."
 TAG=${1:-probe}
-OUT=gpurun_out/valu_probe/$TAG; rm -rf $OUT; mkdir -p $OUT
+OUT=/tmp/valu_probe/$TAG; rm -rf $OUT; mkdir -p $OUT  # raw counter files stay on the box (gpurun_out/ is limited to 64 MiB): the summary lines go to stdout
 export TMPDIR=/tmp
 run() {
   name=$1; shift

@@ -54,6 +54,10 @@ hipError_t hipDeviceGetStreamPriorityRange(int *, int *) { std::abort(); }
 hipError_t hipStreamCreateWithPriority(hipStream_t *, unsigned int, int) { std::abort(); }
 hipError_t hipStreamDestroy(hipStream_t) { std::abort(); }
 int32_t msj_ctx_device(const msj_ctx *) { std::abort(); }
+int32_t msj_stage1_shard_device_cv(msj_ctx *, const uint8_t *, uint64_t, uint32_t *, uint64_t, uint32_t, msj_carry *, msj_segment *,
+                                   uint32_t, uint32_t *, int32_t, int32_t, int32_t, uint64_t, void *, uint32_t) {
+    std::abort();
+}
 int32_t msj_stage1_shard_device(msj_ctx *, const uint8_t *, uint64_t, uint32_t *, uint64_t, const msj_carry *, msj_carry *,
                                 msj_segment *, uint32_t, uint32_t *, int32_t, int32_t, int32_t, uint64_t, void *, uint32_t) {
     std::abort();
