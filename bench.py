@@ -310,6 +310,8 @@ def main():
                          "steps, so that the timed window sees the clocks the GPU holds under load instead of the "
                          "transient after idle (DESIGN.md section 4); 0 = none.  The K steps right after the warm-up "
                          "are timed too and reported as 'unsettled'")
+    ap.add_argument("--no-ceilings", action="store_true",
+                    help="skip the trivial HBM-ceiling kernels behind the verification (profiling passes: 6 000 launches less)")
     ap.add_argument("--no-emit", action="store_true",
                     help="diagnostic: summary pass only, no index writes (never a reported number)")
     args = ap.parse_args()
@@ -600,7 +602,7 @@ def main():
 
     # ---- the box's own ceilings for this launch's bytes (N = 1; the index array is verified: its buffer is scratch now)
     ceil_box = None
-    if world == 1 and rank == 0 and not args.no_emit:
+    if world == 1 and rank == 0 and not args.no_emit and not args.no_ceilings:
         try:
             ceil_box = same_box_ceilings(torch, device, d_shard, min(shard_len, 0xFFFF0000) // 4096 * 4096,
                                          int(total_count * (min(shard_len, 0xFFFF0000) / shard_len)), d_idx)

@@ -425,6 +425,17 @@ typedef struct msj_tokens_result {
 int32_t msj_tokens_device(msj_ctx *ctx, const uint8_t *d_buf, uint64_t len, const uint32_t *d_idx, uint64_t n,
                           uint8_t *d_type, int32_t *d_depth, uint32_t *d_match, msj_tokens_result *d_result,
                           void *stream);
+/* The same for tokens that are NOT the start of their stream -- the next uint32 segment of a shard (msj_segment: a
+ * 64 GiB stream is 8 GiB per GPU, two segments), the next window of a document stream: d_prev (device, or NULL =
+ * msj_tokens_device) is the msj_tokens_result of the call that covered the tokens in front.  The running depth
+ * walk_document keeps (generic/stage2/json_iterator.mojo:84-90,173-180) goes on from d_prev->final_depth -- that
+ * int32 is the whole carry -- and d_result's final / min / max are those of the stream so far (n: this call's).
+ * Read on the device, in stream order: calls chain without a host round trip.  d_match stays LOCAL to the call: a
+ * container that closes in a later call keeps 0xFFFFFFFF at both ends (its opening bracket is found again from the
+ * depths: the first later token at its depth). */
+int32_t msj_tokens_chain_device(msj_ctx *ctx, const uint8_t *d_buf, uint64_t len, const uint32_t *d_idx, uint64_t n,
+                                uint8_t *d_type, int32_t *d_depth, uint32_t *d_match, msj_tokens_result *d_result,
+                                const msj_tokens_result *d_prev, void *stream);
 
 /*
  * msj_token_spans_device -- per structural (DERIVED like the token
@@ -448,13 +459,13 @@ int32_t msj_tokens_device(msj_ctx *ctx, const uint8_t *d_buf, uint64_t len, cons
 int32_t msj_token_spans_device(msj_ctx *ctx, const uint8_t *d_buf, uint64_t len, const uint32_t *d_idx, uint64_t n,
                                uint32_t *d_end, uint8_t *d_flags, void *stream);
 
-/* Test hook (process-wide): stretches of more than lds_limit_bytes take the span kernels' global-memory path, the
- * fix-up list holds fix_capacity entries; 0xFFFFFFFF = the built-in value of either. */
-void msj_debug_set_span_limits(uint32_t lds_limit_bytes, uint32_t fix_capacity);
-/* Test hook (process-wide): which of their two kernels the token calls run -- 0 (default) by the density of the index
+/* Test hook (per context, like msj_debug_set_segment_bytes): stretches of more than lds_limit_bytes take the span
+ * kernels' global-memory path, the fix-up list holds fix_capacity entries; 0xFFFFFFFF = the built-in value of either. */
+int32_t msj_debug_set_span_limits(msj_ctx *ctx, uint32_t lds_limit_bytes, uint32_t fix_capacity);
+/* Test hook (per context): which of their two kernels the token calls run -- 0 (default) by the density of the index
  * (the kernel organised by tiles of the buffer from one structural per 11 bytes on, the one organised by tokens below
  * that), 1 = by tokens, 2 = by tiles whatever the density.  Identical results; the tests run both. */
-void msj_debug_set_span_mode(uint32_t mode);
+int32_t msj_debug_set_span_mode(msj_ctx *ctx, uint32_t mode);
 /* Test hook: bytes of the buffer per workgroup of the kernel organised by tiles (which = 0) and of its halo (which = 1):
  * what the tests move their tokens across. */
 uint32_t msj_debug_tile_group(int32_t which);
@@ -468,6 +479,28 @@ uint32_t msj_debug_tile_group(int32_t which);
 int32_t msj_stage2_prep_device(msj_ctx *ctx, const uint8_t *d_buf, uint64_t len, const uint32_t *d_idx, uint64_t n,
                                uint8_t *d_type, int32_t *d_depth, uint32_t *d_match, uint32_t *d_end, uint8_t *d_flags,
                                msj_tokens_result *d_result, void *stream);
+/* ... continuing a stream (d_prev as in msj_tokens_chain_device). */
+int32_t msj_stage2_prep_chain_device(msj_ctx *ctx, const uint8_t *d_buf, uint64_t len, const uint32_t *d_idx, uint64_t n,
+                                     uint8_t *d_type, int32_t *d_depth, uint32_t *d_match, uint32_t *d_end, uint8_t *d_flags,
+                                     msj_tokens_result *d_result, const msj_tokens_result *d_prev, void *stream);
+/*
+ * msj_stage2_prep_segments -- rows f1 + f2 + f4 for a whole SHARD of several uint32 segments (what
+ * msj_stage1_shard_device leaves behind for more than MSJ_MAX_SEGMENT_BYTES: BASELINE config 5's 8 GiB per GPU), in
+ * one call: one msj_stage2_prep_chain_device per segment, the depth handed from segment to segment on the device.
+ *   segments: HOST copy of the shard's msj_segment table (n_segments entries; their counts size the launches)
+ *   d_buf: the shard's first byte; d_idx and all output arrays: the shard's token arrays, segment s at
+ *          [index_begin_s - index_begin_0, + count_s); every segment's slice must keep the alignment the single
+ *          calls ask for (index counts are not multiples of 4: pass d_* arrays with slack and use `token_stride`)
+ *   d_results: n_segments msj_tokens_result (device); the last one describes the shard
+ *   d_prev: the result in front of the shard, or NULL
+ * Outputs of segment s start at element offsets[s] = the sum of the counts in front of it, each rounded up to a multiple of 8
+ * elements (so that every slice keeps the single calls' alignment); offsets_out (host, n_segments entries, may be NULL) receives them.
+ * d_end is relative to the SEGMENT's bytes (like the indices), d_match to the segment's tokens.
+ */
+int32_t msj_stage2_prep_segments(msj_ctx *ctx, const uint8_t *d_buf, const msj_segment *segments, uint32_t n_segments,
+                                 const uint32_t *d_idx, uint8_t *d_type, int32_t *d_depth, uint32_t *d_match, uint32_t *d_end,
+                                 uint8_t *d_flags, msj_tokens_result *d_results, const msj_tokens_result *d_prev,
+                                 uint64_t *offsets_out, void *stream);
 
 /*
  * ---- multi-document mode (DERIVED) -----------------------------

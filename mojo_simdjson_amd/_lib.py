@@ -129,6 +129,13 @@ def load():
                                            ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
     lib.msj_stage2_prep_device.restype = ctypes.c_int32
     lib.msj_stage2_prep_device.argtypes = [ctypes.c_void_p, u8p, ctypes.c_uint64, u32p, ctypes.c_uint64] + [ctypes.c_void_p] * 7
+    lib.msj_tokens_chain_device.restype = ctypes.c_int32
+    lib.msj_tokens_chain_device.argtypes = lib.msj_tokens_device.argtypes[:-1] + [ctypes.c_void_p, ctypes.c_void_p]
+    lib.msj_stage2_prep_chain_device.restype = ctypes.c_int32
+    lib.msj_stage2_prep_chain_device.argtypes = lib.msj_stage2_prep_device.argtypes[:-1] + [ctypes.c_void_p, ctypes.c_void_p]
+    lib.msj_stage2_prep_segments.restype = ctypes.c_int32
+    lib.msj_stage2_prep_segments.argtypes = [ctypes.c_void_p, u8p, ctypes.c_void_p, ctypes.c_uint32, u32p] + [ctypes.c_void_p] * 7 + \
+        [ctypes.POINTER(ctypes.c_uint64), ctypes.c_void_p]
     lib.msj_documents_device.restype = ctypes.c_int32
     lib.msj_documents_device.argtypes = [ctypes.c_void_p, u8p, ctypes.c_uint64, ctypes.c_int32, u32p, ctypes.c_uint64,
                                          ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
@@ -145,10 +152,10 @@ def load():
     lib.msj_debug_set_pipeline_min_bytes.argtypes = [ctypes.c_void_p, ctypes.c_uint64]
     lib.msj_debug_fail_pipeline_setup.restype = ctypes.c_int32
     lib.msj_debug_fail_pipeline_setup.argtypes = [ctypes.c_void_p, ctypes.c_int32]
-    lib.msj_debug_set_span_limits.restype = None
-    lib.msj_debug_set_span_limits.argtypes = [ctypes.c_uint32, ctypes.c_uint32]
-    lib.msj_debug_set_span_mode.restype = None
-    lib.msj_debug_set_span_mode.argtypes = [ctypes.c_uint32]
+    lib.msj_debug_set_span_limits.restype = ctypes.c_int32
+    lib.msj_debug_set_span_limits.argtypes = [ctypes.c_void_p, ctypes.c_uint32, ctypes.c_uint32]
+    lib.msj_debug_set_span_mode.restype = ctypes.c_int32
+    lib.msj_debug_set_span_mode.argtypes = [ctypes.c_void_p, ctypes.c_uint32]
     lib.msj_debug_tile_group.restype = ctypes.c_uint32
     lib.msj_debug_tile_group.argtypes = [ctypes.c_int32]
     lib.msj_fallback_count.restype = ctypes.c_uint64

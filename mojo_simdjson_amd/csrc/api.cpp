@@ -22,6 +22,7 @@
 
 #include "../../include/msj_stage1.h"
 #include "stage1_kernel.h"
+#include "tokens_launch.h"
 
 // small-input path of msj_stage1: input, result and len + 3 indices fit the pinned staging buffer, which the kernel
 // reads and writes itself over PCIe (no DMA calls; measured against staged copies: 77 B 24 -> 22 us, 13 KB 33 -> 23,
@@ -86,6 +87,9 @@ struct msj_ctx {
     int32_t *tok_ws = nullptr;    // block aggregates of the token pre-pass
     uint64_t tok_ws_bytes = 0;
     uint64_t tok_doc_n = ~0ull;   // the token count whose document aggregates tok_ws holds (~0: none)
+    uint32_t *seg_idx = nullptr;  // msj_stage2_prep_segments: 16-byte aligned copy of a segment's index slice that is not
+    uint64_t seg_idx_words = 0;
+    msj_token_opts tok_opts;      // test hooks of the token calls (msj_debug_set_span_limits / _span_mode): per context
     void *doc_ws = nullptr;       // block counts of the document split
     uint64_t doc_ws_bytes = 0;
 };
@@ -607,6 +611,7 @@ void msj_ctx_destroy(msj_ctx *ctx) {
     if (ctx->ws) (void)hipFree(ctx->ws);
     if (ctx->tp) (void)hipFree(ctx->tp);
     if (ctx->tok_ws) (void)hipFree(ctx->tok_ws);
+    if (ctx->seg_idx) (void)hipFree(ctx->seg_idx);
     if (ctx->span_fix) (void)hipFree(ctx->span_fix);
     if (ctx->doc_ws) (void)hipFree(ctx->doc_ws);
     if (ctx->carries) (void)hipFree(ctx->carries);
@@ -654,11 +659,6 @@ int32_t msj_stage1_shard_device_cv(msj_ctx *ctx, const uint8_t *d_buf, uint64_t 
                          static_cast<hipStream_t>(stream), flags, 0, &carry_bits);
 }
 
-extern "C" uint64_t msj_tokens_workspace_bytes(uint64_t n, int with_match);
-
-extern "C" int msj_launch_tokens(const uint8_t *d_buf, uint64_t len, const uint32_t *d_idx, uint64_t n, uint8_t *d_type,
-                                        int32_t *d_depth, uint32_t *d_match, msj_tokens_result *d_result, int32_t *d_ws, void *stream);
-extern "C" uint64_t msj_stage2_prep_workspace_bytes(uint64_t n, uint64_t len, int with_match);
 
 // the workspace of the token calls (block aggregates, chunk aggregates, group table): grown when a call needs more
 static bool ensure_tok_ws(msj_ctx *ctx, uint64_t need) {
@@ -677,7 +677,13 @@ static bool ensure_tok_ws(msj_ctx *ctx, uint64_t need) {
 int32_t msj_tokens_device(msj_ctx *ctx, const uint8_t *d_buf, uint64_t len, const uint32_t *d_idx, uint64_t n,
                           uint8_t *d_type, int32_t *d_depth, uint32_t *d_match, msj_tokens_result *d_result,
                           void *stream) {
-    if (!ctx || !d_result) return MSJ_ERR_BAD_ARGUMENT;
+    return msj_tokens_chain_device(ctx, d_buf, len, d_idx, n, d_type, d_depth, d_match, d_result, nullptr, stream);
+}
+
+int32_t msj_tokens_chain_device(msj_ctx *ctx, const uint8_t *d_buf, uint64_t len, const uint32_t *d_idx, uint64_t n,
+                                uint8_t *d_type, int32_t *d_depth, uint32_t *d_match, msj_tokens_result *d_result,
+                                const msj_tokens_result *d_prev, void *stream) {
+    if (!ctx || !d_result || d_prev == d_result) return MSJ_ERR_BAD_ARGUMENT;
     if (n > 0 && (!d_buf || !d_idx || !d_type || !d_depth)) return MSJ_ERR_BAD_ARGUMENT;
     if (len > MSJ_MAX_SEGMENT_BYTES || n >= (1ull << 31)) return MSJ_CAPACITY;
     if ((reinterpret_cast<uintptr_t>(d_idx) & 15u) || (reinterpret_cast<uintptr_t>(d_depth) & 15u) ||
@@ -687,14 +693,13 @@ int32_t msj_tokens_device(msj_ctx *ctx, const uint8_t *d_buf, uint64_t len, cons
     const uint64_t need = msj_stage2_prep_workspace_bytes(n, len, d_match != nullptr);  // incl. the fused kernel's chunk aggregates and table
     if (!ensure_tok_ws(ctx, need)) return MSJ_MEMALLOC;
     ctx->tok_doc_n = ~0ull;
-    if (msj_launch_tokens(d_buf, len, d_idx, n, d_type, d_depth, d_match, d_result, ctx->tok_ws, stream) != 0) return MSJ_ERR_HIP;
+    msj_token_opts o = ctx->tok_opts;
+    o.d_prev = d_prev;
+    if (msj_launch_tokens(d_buf, len, d_idx, n, d_type, d_depth, d_match, d_result, ctx->tok_ws, stream, o) != 0) return MSJ_ERR_HIP;
     ctx->tok_doc_n = n;
     return MSJ_SUCCESS;
 }
 
-extern "C" int msj_launch_token_spans(const uint8_t *d_buf, uint64_t len, const uint32_t *d_idx, uint64_t n, uint32_t *d_end,
-                                      uint8_t *d_flags, int32_t *d_ws, uint32_t *d_fix, void *stream);
-extern "C" uint64_t msj_span_fix_bytes(void);
 
 static bool ensure_span_fix(msj_ctx *ctx) {
     if (ctx->span_fix) return true;
@@ -716,17 +721,21 @@ int32_t msj_token_spans_device(msj_ctx *ctx, const uint8_t *d_buf, uint64_t len,
     if (!ensure_span_fix(ctx)) return MSJ_MEMALLOC;
     if (!ensure_tok_ws(ctx, msj_stage2_prep_workspace_bytes(n, len, 0))) return MSJ_MEMALLOC;  // the group table lives there
     ctx->tok_doc_n = ~0ull;
-    return msj_launch_token_spans(d_buf, len, d_idx, n, d_end, d_flags, ctx->tok_ws, ctx->span_fix, stream) == 0 ? MSJ_SUCCESS : MSJ_ERR_HIP;
+    return msj_launch_token_spans(d_buf, len, d_idx, n, d_end, d_flags, ctx->tok_ws, ctx->span_fix, stream, ctx->tok_opts) == 0 ? MSJ_SUCCESS
+                                                                                                                              : MSJ_ERR_HIP;
 }
 
-extern "C" int msj_launch_stage2_prep(const uint8_t *d_buf, uint64_t len, const uint32_t *d_idx, uint64_t n, uint8_t *d_type,
-                                      int32_t *d_depth, uint32_t *d_match, uint32_t *d_end, uint8_t *d_flags,
-                                      msj_tokens_result *d_result, int32_t *d_ws, uint32_t *d_fix, void *stream);
 
 int32_t msj_stage2_prep_device(msj_ctx *ctx, const uint8_t *d_buf, uint64_t len, const uint32_t *d_idx, uint64_t n,
                                uint8_t *d_type, int32_t *d_depth, uint32_t *d_match, uint32_t *d_end, uint8_t *d_flags,
                                msj_tokens_result *d_result, void *stream) {
-    if (!ctx || !d_result) return MSJ_ERR_BAD_ARGUMENT;
+    return msj_stage2_prep_chain_device(ctx, d_buf, len, d_idx, n, d_type, d_depth, d_match, d_end, d_flags, d_result, nullptr, stream);
+}
+
+int32_t msj_stage2_prep_chain_device(msj_ctx *ctx, const uint8_t *d_buf, uint64_t len, const uint32_t *d_idx, uint64_t n,
+                                     uint8_t *d_type, int32_t *d_depth, uint32_t *d_match, uint32_t *d_end, uint8_t *d_flags,
+                                     msj_tokens_result *d_result, const msj_tokens_result *d_prev, void *stream) {
+    if (!ctx || !d_result || d_prev == d_result) return MSJ_ERR_BAD_ARGUMENT;
     if (n > 0 && (!d_buf || !d_idx || !d_type || !d_depth || !d_end || !d_flags)) return MSJ_ERR_BAD_ARGUMENT;
     if (len > MSJ_MAX_SEGMENT_BYTES || n >= (1ull << 31)) return MSJ_CAPACITY;
     if ((reinterpret_cast<uintptr_t>(d_idx) & 15u) || (reinterpret_cast<uintptr_t>(d_depth) & 15u) ||
@@ -737,9 +746,54 @@ int32_t msj_stage2_prep_device(msj_ctx *ctx, const uint8_t *d_buf, uint64_t len,
     if (!ensure_tok_ws(ctx, need)) return MSJ_MEMALLOC;
     ctx->tok_doc_n = ~0ull;
     if (!ensure_span_fix(ctx)) return MSJ_MEMALLOC;
-    if (msj_launch_stage2_prep(d_buf, len, d_idx, n, d_type, d_depth, d_match, d_end, d_flags, d_result, ctx->tok_ws, ctx->span_fix, stream) != 0)
+    msj_token_opts o = ctx->tok_opts;
+    o.d_prev = d_prev;
+    if (msj_launch_stage2_prep(d_buf, len, d_idx, n, d_type, d_depth, d_match, d_end, d_flags, d_result, ctx->tok_ws, ctx->span_fix, stream, o) != 0)
         return MSJ_ERR_HIP;
     ctx->tok_doc_n = n;
+    return MSJ_SUCCESS;
+}
+
+int32_t msj_stage2_prep_segments(msj_ctx *ctx, const uint8_t *d_buf, const msj_segment *segments, uint32_t n_segments,
+                                 const uint32_t *d_idx, uint8_t *d_type, int32_t *d_depth, uint32_t *d_match, uint32_t *d_end,
+                                 uint8_t *d_flags, msj_tokens_result *d_results, const msj_tokens_result *d_prev,
+                                 uint64_t *offsets_out, void *stream) {
+    if (!ctx || !segments || n_segments == 0 || !d_results || !d_buf) return MSJ_ERR_BAD_ARGUMENT;
+    if (!hip_ok(hipSetDevice(ctx->device))) return MSJ_ERR_HIP;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const uint64_t begin0 = segments[0].index_begin, base0 = segments[0].byte_base;
+    uint64_t off = 0;
+    for (uint32_t s = 0; s < n_segments; s++) {
+        const msj_segment &sg = segments[s];
+        if (sg.index_begin < begin0 || sg.byte_base < base0) return MSJ_ERR_BAD_ARGUMENT;
+        const uint64_t n = sg.count;
+        const uint32_t *idx = d_idx + (sg.index_begin - begin0);
+        if (n && (reinterpret_cast<uintptr_t>(idx) & 15u)) {
+            // stage 1 writes a shard's indices densely, so a later segment's slice starts wherever the one in front
+            // ended: the token kernels read index quads, so it is copied to an aligned buffer first (4 bytes per token
+            // each way, on the stream; the first segment of a shard never needs it)
+            if (n > ctx->seg_idx_words) {
+                if (ctx->seg_idx) {
+                    (void)hipDeviceSynchronize();
+                    (void)hipFree(ctx->seg_idx);
+                }
+                ctx->seg_idx = nullptr;
+                ctx->seg_idx_words = 0;
+                if (!hip_ok(hipMalloc(reinterpret_cast<void **>(&ctx->seg_idx), (n + 4) * sizeof(uint32_t)))) return MSJ_MEMALLOC;
+                ctx->seg_idx_words = n + 4;
+            }
+            if (!hip_ok(hipMemcpyAsync(ctx->seg_idx, idx, n * sizeof(uint32_t), hipMemcpyDeviceToDevice, st))) return MSJ_ERR_HIP;
+            idx = ctx->seg_idx;
+        }
+        if (offsets_out) offsets_out[s] = off;
+        const int32_t rc = msj_stage2_prep_chain_device(ctx, d_buf + (sg.byte_base - base0), sg.byte_len, idx, n, d_type ? d_type + off : nullptr,
+                                                        d_depth ? d_depth + off : nullptr, d_match ? d_match + off : nullptr,
+                                                        d_end ? d_end + off : nullptr, d_flags ? d_flags + off : nullptr, &d_results[s],
+                                                        s == 0 ? d_prev : &d_results[s - 1], stream);
+        if (rc != MSJ_SUCCESS) return rc;
+        off += (n + 3u) & ~3ull;  // every segment's slices start 16-byte aligned (8 for the byte arrays: n rounded to 4 ... 8 below)
+        off = (off + 7u) & ~7ull;
+    }
     return MSJ_SUCCESS;
 }
 
@@ -747,7 +801,6 @@ extern "C" uint64_t msj_documents_workspace_bytes(uint64_t n);
 extern "C" int msj_launch_documents(const uint8_t *d_buf, uint64_t len, int is_final, const uint32_t *d_idx, uint64_t n,
                                     const uint8_t *d_type, const int32_t *d_depth, const msj_carry *d_carry, uint32_t *d_doc_first, uint64_t capacity,
                                     msj_documents_result *d_result, void *d_ws, const void *d_block_agg, void *stream);
-extern "C" void *msj_tokens_doc_aggregates(int32_t *d_ws, uint64_t n);
 
 int32_t msj_documents_device(msj_ctx *ctx, const uint8_t *d_buf, uint64_t len, int32_t is_final, const uint32_t *d_idx,
                              uint64_t n, const uint8_t *d_type, const int32_t *d_depth, const msj_carry *d_carry,
@@ -906,6 +959,18 @@ int32_t msj_debug_fail_pipeline_setup(msj_ctx *ctx, int32_t on) {
     ctx->pipe_fail_setup = on != 0;
     if (!on) ctx->pipe_unavailable = false;
     return ctx->pipe_unavailable ? 1 : 0;
+}
+
+int32_t msj_debug_set_span_limits(msj_ctx *ctx, uint32_t lds_limit_bytes, uint32_t fix_capacity) {
+    if (!ctx) return MSJ_ERR_BAD_ARGUMENT;
+    ctx->tok_opts.lds_limit = lds_limit_bytes;
+    ctx->tok_opts.fix_cap = fix_capacity;
+    return MSJ_SUCCESS;
+}
+int32_t msj_debug_set_span_mode(msj_ctx *ctx, uint32_t mode) {
+    if (!ctx || mode > 2u) return MSJ_ERR_BAD_ARGUMENT;
+    ctx->tok_opts.span_mode = mode;
+    return MSJ_SUCCESS;
 }
 
 int32_t msj_debug_set_segment_bytes(msj_ctx *ctx, uint64_t bytes) {

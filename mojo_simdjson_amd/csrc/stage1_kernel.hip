@@ -1096,6 +1096,11 @@ __device__ __forceinline__ void worker_wave(const KernelArgs &a, Shared &sh, con
         asm volatile("" : "+s"(wave_p));
         KernelArgs al = a;
         asm volatile("" : "+s"(al.flags));
+        // (Round 4, measured: reading the arguments the emission and the rare paths use -- idx, capacity, ws_clean,
+        // wait_ticks, index_bias -- again from the kernel-argument segment at the top of every iteration, so that they
+        // need not live in scalar registers across it, RAISED the spilled registers from 44 to 52: the pressure peaks
+        // inside the iteration, in the two tiles' wave-level masks, not across its back edge.  The ~31 reload sites in
+        // the loop are <= 1.5 % of its vector instructions.)
         const uint32_t tid_p = wave_p * 64u + lane_p;
         uint32_t carry0_p = carry0, shard_p = shard;  // the same for values the loop only takes bits or addresses from
         asm volatile("" : "+s"(carry0_p), "+s"(shard_p));
@@ -1204,16 +1209,16 @@ __device__ __forceinline__ void worker_wave(const KernelArgs &a, Shared &sh, con
                                                     (uint64_t)(tot & 0xFFFFu));
             }
         }
-        if (a.ws_clean && wave_p == kWaves - 1) {  // uniform
+        if (al.ws_clean && wave_p == kWaves - 1) {  // uniform
             // double-buffered workspace: zero, in the buffer the NEXT launch will use, exactly
             // the words this range dirtied in the previous launch (same ntiles, same layout)
             const uint32_t rid = lo_cur / kRange;
             if (lane_p < kRange) {
-                if (lo_cur + lane < ntiles) a.ws_clean[kDescOffset + lo_cur + lane] = 0ull;
+                if (lo_cur + lane < ntiles) al.ws_clean[kDescOffset + lo_cur + lane] = 0ull;
             } else if (lane_p == kRange) {
-                a.ws_clean[kDescOffset + ntiles + rid] = 0ull;
+                al.ws_clean[kDescOffset + ntiles + rid] = 0ull;
             } else if (lane_p == kRange + 1u) {
-                a.ws_clean[kDescOffset + ntiles + nranges + rid] = 0ull;
+                al.ws_clean[kDescOffset + ntiles + nranges + rid] = 0ull;
             }
         }
         MSJ_STAMP(srow, 10);  // folded, range aggregate published
@@ -1225,7 +1230,7 @@ __device__ __forceinline__ void worker_wave(const KernelArgs &a, Shared &sh, con
             while ((uint32_t)(h >> 32) != r + 1u) {
                 __builtin_amdgcn_s_sleep(1);
                 h = uniform64(__hip_atomic_load(&sh.handoff, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
-                if (clk.expired(a.wait_ticks)) {
+                if (clk.expired(al.wait_ticks)) {
                     // wave 0 never came back with the ticket: give up (this wave drains and leaves;
                     // a wave that has ended does not hold up the others' barrier)
                     timeout = 1;
@@ -1238,7 +1243,7 @@ __device__ __forceinline__ void worker_wave(const KernelArgs &a, Shared &sh, con
         MSJ_RSTAMP(lo_cur, 8, tid == 0);  // range aggregate published (real time)
         // ---- 3. emit the range parked kDefer iterations ago; hand the next range over in between
         if (have_old) {
-            rp_word = range_prefix(a, rpre, old_range, uniform64(rp_word), timeout);
+            rp_word = range_prefix(al, rpre, old_range, uniform64(rp_word), timeout);
             MSJ_RSTAMP(old_range * kRange, 9, tid == 0);  // its prefix is in hand (real time)
         }
         // wave-uniform by construction; say so, or the whole emission is vector code with exec masks
@@ -1252,7 +1257,7 @@ __device__ __forceinline__ void worker_wave(const KernelArgs &a, Shared &sh, con
         emit_stage(sh, e0, wave, slot0, stage, lane, lane64);
         lds_wave_sync();
         MSJ_STAMP(srow, 13);  // tile A staged
-        emit_store(a, sh, e0, wave, slot0, stage, lane, lane_p);
+        emit_store(al, sh, e0, wave, slot0, stage, lane, lane_p);
         lds_wave_sync();  // the staging slice is reused by the next tile
         MSJ_STAMP(srow, 14);  // tile A stored
         EmitU e1 = emit_prepare(al, sh, wave, slot0 + 1u, rp, count0, timeout);
@@ -1264,7 +1269,7 @@ __device__ __forceinline__ void worker_wave(const KernelArgs &a, Shared &sh, con
 #pragma unroll
         for (uint32_t j = 0; j < kBatch; j++) touch_block(blk[j]);
         MSJ_STAMP(srow, 11);  // the next range's bytes have arrived
-        emit_store(a, sh, e1, wave, slot0 + 1u, stage, lane, lane_p);
+        emit_store(al, sh, e1, wave, slot0 + 1u, stage, lane, lane_p);
         lds_wave_sync();
         __builtin_amdgcn_s_setprio(MSJ_PRIO_COMPUTE);
         // ---- 4. park this iteration's tiles

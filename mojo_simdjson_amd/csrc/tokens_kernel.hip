@@ -25,6 +25,7 @@
 #include "../../include/msj_stage1.h"
 #include "lane_math.h"
 #include "token_math.h"
+#include "tokens_launch.h"
 
 #ifndef MSJ_SPAN_ABLATE
 #define MSJ_SPAN_ABLATE 0  // diagnostic builds: 1 no token evaluation, 2 no depth aggregates, 3 no bit-plane transpose (wrong results)
@@ -184,7 +185,8 @@ __global__ __launch_bounds__(256) void scan_super(const int32_t *__restrict__ bl
 //     thread folds kScanPer consecutive block aggregates serially (so a pass covers 8 192 blocks).
 constexpr int kScanPer = 8;
 __global__ __launch_bounds__(1024) void scan_blocks(const int32_t *__restrict__ block_agg, uint32_t nblocks, int32_t *__restrict__ block_start,
-                                                    uint32_t *__restrict__ open_start, msj_tokens_result *__restrict__ result, uint64_t n) {
+                                                    uint32_t *__restrict__ open_start, msj_tokens_result *__restrict__ result, uint64_t n,
+                                                    const msj_tokens_result *__restrict__ prev, uint32_t *__restrict__ survivors) {
     __shared__ Agg wave_agg[16];
     __shared__ uint32_t wave_opens[16];
     __shared__ Agg carry;
@@ -257,22 +259,59 @@ __global__ __launch_bounds__(1024) void scan_blocks(const int32_t *__restrict__ 
         __syncthreads();
     }
     if (threadIdx.x == 0) {
+        // the tokens in front of this call (msj_token_opts.d_prev): the running depth goes on from where they left it,
+        // minimum and maximum are those of the stream so far
+        const int32_t base = prev ? prev->final_depth : 0;
+        const bool prev_has = prev && prev->n > 0;
+        int32_t mn = (n && carry.mn != kNone) ? base + carry.mn : kNone;
+        int32_t mx = (n && carry.mx != -kNone) ? base + carry.mx : -kNone;
+        if (prev_has) {
+            mn = min(mn, prev->min_depth);
+            mx = max(mx, prev->max_depth);
+        }
+        // (kNone / -kNone left in place when the kernel in front only counted brackets: min_max_depth folds the exact
+        // values in; an empty call at the start of a stream reports 0 / 0)
+        const bool none = n == 0 && !prev_has;
         result->n = n;
-        result->final_depth = carry.sum;
-        result->min_depth = n ? carry.mn : 0;
-        result->max_depth = n ? carry.mx : 0;
-        result->reserved = carry_opens;  // number of opening brackets (the matching pass runs over exactly these)
+        result->final_depth = base + carry.sum;
+        result->min_depth = none ? 0 : mn;
+        result->max_depth = none ? 0 : mx;
+        result->reserved = carry_opens;  // number of opening brackets
+        if (survivors) *survivors = 0u;  // apply_depth<true> appends the brackets it could not pair inside their block
     }
 }
 
-// (3) depth of every token
+// (3) depth of every token -- and, kMatch, the partner of every bracket whose container closes inside the block:
+// the stack of start_container / end_container (generic/stage2/tape_builder.mojo:235-272) as a data-parallel step.
+// The partner of a closing bracket at depth d is the MOST RECENT opening bracket at depth d in front of it (brackets
+// of one depth alternate: between two closing ones the running depth must come back up through an opening one), so
+// per depth level of the block a bitmap of its opening brackets (LDS, one bit per token, kMatchLevels levels from 4
+// below the depth at the block's start) and a 64-bit summary of its non-empty words answer every closing bracket
+// with at most three LDS reads and no loop.  Both ends are written into an LDS copy of the block's match[] slice,
+// which leaves as one coalesced stream (no fill of match[] in front, no scattered writes); opening brackets nobody
+// claimed (their container ends in a later block, or lies outside the levels) go on the survivors' list, which
+// match_brackets resolves through the min tree as before.  1 GiB minified: of 8.6 M containers ... survive.
+constexpr int kMatchLevels = 16;
+constexpr int kMatchBelow = 4;
+template <bool kMatch>
 __global__ __launch_bounds__(kThreads) void apply_depth(const uint8_t *__restrict__ type, uint64_t n,
                                                         const int32_t *__restrict__ block_start, const int32_t *__restrict__ super_start,
                                                         const uint32_t *__restrict__ super_open, int32_t *__restrict__ depth,
                                                         int32_t *__restrict__ min8, int32_t *__restrict__ min64,
                                                         int32_t *__restrict__ min512, const uint32_t *__restrict__ open_start,
                                                         uint32_t *__restrict__ opens, uint4 *__restrict__ doc_agg,
-                                                        int32_t *__restrict__ block_mm) {
+                                                        int32_t *__restrict__ block_mm, const msj_tokens_result *__restrict__ prev,
+                                                        uint32_t *__restrict__ match, uint32_t *__restrict__ survivors) {
+    __shared__ uint32_t bm[kMatch ? kMatchLevels : 1][kMatch ? kBlock / 32 : 1];  // opening brackets per level, one bit per token
+    __shared__ uint64_t bm_words[kMatch ? kMatchLevels : 1];                        // ... and which of a level's 64 words are not empty
+    __shared__ __attribute__((aligned(16))) uint32_t s_match[kMatch ? kBlock : 4];
+    if (kMatch) {
+        uint32_t *z = &bm[0][0];
+#pragma unroll
+        for (int k = 0; k < kMatchLevels * (int)(kBlock / 32) / kThreads; k++) z[threadIdx.x + k * kThreads] = 0u;
+        *reinterpret_cast<uint4 *>(&s_match[8 * threadIdx.x]) = make_uint4(~0u, ~0u, ~0u, ~0u);
+        *reinterpret_cast<uint4 *>(&s_match[8 * threadIdx.x + 4]) = make_uint4(~0u, ~0u, ~0u, ~0u);
+    }
     __shared__ int wave_sum[kThreads / 64];
     __shared__ int wave_no[kThreads / 64];
     __shared__ int wave_rmn[kThreads / 64], wave_rmx[kThreads / 64];
@@ -305,15 +344,9 @@ __global__ __launch_bounds__(kThreads) void apply_depth(const uint8_t *__restric
         wave_no[wave] = incl_no;
     }
     __syncthreads();
-    int before = super_start[blockIdx.x / kSuper] + block_start[blockIdx.x] + incl - run;
+    const int block_depth0 = (prev ? prev->final_depth : 0) + super_start[blockIdx.x / kSuper] + block_start[blockIdx.x];  // uniform
+    int before = block_depth0 + incl - run;
     for (int w = 0; w < wave; w++) before += wave_sum[w];
-    if (opens) {  // the token indices of all opening brackets, in order (work list of match_brackets)
-        uint32_t slot = super_open[blockIdx.x / kSuper] + open_start[blockIdx.x] + (uint32_t)(incl_no - no);
-        for (int w = 0; w < wave; w++) slot += (uint32_t)wave_no[w];
-#pragma unroll
-        for (int k = 0; k < kPer; k++)
-            if (d[k] > 0) opens[slot++] = (uint32_t)(base + k);
-    }
     int out[kPer];
     int rmn = kNone, rmx = -kNone;  // minimum / maximum of the running depth AFTER each of this thread's tokens
 #pragma unroll
@@ -323,6 +356,78 @@ __global__ __launch_bounds__(kThreads) void apply_depth(const uint8_t *__restric
         if (base + k < n) {
             rmn = min(rmn, before);
             rmx = max(rmx, before);
+        }
+    }
+    if (kMatch) {
+        const int level0 = block_depth0 - kMatchBelow;
+        const uint32_t t0 = 8u * threadIdx.x;  // this thread's first token inside the block
+        // (a) the opening brackets' bits (the zeroing above is behind the barrier that published wave_sum)
+#pragma unroll
+        for (int k = 0; k < kPer; k++) {
+            const uint32_t lv = (uint32_t)(out[k] - level0);
+            if (d[k] > 0 && lv < (uint32_t)kMatchLevels && base + k < n) atomicOr(&bm[lv][(t0 + k) >> 5], 1u << ((t0 + k) & 31u));
+        }
+        __syncthreads();
+        // (b) per level, the words that hold a bit
+        for (int lv = wave; lv < kMatchLevels; lv += kThreads / 64) {
+            const uint64_t nz = __ballot(bm[lv][lane] != 0u);
+            if (lane == 0) bm_words[lv] = nz;
+        }
+        __syncthreads();
+        // (c) every closing bracket looks for the most recent opening one of its level
+#pragma unroll
+        for (int k = 0; k < kPer; k++) {
+            const uint32_t lv = (uint32_t)(out[k] - level0);
+            if (d[k] < 0 && lv < (uint32_t)kMatchLevels && base + k < n) {
+                const uint32_t t = t0 + k, w = t >> 5;
+                uint32_t m = bm[lv][w] & ((1u << (t & 31u)) - 1u);
+                uint32_t wi = w;
+                if (m == 0u) {
+                    const uint64_t nz = bm_words[lv] & ((1ull << w) - 1ull);
+                    if (nz != 0ull) {
+                        wi = 63u - (uint32_t)__clzll((long long)nz);
+                        m = bm[lv][wi];
+                    }
+                }
+                if (m != 0u) {
+                    const uint32_t i = 32u * wi + 31u - (uint32_t)__clz((int)m);
+                    const uint32_t blk0 = blockIdx.x * kBlock;  // token indices are < 2^31
+                    s_match[t] = blk0 + i;
+                    s_match[i] = blk0 + t;
+                }
+            }
+        }
+        __syncthreads();
+        // (d) the opening brackets nobody claimed: to the list match_brackets works through (any order)
+        uint32_t mine = 0;
+        const uint4 ma = *reinterpret_cast<const uint4 *>(&s_match[t0]);
+        const uint4 mb = *reinterpret_cast<const uint4 *>(&s_match[t0 + 4]);
+        const uint32_t mk[8] = {ma.x, ma.y, ma.z, ma.w, mb.x, mb.y, mb.z, mb.w};
+#pragma unroll
+        for (int k = 0; k < kPer; k++) mine += (d[k] > 0 && mk[k] == ~0u && base + k < n) ? 1u : 0u;
+        const uint64_t any = __ballot(mine != 0u);
+        if (any != 0ull) {  // uniform per wave
+            const uint32_t incl_m = wave_incl_sum(mine);
+            uint32_t slot0 = 0;
+            if (lane == 63) slot0 = atomicAdd(survivors, incl_m);
+            slot0 = (uint32_t)__builtin_amdgcn_readlane((int)slot0, 63) + incl_m - mine;
+#pragma unroll
+            for (int k = 0; k < kPer; k++)
+                if (d[k] > 0 && mk[k] == ~0u && base + k < n) opens[slot0++] = (uint32_t)(base + k);
+        }
+        // (e) the block's slice of match[]: 1 KiB contiguous per store instruction, like the depths below
+        const uint64_t wb = (uint64_t)blockIdx.x * kBlock + (uint64_t)wave * 512u;
+        if (wb + 512u <= n) {  // uniform per wave
+            typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+            const uint4 a = *reinterpret_cast<const uint4 *>(&s_match[wave * 512 + 4 * lane]);
+            const uint4 b = *reinterpret_cast<const uint4 *>(&s_match[wave * 512 + 256 + 4 * lane]);
+            const u32x4 o0 = {a.x, a.y, a.z, a.w}, o1 = {b.x, b.y, b.z, b.w};
+            __builtin_nontemporal_store(o0, reinterpret_cast<u32x4 *>(match + wb + 4 * lane));
+            __builtin_nontemporal_store(o1, reinterpret_cast<u32x4 *>(match + wb + 256 + 4 * lane));
+        } else {
+#pragma unroll
+            for (int k = 0; k < kPer; k++)
+                if (base + k < n) match[base + k] = mk[k];
         }
     }
     // The depths leave through LDS, so that each store instruction of a wave writes 1 KiB contiguous instead of 16 bytes
@@ -496,10 +601,10 @@ __device__ __forceinline__ uint32_t first_le(const int v[8], uint32_t from, int 
 // one thread per OPENING bracket (a dense work list: with one thread per token only a few lanes of
 // a wave would walk the tree, each through a chain of dependent loads)
 __global__ __launch_bounds__(256) void match_brackets(const uint8_t *__restrict__ type, const uint32_t *__restrict__ opens,
-                                                      const msj_tokens_result *__restrict__ result, const MinTree t,
+                                                      const uint32_t *__restrict__ n_opens, const MinTree t,
                                                       uint32_t *__restrict__ match) {
-    const uint64_t w = (uint64_t)blockIdx.x * 256u + threadIdx.x;
-    if (w >= result->reserved) return;
+    const uint32_t total = *n_opens;
+    for (uint64_t w = (uint64_t)blockIdx.x * 256u + threadIdx.x; w < total; w += (uint64_t)gridDim.x * 256u) {
     const uint32_t i = opens[w];
     const int target = t.lv[0][i];
     uint32_t pos = i + 1u;
@@ -520,7 +625,7 @@ __global__ __launch_bounds__(256) void match_brackets(const uint8_t *__restrict_
         pos = g + 1u;  // the rest of this group holds nothing: next node one level up
         lev++;
     }
-    if (!found) return;
+    if (!found) continue;
     while (lev > 0) {  // descend: the first child that qualifies
         lev--;
         load_group(t, lev, pos, v);
@@ -530,6 +635,7 @@ __global__ __launch_bounds__(256) void match_brackets(const uint8_t *__restrict_
     if (cj == '}' || cj == ']') {
         match[i] = pos;
         match[pos] = i;
+    }
     }
 }
 
@@ -564,15 +670,14 @@ static uint64_t head_words(uint64_t n) {  // ... + the same six words per run of
     return block_words(n) + ((6 * super_count(n) + 7u) & ~7ull);
 }
 extern "C" uint64_t msj_tokens_workspace_bytes(uint64_t n, int with_match) {
-    return (head_words(n) + (with_match ? tree_words(n) + 64 + n : 0)) * sizeof(int32_t);
+    // (matching: the min tree, 64 scratch words, the list of opening brackets left to the tree -- one uint32 per token
+    // at most -- and its counter)
+    return (head_words(n) + (with_match ? tree_words(n) + 64 + n + 8 : 0)) * sizeof(int32_t);
 }
 
 // scan of the block aggregates (already in d_ws), depth of every token, bracket partners
 static int launch_depth_passes(const uint32_t *d_idx, uint64_t n, uint8_t *d_type, int32_t *d_depth, uint32_t *d_match,
-                               msj_tokens_result *d_result, int32_t *d_ws, hipStream_t s);
-
-static int launch_depth_passes(const uint32_t *d_idx, uint64_t n, uint8_t *d_type, int32_t *d_depth, uint32_t *d_match,
-                               msj_tokens_result *d_result, int32_t *d_ws, hipStream_t s) {
+                               msj_tokens_result *d_result, int32_t *d_ws, hipStream_t s, const msj_token_opts &o) {
     using namespace msj_tokens;
     (void)d_idx;
     const uint32_t nb = (uint32_t)((n + kBlock - 1) / kBlock);
@@ -583,11 +688,13 @@ static int launch_depth_passes(const uint32_t *d_idx, uint64_t n, uint8_t *d_typ
     int32_t *tree = d_ws + head_words(n);  // 32-byte aligned inside the workspace
     const bool want_match = d_match != nullptr && n > 0;
     uint32_t *opens = want_match ? reinterpret_cast<uint32_t *>(tree + tree_words(n) + 64) : nullptr;
+    uint32_t *survivors = want_match ? opens + n : nullptr;  // how many of them there are (zeroed by scan_blocks)
     const uint32_t nsuper = (uint32_t)super_count(n);
     int32_t *super_agg = d_ws + block_words(n), *super_start = super_agg + 4 * (uint64_t)nsuper;
     uint32_t *super_open = reinterpret_cast<uint32_t *>(super_start + nsuper);
     if (nb) hipLaunchKernelGGL(scan_super, dim3(nsuper), dim3(256), 0, s, agg, nb, start, open_start, super_agg);
-    hipLaunchKernelGGL(scan_blocks, dim3(1), dim3(1024), 0, s, super_agg, nb ? nsuper : 0u, super_start, super_open, d_result, n);
+    hipLaunchKernelGGL(scan_blocks, dim3(1), dim3(1024), 0, s, super_agg, nb ? nsuper : 0u, super_start, super_open, d_result, n, o.d_prev,
+                       survivors);
     // levels of the min tree: 1..3 come out of apply_depth, the rest from build_level
     MinTree t;
     t.lv[0] = d_depth;
@@ -611,14 +718,20 @@ static int launch_depth_passes(const uint32_t *d_idx, uint64_t n, uint8_t *d_typ
     int32_t *l3 = want_match ? (t.nlev > 3 ? lvl[3] : tree + tree_words(n) + 40) : nullptr;
     if (want_match)  // padding entries of the tree levels must never qualify: 0x7F7F7F7F
         (void)hipMemsetAsync(tree, 0x7F, (tree_words(n) + 64) * sizeof(int32_t), s);
-    if (nb) hipLaunchKernelGGL(apply_depth, dim3(nb), dim3(kThreads), 0, s, d_type, n, start, super_start, super_open, d_depth, l1, l2, l3, open_start, opens, doc_agg, agg);
+    if (nb && want_match)
+        hipLaunchKernelGGL(apply_depth<true>, dim3(nb), dim3(kThreads), 0, s, d_type, n, start, super_start, super_open, d_depth, l1, l2, l3,
+                           open_start, opens, doc_agg, agg, o.d_prev, d_match, survivors);
+    else if (nb)
+        hipLaunchKernelGGL(apply_depth<false>, dim3(nb), dim3(kThreads), 0, s, d_type, n, start, super_start, super_open, d_depth, l1, l2, l3,
+                           open_start, opens, doc_agg, agg, o.d_prev, d_match, survivors);
     if (nb) hipLaunchKernelGGL(min_max_depth, dim3(nb < kMinMaxGroups * 256u ? (nb + 255u) / 256u : kMinMaxGroups), dim3(256), 0, s, agg, nb, d_result);
     if (want_match) {
         for (int k = 4; k < t.nlev; k++)
             hipLaunchKernelGGL(build_level, dim3((t.cnt[k] + 255u) / 256u), dim3(256), 0, s, t.lv[k - 1], t.cnt[k - 1], lvl[k], t.cnt[k]);
-        // closing brackets without a partner keep this value
-        (void)hipMemsetAsync(d_match, 0xFF, n * sizeof(uint32_t), s);
-        hipLaunchKernelGGL(match_brackets, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, s, d_type, opens, d_result, t, d_match);
+        // match[] is complete for every container that closes inside a block (apply_depth<true> wrote the whole array);
+        // what is left -- a container that spans a block border, or lies outside the levels a block keeps -- walks the tree.
+        // The grid covers the worst case (every 8th token an unpaired opening bracket would need more: the kernel strides)
+        hipLaunchKernelGGL(match_brackets, dim3((uint32_t)((n / 8 + 255) / 256) + 1u), dim3(256), 0, s, d_type, opens, survivors, t, d_match);
     }
     return (int)hipGetLastError();
 }
@@ -1148,13 +1261,12 @@ __global__ __launch_bounds__(kSpanThreads) void token_spans(const uint8_t *__res
 
 #undef MSJ_SPAN_ARRIVED
 
-// Test hooks (msj_debug_set_span_limits; 0xFFFFFFFF = the built-in value): stretches over g_lds_limit bytes take
-// the global-memory path, the fix-up list holds g_fix_cap entries.  No environment variable is read.
-static uint32_t g_lds_limit = 0xFFFFFFFFu, g_fix_cap = 0xFFFFFFFFu;
-static uint32_t fix_cap() {  // host: the list's capacity for this launch
-    return g_fix_cap < kFixCap ? g_fix_cap : kFixCap;
+// Test hooks (msj_token_opts, kept per context by msj_debug_set_span_limits; 0xFFFFFFFF = the built-in value): stretches
+// over lds_limit bytes take the global-memory path, the fix-up list holds fix_cap entries.  No environment variable is read.
+static uint32_t fix_cap(const msj_token_opts &o) {  // host: the list's capacity for this launch
+    return o.fix_cap < kFixCap ? o.fix_cap : kFixCap;
 }
-static uint32_t span_lds_limit() { return g_lds_limit < kSpanLds ? g_lds_limit : kSpanLds; }
+static uint32_t span_lds_limit(const msj_token_opts &o) { return o.lds_limit < kSpanLds ? o.lds_limit : kSpanLds; }
 
 // ---- the same results from TILES of the buffer (round 3) -------------------------------------------------------
 // token_spans above is organised by tokens: a workgroup first loads idx[first], idx[first + 512] to learn WHICH bytes
@@ -1728,15 +1840,9 @@ __global__ __launch_bounds__(256) void merge_chunk_counts(const int4 *__restrict
 // (1 / 7.2) 0.72 / 0.79, indent 2 (1 / 8.0) 0.64 / 0.73, UTF-8-heavy (1 / 9.6) 0.63 / 0.64, indent 4 (1 / 10.3)
 // 0.575 / 0.592, indent 8 (1 / 14.9) 0.51 / 0.43 -- the tiles from one structural per 11 bytes on.  1: token_spans,
 // 2: token_tiles whatever the density (msj_debug_set_span_mode: the tests run both, A/B runs).
-static uint32_t g_span_mode = 0;
-static bool by_tiles(uint64_t n, uint64_t len) { return g_span_mode == 2u || (g_span_mode == 0u && n * 11u >= len); }
+static bool by_tiles(const msj_token_opts &o, uint64_t n, uint64_t len) { return o.span_mode == 2u || (o.span_mode == 0u && n * 11u >= len); }
 }  // namespace msj_tokens
 
-extern "C" void msj_debug_set_span_limits(uint32_t lds_limit_bytes, uint32_t fix_capacity) {
-    msj_tokens::g_lds_limit = lds_limit_bytes;
-    msj_tokens::g_fix_cap = fix_capacity;
-}
-extern "C" void msj_debug_set_span_mode(uint32_t mode) { msj_tokens::g_span_mode = mode; }
 // what the tests place their tokens around: bytes of the buffer per workgroup of token_tiles (0) and its halo (1)
 extern "C" uint32_t msj_debug_tile_group(int32_t which) { return which == 0 ? msj_tokens::kTgBytes : msj_tokens::kTgHaloBlocks * 64u; }
 #ifdef MSJ_TILE_STAMPS
@@ -1767,41 +1873,41 @@ static uint32_t *table_of(int32_t *d_ws, uint64_t n, int with_match) {
 // the tile-organised kernel with its table in front of it and the fix-up pass behind it
 template <bool kFused, bool kSpans>
 static void launch_token_tiles(const uint8_t *d_buf, uint64_t len, const uint32_t *d_idx, uint64_t n, uint32_t *d_end, uint8_t *d_flags,
-                               uint8_t *d_type, int4 *sub, uint32_t *tbl, uint32_t *d_fix, hipStream_t s) {
+                               uint8_t *d_type, int4 *sub, uint32_t *tbl, uint32_t *d_fix, hipStream_t s, const msj_token_opts &o) {
     using namespace msj_tokens;
     const uint32_t ngroups = (uint32_t)group_count(len);
     hipLaunchKernelGGL(group_table, dim3((ngroups + 1u + 255u) / 256u), dim3(256), 0, s, d_idx, (uint32_t)n, ngroups, len, tbl);
     hipLaunchKernelGGL((token_tiles<kFused, kSpans>), dim3(ngroups), dim3(kTgThreads), 0, s, d_buf, len, d_idx, n, d_end, d_flags,
-                       g_lds_limit < kTgStage ? g_lds_limit : 0xFFFFFFFFu, d_type, sub, d_fix, fix_cap(), tbl);
+                       o.lds_limit < kTgStage ? o.lds_limit : 0xFFFFFFFFu, d_type, sub, d_fix, fix_cap(o), tbl);
     if (kSpans)
-        hipLaunchKernelGGL(span_fixup, dim3(kFixGroups), dim3(256), 0, s, d_buf, len, d_idx, n, d_end, d_flags, d_fix, fix_cap());
+        hipLaunchKernelGGL(span_fixup, dim3(kFixGroups), dim3(256), 0, s, d_buf, len, d_idx, n, d_end, d_flags, d_fix, fix_cap(o));
 }
 
-extern "C" int msj_launch_token_spans(const uint8_t *d_buf, uint64_t len, const uint32_t *d_idx, uint64_t n, uint32_t *d_end,
-                                      uint8_t *d_flags, int32_t *d_ws, uint32_t *d_fix, void *stream) {
+int msj_launch_token_spans(const uint8_t *d_buf, uint64_t len, const uint32_t *d_idx, uint64_t n, uint32_t *d_end, uint8_t *d_flags,
+                           int32_t *d_ws, uint32_t *d_fix, void *stream, const msj_token_opts &o) {
     using namespace msj_tokens;
     if (n == 0) return 0;
     hipStream_t s = static_cast<hipStream_t>(stream);
     // the spans alone: the tiles only where the index is dense (1 GiB minified 0.70 against 0.76 ms, UTF-8-heavy 0.53
     // against 0.49, pretty-printed 0.48 against 0.45: without the type bytes and bracket counts the fused call gets for
     // nothing, the tile kernel's per-byte work pays off later) -- from one structural per 7 bytes on
-    if ((g_span_mode == 2u || (g_span_mode == 0u && n * 7u >= len)) && (reinterpret_cast<uintptr_t>(d_idx) & 7u) == 0) {
-        launch_token_tiles<false, true>(d_buf, len, d_idx, n, d_end, d_flags, nullptr, nullptr, table_of(d_ws, n, 0), d_fix, s);
+    if ((o.span_mode == 2u || (o.span_mode == 0u && n * 7u >= len)) && (reinterpret_cast<uintptr_t>(d_idx) & 7u) == 0) {
+        launch_token_tiles<false, true>(d_buf, len, d_idx, n, d_end, d_flags, nullptr, nullptr, table_of(d_ws, n, 0), d_fix, s, o);
         return (int)hipGetLastError();
     }
-    const uint32_t lds_limit = span_lds_limit();  // stretches over this many bytes take the global-memory path
+    const uint32_t lds_limit = span_lds_limit(o);  // stretches over this many bytes take the global-memory path
     hipLaunchKernelGGL(token_spans<false>, dim3((uint32_t)((n + kSpanTokens - 1) / kSpanTokens)), dim3(kSpanThreads), 0, s, d_buf, len, d_idx, n,
-                       d_end, d_flags, lds_limit, static_cast<uint8_t *>(nullptr), static_cast<int4 *>(nullptr), d_fix, fix_cap());
-    hipLaunchKernelGGL(span_fixup, dim3(kFixGroups), dim3(256), 0, s, d_buf, len, d_idx, n, d_end, d_flags, d_fix, fix_cap());
+                       d_end, d_flags, lds_limit, static_cast<uint8_t *>(nullptr), static_cast<int4 *>(nullptr), d_fix, fix_cap(o));
+    hipLaunchKernelGGL(span_fixup, dim3(kFixGroups), dim3(256), 0, s, d_buf, len, d_idx, n, d_end, d_flags, d_fix, fix_cap(o));
     return (int)hipGetLastError();
 }
 
 // ---- everything stage 2 reads first, in one go (rows f1 + f2 + f4): the span kernel has every token's
 // first byte in LDS anyway, so it writes the type bytes and the depth aggregates as well and the token
 // pre-pass starts at its scan -- one pass over the buffer instead of two.
-extern "C" int msj_launch_stage2_prep(const uint8_t *d_buf, uint64_t len, const uint32_t *d_idx, uint64_t n, uint8_t *d_type,
-                                      int32_t *d_depth, uint32_t *d_match, uint32_t *d_end, uint8_t *d_flags,
-                                      msj_tokens_result *d_result, int32_t *d_ws, uint32_t *d_fix, void *stream) {
+int msj_launch_stage2_prep(const uint8_t *d_buf, uint64_t len, const uint32_t *d_idx, uint64_t n, uint8_t *d_type, int32_t *d_depth,
+                           uint32_t *d_match, uint32_t *d_end, uint8_t *d_flags, msj_tokens_result *d_result, int32_t *d_ws,
+                           uint32_t *d_fix, void *stream, const msj_token_opts &o) {
     using namespace msj_tokens;
     hipStream_t s = static_cast<hipStream_t>(stream);
     const uint64_t nb64 = (n + kBlock - 1) / kBlock;
@@ -1810,21 +1916,21 @@ extern "C" int msj_launch_stage2_prep(const uint8_t *d_buf, uint64_t len, const 
     // the fused kernel's aggregates live behind the token pre-pass's own workspace (16-byte aligned)
     const int wm = d_match != nullptr;
     int4 *sub = sub_of(d_ws, n, wm);
-    if (n && by_tiles(n, len)) {
-        launch_token_tiles<true, true>(d_buf, len, d_idx, n, d_end, d_flags, d_type, sub, table_of(d_ws, n, wm), d_fix, s);
+    if (n && by_tiles(o, n, len)) {
+        launch_token_tiles<true, true>(d_buf, len, d_idx, n, d_end, d_flags, d_type, sub, table_of(d_ws, n, wm), d_fix, s, o);
         hipLaunchKernelGGL(merge_chunk_counts, dim3((nb * 16u + 255u) / 256u), dim3(256), 0, s, sub, (uint32_t)chunk_count(n), d_ws, nb);
     } else if (n) {
         const uint32_t nsub = (uint32_t)((n + kSpanTokens - 1) / kSpanTokens);
-        const uint32_t lds_limit = span_lds_limit();
-        hipLaunchKernelGGL(token_spans<true>, dim3(nsub), dim3(kSpanThreads), 0, s, d_buf, len, d_idx, n, d_end, d_flags, lds_limit, d_type, sub, d_fix, fix_cap());
-        hipLaunchKernelGGL(span_fixup, dim3(kFixGroups), dim3(256), 0, s, d_buf, len, d_idx, n, d_end, d_flags, d_fix, fix_cap());
+        const uint32_t lds_limit = span_lds_limit(o);
+        hipLaunchKernelGGL(token_spans<true>, dim3(nsub), dim3(kSpanThreads), 0, s, d_buf, len, d_idx, n, d_end, d_flags, lds_limit, d_type, sub, d_fix, fix_cap(o));
+        hipLaunchKernelGGL(span_fixup, dim3(kFixGroups), dim3(256), 0, s, d_buf, len, d_idx, n, d_end, d_flags, d_fix, fix_cap(o));
         hipLaunchKernelGGL(merge_chunk_counts, dim3((nb * 16u + 255u) / 256u), dim3(256), 0, s, sub, (uint32_t)chunk_count(n), d_ws, nb);
     }
-    return launch_depth_passes(d_idx, n, d_type, d_depth, d_match, d_result, d_ws, s);
+    return launch_depth_passes(d_idx, n, d_type, d_depth, d_match, d_result, d_ws, s, o);
 }
 
-extern "C" int msj_launch_tokens(const uint8_t *d_buf, uint64_t len, const uint32_t *d_idx, uint64_t n, uint8_t *d_type,
-                                        int32_t *d_depth, uint32_t *d_match, msj_tokens_result *d_result, int32_t *d_ws, void *stream) {
+int msj_launch_tokens(const uint8_t *d_buf, uint64_t len, const uint32_t *d_idx, uint64_t n, uint8_t *d_type, int32_t *d_depth,
+                      uint32_t *d_match, msj_tokens_result *d_result, int32_t *d_ws, void *stream, const msj_token_opts &o) {
     using namespace msj_tokens;
     hipStream_t s = static_cast<hipStream_t>(stream);
     const uint64_t nb64 = (n + kBlock - 1) / kBlock;
@@ -1832,8 +1938,8 @@ extern "C" int msj_launch_tokens(const uint8_t *d_buf, uint64_t len, const uint3
     const uint32_t nb = (uint32_t)nb64;
     const int wm = d_match != nullptr;
     int4 *sub = sub_of(d_ws, n, wm);
-    if (n && by_tiles(n, len)) {
-        launch_token_tiles<true, false>(d_buf, len, d_idx, n, nullptr, nullptr, d_type, sub, table_of(d_ws, n, wm), nullptr, s);
+    if (n && by_tiles(o, n, len)) {
+        launch_token_tiles<true, false>(d_buf, len, d_idx, n, nullptr, nullptr, d_type, sub, table_of(d_ws, n, wm), nullptr, s, o);
         hipLaunchKernelGGL(merge_chunk_counts, dim3((nb * 16u + 255u) / 256u), dim3(256), 0, s, sub, (uint32_t)chunk_count(n), d_ws, nb);
     } else if (n) {
         const uint32_t nsub = (uint32_t)((n + kSpanTokens - 1) / kSpanTokens);
@@ -1841,5 +1947,5 @@ extern "C" int msj_launch_tokens(const uint8_t *d_buf, uint64_t len, const uint3
                            static_cast<uint8_t *>(nullptr), kSpanLds, d_type, sub, static_cast<uint32_t *>(nullptr), 0u);
         hipLaunchKernelGGL(merge_chunk_counts, dim3((nb * 16u + 255u) / 256u), dim3(256), 0, s, sub, (uint32_t)chunk_count(n), d_ws, nb);
     }
-    return launch_depth_passes(d_idx, n, d_type, d_depth, d_match, d_result, d_ws, s);
+    return launch_depth_passes(d_idx, n, d_type, d_depth, d_match, d_result, d_ws, s, o);
 }

@@ -87,7 +87,8 @@ class Stage1Device:
             raise RuntimeError(f"msj_stage1_shard_device failed: {rc}")
         return rc, nseg.value
 
-    def tokens(self, d_buf, length, d_idx, n, d_type=None, d_depth=None, d_match=None, match=False, d_result=None, sync=True):
+    def tokens(self, d_buf, length, d_idx, n, d_type=None, d_depth=None, d_match=None, match=False, d_result=None, sync=True,
+               d_prev=None):
         """Token stream for stage 2 (``msj_tokens_device``): type byte and nesting depth of every
         structural, optionally (match=True or d_match given) the partner index of every bracket.
         Returns (d_type uint8[n], d_depth int32[n], msj_tokens_result[, d_match int32[n]]); blocking
@@ -100,9 +101,10 @@ class Stage1Device:
         if match and d_match is None:
             d_match = torch.empty(max(n, 1), dtype=torch.int32, device=self.device)
         d_res = d_result if d_result is not None else torch.zeros(24, dtype=torch.uint8, device=self.device)
-        rc = self.lib.msj_tokens_device(self.ctx, _ptr(d_buf), int(length), _ptr(d_idx), n, _ptr(d_type),
-                                        _ptr(d_depth), _ptr(d_match) if d_match is not None else None,
-                                        _ptr(d_res), self._stream())
+        # d_prev: the device msj_tokens_result of the call for the tokens in front (``msj_tokens_chain_device``)
+        rc = self.lib.msj_tokens_chain_device(self.ctx, _ptr(d_buf), int(length), _ptr(d_idx), n, _ptr(d_type),
+                                              _ptr(d_depth), _ptr(d_match) if d_match is not None else None,
+                                              _ptr(d_res), _ptr(d_prev) if d_prev is not None else None, self._stream())
         if rc != 0:
             raise RuntimeError(f"msj_tokens_device failed: {rc}")
         # sync=False: nothing is waited for; the third element is the device tensor holding the msj_tokens_result
@@ -123,9 +125,11 @@ class Stage1Device:
             raise RuntimeError(f"msj_token_spans_device failed: {rc}")
         return d_end[:n], d_flags[:n]
 
-    def stage2_prep(self, d_buf, length, d_idx, n, match=False):
+    def stage2_prep(self, d_buf, length, d_idx, n, match=False, d_prev=None, d_result=None):
         """``tokens`` and ``token_spans`` in one go (``msj_stage2_prep_device``), identical results:
-        returns (d_type, d_depth, msj_tokens_result, d_match or None, d_end, d_flags)."""
+        returns (d_type, d_depth, msj_tokens_result, d_match or None, d_end, d_flags).  d_prev: the device
+        msj_tokens_result of the call for the tokens in front (``msj_stage2_prep_chain_device``); d_result: where
+        this call's goes (to hand on as the next call's d_prev)."""
         n = int(n)
         dv = self.device
         d_type = torch.empty(max(n, 1), dtype=torch.uint8, device=dv)
@@ -133,14 +137,41 @@ class Stage1Device:
         d_match = torch.empty(max(n, 1), dtype=torch.int32, device=dv) if match else None
         d_end = torch.empty(max(n, 1), dtype=torch.int32, device=dv)
         d_flags = torch.empty(max(n, 1), dtype=torch.uint8, device=dv)
-        d_res = torch.zeros(24, dtype=torch.uint8, device=dv)
-        rc = self.lib.msj_stage2_prep_device(self.ctx, _ptr(d_buf), int(length), _ptr(d_idx), n, _ptr(d_type), _ptr(d_depth),
-                                             _ptr(d_match) if match else None, _ptr(d_end), _ptr(d_flags), _ptr(d_res),
-                                             self._stream())
+        d_res = d_result if d_result is not None else torch.zeros(24, dtype=torch.uint8, device=dv)
+        rc = self.lib.msj_stage2_prep_chain_device(self.ctx, _ptr(d_buf), int(length), _ptr(d_idx), n, _ptr(d_type), _ptr(d_depth),
+                                                   _ptr(d_match) if match else None, _ptr(d_end), _ptr(d_flags), _ptr(d_res),
+                                                   _ptr(d_prev) if d_prev is not None else None, self._stream())
         if rc != 0:
             raise RuntimeError(f"msj_stage2_prep_device failed: {rc}")
         res = _lib.MsjTokensResult.from_buffer_copy(d_res.cpu().numpy().tobytes())
         return d_type[:n], d_depth[:n], res, (d_match[:n] if match else None), d_end[:n], d_flags[:n]
+
+    def stage2_prep_segments(self, d_buf, segments, d_idx, match=False, d_prev=None):
+        """Rows f1 + f2 + f4 for a shard of several uint32 segments (``msj_stage2_prep_segments``).  segments: list of
+        (byte_base, byte_len, index_begin, count) -- a host copy of the msj_segment table the shard call wrote.
+        Returns (offsets, d_type, d_depth, d_match or None, d_end, d_flags, results): segment s's arrays are the slices
+        [offsets[s], offsets[s] + count_s); results = one msj_tokens_result per segment (the last describes the shard)."""
+        nseg = len(segments)
+        table = (_lib.MsjSegment * nseg)()
+        for k, (bb, bl, ib, cnt) in enumerate(segments):
+            table[k].byte_base, table[k].byte_len, table[k].index_begin, table[k].count = bb, bl, ib, cnt
+        total = sum(((c + 7) // 8) * 8 for _, _, _, c in segments)
+        dv = self.device
+        d_type = torch.empty(max(total, 8), dtype=torch.uint8, device=dv)
+        d_depth = torch.empty(max(total, 8), dtype=torch.int32, device=dv)
+        d_match = torch.empty(max(total, 8), dtype=torch.int32, device=dv) if match else None
+        d_end = torch.empty(max(total, 8), dtype=torch.int32, device=dv)
+        d_flags = torch.empty(max(total, 8), dtype=torch.uint8, device=dv)
+        d_res = torch.zeros(24 * nseg, dtype=torch.uint8, device=dv)
+        offs = (ctypes.c_uint64 * nseg)()
+        rc = self.lib.msj_stage2_prep_segments(self.ctx, _ptr(d_buf), ctypes.byref(table), nseg, _ptr(d_idx), _ptr(d_type), _ptr(d_depth),
+                                               _ptr(d_match) if match else None, _ptr(d_end), _ptr(d_flags), _ptr(d_res),
+                                               _ptr(d_prev) if d_prev is not None else None, offs, self._stream())
+        if rc != 0:
+            raise RuntimeError(f"msj_stage2_prep_segments failed: {rc}")
+        raw = d_res.cpu().numpy().tobytes()
+        results = [_lib.MsjTokensResult.from_buffer_copy(raw[24 * k: 24 * k + 24]) for k in range(nseg)]
+        return [int(o) for o in offs], d_type, d_depth, d_match, d_end, d_flags, results
 
     def documents(self, d_buf, length, d_idx, n, d_type, d_depth, is_final=False, d_carry=None, d_doc_first=None,
                   d_result=None, sync=True, after_tokens=False):

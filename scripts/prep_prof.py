@@ -28,7 +28,7 @@ if a.lib:
     _lib.LIB_PATH = os.path.abspath(a.lib)
 
 dev = Stage1Device(0)
-dev.lib.msj_debug_set_span_mode(a.mode)
+dev.lib.msj_debug_set_span_mode(dev.ctx, a.mode)
 torch.cuda.set_device(0)
 u = synth.workload(a.workload, 64 << 20)
 d_buf = torch.from_numpy(u).to(dev.device).repeat((a.mib << 20) // u.size)

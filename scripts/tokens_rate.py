@@ -12,7 +12,7 @@ from mojo_simdjson_amd.device import Stage1Device  # noqa: E402
 
 dev = Stage1Device(0)
 if len(sys.argv) > 1:  # 1 = the kernel organised by tokens, 2 = by tiles; default: the product's choice by density
-    dev.lib.msj_debug_set_span_mode(int(sys.argv[1]))
+    dev.lib.msj_debug_set_span_mode(dev.ctx, int(sys.argv[1]))
     print(f"span mode {sys.argv[1]}")
 torch.cuda.set_device(0)
 for name in ("minified", "utf8", "pretty4"):

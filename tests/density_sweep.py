@@ -16,6 +16,7 @@ sys.path.insert(0, ROOT)
 from tests import helpers  # noqa: E402
 from mojo_simdjson_amd import synth  # noqa: E402
 from mojo_simdjson_amd.device import Stage1Device  # noqa: E402
+import bench  # noqa: E402  (same_box_ceilings: the trivial kernels of scripts/ubench/hbm_ceilings.hip on this box)
 
 UNIT = 64 << 20
 CASES = [("spaces + one scalar", lambda: synth.extreme(UNIT, 3)), ("one giant string", lambda: synth.extreme(UNIT, 2)),
@@ -44,7 +45,9 @@ def main():
         d_buf = d_unit.repeat(reps)
         n = d_buf.numel()
         want = n_unit * reps
-        d_idx = torch.empty(want + 16, dtype=torch.int32, device=dev.device)
+        ntiles = n // 4096
+        wquads = min(1024, -(-(-(-4 * want // ntiles)) // 128) * 8)  # what the ceiling kernels write per tile (whole lines)
+        d_idx = torch.empty(max(want + 16, ntiles * wquads * 4), dtype=torch.int32, device=dev.device)
         d_res = dev.new_carry()
         import time
         for _ in range(5):
@@ -72,8 +75,19 @@ def main():
         assert int(res.count) == want and res.internal_error == 0, (name, int(res.count), want)
         # the reference's code for the repeated stream: only meaningful for the valid documents
         alg = n + 4 * want
+        # the same bytes moved by trivial kernels on this box, right behind the product's window (the index array is scratch now)
+        ceil = None
+        try:
+            ceil = bench.same_box_ceilings(torch, dev.device, d_buf, ntiles * 4096, want, d_idx)
+        except Exception as exc:
+            print("ceilings:", repr(exc))
+        cs = ""
+        if ceil:
+            cs = (f"   same-mix ceiling {ceil['same_mix_best']:.0f} GB/s (w/r {ceil['w_per_r']:.2f}; mixes "
+                  f"{ceil.get('same_mix_plain_nt', 0):.0f}/{ceil.get('same_mix_nt_nt', 0):.0f}/{ceil.get('same_mix_deferred_nt_nt', 0):.0f}, "
+                  f"serial sum {ceil.get('serial_sum_of_pure_streams', 0):.0f}) -> {alg / ms / 1e6 / ceil['same_mix_best']:.3f} of it")
         print(f"{name:24s} {n:12d} {want / n:8.4f} {ms:8.4f} {n / ms / 1e6:12.1f} {alg / ms / 1e6:14.1f} {alg / ms / 1e6 / 8000:14.3f}"
-              f"   unsettled {ms_unsettled:.4f} ms ({alg / ms_unsettled / 1e6 / 8000:.3f})", flush=True)
+              f"   unsettled {ms_unsettled:.4f} ms ({alg / ms_unsettled / 1e6 / 8000:.3f}){cs}", flush=True)
         del d_buf, d_idx
     dev.close()
 

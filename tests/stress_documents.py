@@ -62,11 +62,11 @@ def main():
         assert np.array_equal(m.cpu().numpy().view(np.uint32), helpers.oracle_match(wt)), (seed, cases)
         we, wf = helpers.oracle_token_spans(data, widx)
         for limit in ("", "0", "2048"):
-            dev.lib.msj_debug_set_span_limits(int(limit) if limit else 0xFFFFFFFF, 0xFFFFFFFF)
+            dev.lib.msj_debug_set_span_limits(dev.ctx, int(limit) if limit else 0xFFFFFFFF, 0xFFFFFFFF)
             e, f = dev.token_spans(d_buf, len(data), d_idx, n)
             assert np.array_equal(f.cpu().numpy(), wf), (seed, cases, limit)
             assert np.array_equal(e.cpu().numpy().view(np.uint32), we), (seed, cases, limit)
-        dev.lib.msj_debug_set_span_limits(0xFFFFFFFF, 0xFFFFFFFF)
+        dev.lib.msj_debug_set_span_limits(dev.ctx, 0xFFFFFFFF, 0xFFFFFFFF)
         cases += 1
         nbytes += len(data)
         if cases % 20 == 0:

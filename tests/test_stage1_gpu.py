@@ -807,6 +807,54 @@ def test_multi_segment_over_4gib(torch_mod, dev, oracle):
     assert tail == [total & 0xFFFFFFFF, total & 0xFFFFFFFF, 0]
 
 
+@pytest.mark.parametrize("shape", ["all_brackets", "d_two_thirds"])
+def test_one_segment_at_the_uint32_edge(torch_mod, dev, shape):
+    """the largest segment one launch indexes (0xFFFF0000 bytes) at the densities where the
+    32-bit launch-relative count of the range prefixes (stage1_kernel.hip: 31:0 of pre[]) comes closest to its limit:
+    `[[[[...` -- every byte structural, 4 294 901 760 indices = 17 GB, index k = k -- and `[10,10,...` at 3.9 GiB
+    (2.8 G indices).  Checked on the device against the closed form, in slices."""
+    torch = torch_mod
+    SEG = 0xFFFF0000
+    if shape == "all_brackets":
+        n_bytes = SEG
+        d_buf = torch.full((n_bytes,), ord("["), dtype=torch.uint8, device=dev.device)
+        want_n = n_bytes
+
+        def expected(a, b):  # indices a .. b-1
+            return torch.arange(a, b, dtype=torch.int64, device=dev.device)
+    else:
+        m = (int(3.9 * (1 << 30)) - 1) // 3
+        n_bytes = 1 + 3 * m
+        d_buf = torch.empty(n_bytes + 15, dtype=torch.uint8, device=dev.device)[:n_bytes]
+        d_buf[0] = ord("[")
+        d_buf[1:].view(m, 3).copy_(torch.tensor(list(b"10,"), dtype=torch.uint8, device=dev.device).expand(m, 3))
+        want_n = 1 + 2 * m  # '[', then '1' and ',' of every "10,"
+
+        def expected(a, b):
+            k = torch.arange(a, b, dtype=torch.int64, device=dev.device)
+            j = (k - 1) // 2
+            e = torch.where((k - 1) % 2 == 0, 1 + 3 * j, 3 + 3 * j)
+            return torch.where(k == 0, torch.zeros_like(k), e)
+    assert d_buf.data_ptr() % 16 == 0
+    d_idx = torch.empty(want_n + 3 + 1, dtype=torch.int32, device=dev.device)
+    cin, cout = dev.new_carry(), dev.new_carry()
+    rc, nseg = dev.shard(d_buf, n_bytes, d_idx, cin, cout, is_final=True, trailer_len=n_bytes)
+    assert rc == 0 and nseg == 1
+    res = dev.fetch(cout)
+    assert (res.code, res.count, res.bytes, res.internal_error, res.capacity_error) == (0, want_n, n_bytes, 0, 0)
+    step = 1 << 28
+    for a in range(0, want_n, step):
+        b = min(want_n, a + step)
+        got = d_idx[a:b].to(torch.int64) & 0xFFFFFFFF
+        want = expected(a, b)
+        if not torch.equal(got, want):
+            bad = int((got != want).nonzero()[0]) + a
+            raise AssertionError(f"{shape}: index {bad}: {int(d_idx[bad]) & 0xFFFFFFFF} != {int(expected(bad, bad + 1)[0])}")
+        del got, want
+    tail = (d_idx[want_n:want_n + 3].to(torch.int64) & 0xFFFFFFFF).tolist()
+    assert tail == [n_bytes & 0xFFFFFFFF, n_bytes & 0xFFFFFFFF, 0]
+
+
 def test_config5_share_of_a_non_first_rank_8gib(torch_mod, dev, oracle):
     """BASELINE.json config 5 as one of its ranks sees it, at full size, index by index: the stream is 1 024 units
     (64 GiB) cut into 8 byte ranges of ~8 GiB; this is the exact share of a rank > 0 whose cut falls INSIDE A STRING

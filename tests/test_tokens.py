@@ -2,6 +2,8 @@
 
 Derived quantities (the reference has no such arrays, oracle/tokens_oracle.c is their definition);
 the CPU part checks that definition by hand, the GPU part the HIP kernels against it."""
+import ctypes
+
 import numpy as np
 import pytest
 
@@ -191,8 +193,8 @@ def span_mode(dev, request):
     """The token calls' two kernels, each forced whatever the density of the index (the product picks by density):
     organised by tiles of the buffer (msj_debug_set_span_mode(2)) and by tokens (1): the same tests, the same
     definitions."""
-    dev.lib.msj_debug_set_span_mode(1 if request.param == "tokens" else 2)
-    request.addfinalizer(lambda: dev.lib.msj_debug_set_span_mode(0))
+    dev.lib.msj_debug_set_span_mode(dev.ctx, 1 if request.param == "tokens" else 2)
+    request.addfinalizer(lambda: dev.lib.msj_debug_set_span_mode(dev.ctx, 0))
     return request.param
 
 
@@ -233,8 +235,8 @@ def test_token_spans(dev, lds_limit, request, span_mode):
     and the per-token path from global memory that long stretches take (forced by a limit of 0; 4096 mixes them)."""
     from mojo_simdjson_amd import synth
 
-    dev.lib.msj_debug_set_span_limits(int(lds_limit) if lds_limit else 0xFFFFFFFF, 0xFFFFFFFF)
-    request.addfinalizer(lambda: dev.lib.msj_debug_set_span_limits(0xFFFFFFFF, 0xFFFFFFFF))
+    dev.lib.msj_debug_set_span_limits(dev.ctx, int(lds_limit) if lds_limit else 0xFFFFFFFF, 0xFFFFFFFF)
+    request.addfinalizer(lambda: dev.lib.msj_debug_set_span_limits(dev.ctx, 0xFFFFFFFF, 0xFFFFFFFF))
 
     for f in helpers.golden_valid_files():
         js, _ = helpers.read_fixture(f)
@@ -268,9 +270,9 @@ def test_token_spans(dev, lds_limit, request, span_mode):
     # ... many of them: the work list of the fix-up pass, and (capacity lowered to 3 entries) its overflow path
     many = b"[" + (b"1," * 255 + b'1.5"xx"' + b"y" * 300 + b" ,") * 40 + b"7]"
     _check_spans(dev, many, "forty tokens on the fix-up list")
-    dev.lib.msj_debug_set_span_limits(int(lds_limit) if lds_limit else 0xFFFFFFFF, 3)
+    dev.lib.msj_debug_set_span_limits(dev.ctx, int(lds_limit) if lds_limit else 0xFFFFFFFF, 3)
     _check_spans(dev, many, "the fix-up list overflows")
-    dev.lib.msj_debug_set_span_limits(int(lds_limit) if lds_limit else 0xFFFFFFFF, 0xFFFFFFFF)
+    dev.lib.msj_debug_set_span_limits(dev.ctx, int(lds_limit) if lds_limit else 0xFFFFFFFF, 0xFFFFFFFF)
     _check_spans(dev, many, "the list is clean again")
     # the closing quote is found from the NEXT structural: byte soups (valid or not) must agree with the forward scan
     rng = np.random.default_rng(9)
@@ -341,8 +343,8 @@ def test_stage2_prep_equals_the_separate_calls(dev, lds_limit, request, span_mod
     """msj_stage2_prep_device = token pre-pass + token spans from one pass over the buffer."""
     from mojo_simdjson_amd import synth
 
-    dev.lib.msj_debug_set_span_limits(int(lds_limit) if lds_limit else 0xFFFFFFFF, 0xFFFFFFFF)
-    request.addfinalizer(lambda: dev.lib.msj_debug_set_span_limits(0xFFFFFFFF, 0xFFFFFFFF))
+    dev.lib.msj_debug_set_span_limits(dev.ctx, int(lds_limit) if lds_limit else 0xFFFFFFFF, 0xFFFFFFFF)
+    request.addfinalizer(lambda: dev.lib.msj_debug_set_span_limits(dev.ctx, 0xFFFFFFFF, 0xFFFFFFFF))
     for f in helpers.golden_valid_files():
         js, _ = helpers.read_fixture(f)
         _check_prep(dev, js, f)
@@ -365,9 +367,9 @@ def test_prep_around_the_tile_groups(dev, lds_limit, request):
     chunks of 128 that belong to the group their first token lies in: tokens, chunk borders, long strings, floats whose
     scan runs past the next structural and numbers at the cap are moved across the group border, the end of the halo
     and the end of the buffer byte by byte."""
-    dev.lib.msj_debug_set_span_limits(int(lds_limit) if lds_limit else 0xFFFFFFFF, 0xFFFFFFFF)
-    dev.lib.msj_debug_set_span_mode(2)
-    request.addfinalizer(lambda: (dev.lib.msj_debug_set_span_limits(0xFFFFFFFF, 0xFFFFFFFF), dev.lib.msj_debug_set_span_mode(0)))
+    dev.lib.msj_debug_set_span_limits(dev.ctx, int(lds_limit) if lds_limit else 0xFFFFFFFF, 0xFFFFFFFF)
+    dev.lib.msj_debug_set_span_mode(dev.ctx, 2)
+    request.addfinalizer(lambda: (dev.lib.msj_debug_set_span_limits(dev.ctx, 0xFFFFFFFF, 0xFFFFFFFF), dev.lib.msj_debug_set_span_mode(dev.ctx, 0)))
     G, H = int(dev.lib.msj_debug_tile_group(0)), int(dev.lib.msj_debug_tile_group(1))  # 12 KiB of the buffer per workgroup + 2 KiB
     rng = np.random.default_rng(77)
     # (a) a dense run of short tokens across two borders, shifted byte by byte (chunk grid against byte grid)
@@ -475,8 +477,8 @@ def test_stage2_prep_1gib_replicated(dev, workload, mode, reps, request):
 
     from mojo_simdjson_amd import synth
 
-    dev.lib.msj_debug_set_span_mode(mode)
-    request.addfinalizer(lambda: dev.lib.msj_debug_set_span_mode(0))
+    dev.lib.msj_debug_set_span_mode(dev.ctx, mode)
+    request.addfinalizer(lambda: dev.lib.msj_debug_set_span_mode(dev.ctx, 0))
     u = synth.workload(workload, 64 << 20)
     oracle = helpers.load_oracle()
     data = u.tobytes()
@@ -503,3 +505,117 @@ def test_stage2_prep_1gib_replicated(dev, workload, mode, reps, request):
     for k in range(reps):
         want_e = torch.where(we_d == 0, we_d, we_d + k * len(data))
         assert torch.equal(ev[k].to(torch.int64) & 0xFFFFFFFF, want_e), k
+
+
+# ---- round 4: bracket partners inside a block (apply_depth<true>), the depth carried from call to call, segments ----
+@pytest.mark.gpu
+def test_bracket_partners_around_the_block_levels(dev, span_mode):
+    """The partner of a bracket is settled inside its block of 2 048 tokens where its container closes there and lies
+    inside the 16 depth levels the block keeps bitmaps of (4 below the depth at its start .. 11 above); everything
+    else goes through the min tree.  Containers placed across block borders, nests that leave the levels on either
+    side, the same level re-used many times inside one block, empty containers, stray brackets."""
+    cases = {
+        "many small containers at one level": b"[" + b"[1,2],{},[[]]," * 3000 + b"0]",
+        "a nest of 11 / 12 / 13 inside a block": b"[" + (b"[" * 11 + b"]" * 11 + b",") * 50 + (b"[" * 12 + b"]" * 12 + b",") * 50 +
+                                                   (b"[" * 13 + b"]" * 13 + b",") * 50 + b"0]",
+        "a block that starts deep and climbs 6 below its start": b"[" * 40 + b"1," * 2100 + b"2" + b"]" * 6 + b",[3]" * 700 + b"]" * 34,
+        "containers over block borders": b"[" + (b"[" + b"7," * 500 + b"8],") * 30 + b"0]",
+        "closing brackets in front of every opening one": b"]" * 3000 + b"[" * 10 + b"]" * 10 + b"[" * 3000,
+        "alternating at the top level": b"[]" * 5000 + b"{}" * 5000,
+        "one long flat array": b"[" + b"1," * 50000 + b"1]",
+    }
+    for where, data in cases.items():
+        _check(dev, data, where)
+    rng = np.random.default_rng(11)
+    for k in range(40):  # nests of random depth and width around the block size
+        parts = []
+        for _ in range(int(rng.integers(50, 400))):
+            dpt = int(rng.integers(1, 24))
+            parts.append(b"[" * dpt + b"1," * int(rng.integers(0, 60)) + b"1" + b"]" * dpt)
+        _check(dev, b"[" + b",".join(parts) + b"]", f"random nests {k}")
+
+
+@pytest.mark.gpu
+def test_depth_is_carried_from_call_to_call(dev, span_mode):
+    """msj_tokens_chain_device / msj_stage2_prep_chain_device: a token array cut anywhere -- inside containers, at
+    negative depths -- and handed over in pieces gives the depths, the final / minimum / maximum of the whole; the
+    partners are those of each piece alone (a container cut by the border keeps 0xFFFFFFFF at both ends)."""
+    import torch
+    from mojo_simdjson_amd import synth
+
+    rng = np.random.default_rng(12)
+    docs = [synth.workload("minified", 2 << 20).tobytes(), b"]" * 700 + b"[" * 300 + b"1," * 5000 + b"]" * 100 + b"[" * 9000,
+            b"[" + (b"[" * 9 + b"1" + b"]" * 9 + b",") * 3000 + b"0]"]
+    for which, data in enumerate(docs):
+        d_buf = torch.from_numpy(np.frombuffer(data, dtype=np.uint8).copy()).to(dev.device)
+        d_idx = torch.empty(len(data) + 8, dtype=torch.int32, device=dev.device)
+        d_res = dev.new_carry()
+        dev.index(d_buf, d_idx, d_res)
+        n = int(dev.fetch(d_res).count)
+        idx = d_idx[:n].cpu().numpy().view(np.uint32)
+        wt, wd, (final, mn, mx) = helpers.oracle_tokens(data, idx)
+        for trial in range(4):
+            cuts = sorted(set([0, n] + [int(c) // 4 * 4 for c in rng.integers(1, n, int(rng.integers(1, 4)))]))  # 16-byte aligned slices
+            prev = None
+            for a, b in zip(cuts[:-1], cuts[1:]):
+                res_buf = torch.zeros(24, dtype=torch.uint8, device=dev.device)
+                if trial % 2 == 0:
+                    t, d, _, m = dev.tokens(d_buf, len(data), d_idx[a:], b - a, match=True, d_result=res_buf, sync=False, d_prev=prev)
+                else:
+                    t, d, _, m, _, _ = dev.stage2_prep(d_buf, len(data), d_idx[a:], b - a, match=True, d_prev=prev, d_result=res_buf)
+                where = f"doc {which}, tokens [{a}, {b}) of {n}"
+                assert np.array_equal(t.cpu().numpy(), wt[a:b]), where
+                assert np.array_equal(d.cpu().numpy(), wd[a:b]), where
+                assert np.array_equal(m.cpu().numpy().view(np.uint32), helpers.oracle_match(wt[a:b])), where
+                prev = res_buf
+            from mojo_simdjson_amd import _lib
+
+            r = _lib.MsjTokensResult.from_buffer_copy(prev.cpu().numpy().tobytes())
+            assert (r.n, r.final_depth, r.min_depth, r.max_depth) == (cuts[-1] - cuts[-2], final, mn, mx), (which, cuts, r.final_depth, r.min_depth, r.max_depth)
+
+
+@pytest.mark.gpu
+def test_prep_segments_of_one_shard(dev):
+    """msj_stage2_prep_segments: the shard call's segment table (here 1 MiB segments forced by the test hook, so that
+    an 8 MiB document is a chain of eight) -> type, depth, spans and partners of every token, the depth handed from
+    segment to segment on the device; a later segment's index slice starts wherever the one in front ended (not on the
+    16-byte grid: the library copies it)."""
+    import torch
+    from mojo_simdjson_amd import _lib, synth
+
+    data = synth.workload("minified", 8 << 20).tobytes()
+    L = dev.lib
+    L.msj_debug_set_segment_bytes.argtypes = [ctypes.c_void_p, ctypes.c_uint64]
+    assert L.msj_debug_set_segment_bytes(dev.ctx, 1 << 20) == 0
+    try:
+        d_buf = torch.from_numpy(np.frombuffer(data, dtype=np.uint8).copy()).to(dev.device)
+        d_idx = torch.empty(len(data) // 2, dtype=torch.int32, device=dev.device)
+        d_seg = torch.zeros(16 * 32, dtype=torch.uint8, device=dev.device)
+        cin, cout = dev.make_carry(0, 0, 0), dev.new_carry()
+        _, nseg = dev.shard(d_buf, len(data), d_idx, cin, cout, segments=d_seg, is_final=True, trailer_len=len(data))
+        assert nseg == 8 and dev.fetch(cout).code == 0
+        table = np.frombuffer(d_seg.cpu().numpy().tobytes(), dtype=np.uint64).reshape(16, 4)[:nseg]
+        segs = [tuple(int(x) for x in row) for row in table]
+        assert any(s[2] % 4 for s in segs[1:]), "the test wants a slice off the 16-byte grid"
+        offs, t, d, m, e, f, results = dev.stage2_prep_segments(d_buf, segs, d_idx, match=True)
+        idx_all = d_idx.cpu().numpy().view(np.uint32)
+        depth0, mn_all, mx_all = 0, None, None
+        for s, (bb, bl, ib, cnt) in enumerate(segs):
+            piece = data[bb:bb + bl]
+            idx = idx_all[ib:ib + cnt]
+            wt, wd, (final, mn, mx) = helpers.oracle_tokens(piece, idx)
+            we, wf = helpers.oracle_token_spans(piece, idx)
+            o = offs[s]
+            where = f"segment {s}"
+            assert np.array_equal(t[o:o + cnt].cpu().numpy(), wt), where
+            assert np.array_equal(d[o:o + cnt].cpu().numpy(), wd + depth0), where
+            assert np.array_equal(m[o:o + cnt].cpu().numpy().view(np.uint32), helpers.oracle_match(wt)), where
+            assert np.array_equal(f[o:o + cnt].cpu().numpy(), wf) and np.array_equal(e[o:o + cnt].cpu().numpy().view(np.uint32), we), where
+            mn_all = depth0 + mn if mn_all is None else min(mn_all, depth0 + mn)
+            mx_all = depth0 + mx if mx_all is None else max(mx_all, depth0 + mx)
+            depth0 += final
+            r = results[s]
+            assert (r.n, r.final_depth, r.min_depth, r.max_depth) == (cnt, depth0, mn_all, mx_all), where
+        assert depth0 == 0  # the document is closed at the end of the shard
+    finally:
+        assert L.msj_debug_set_segment_bytes(dev.ctx, 0xFFFF0000) == 0
