@@ -120,6 +120,14 @@ __device__ __forceinline__ uint32_t wave_incl_sum(uint32_t x) {
 //      the blocks alone took 0.1 - 0.26 ms for 10^5 blocks (every pass pays the full memory latency with
 //      nothing else on the chip); this way the single workgroup of (2) only sees the runs.
 constexpr uint32_t kSuper = 1024;  // blocks per run: 256 threads x 4
+// The list of opening brackets left to the min tree is kept in kSurvivorShards separate lists, block b appending to
+// list b mod kSurvivorShards with one returning atomic per wave that has any: ONE counter word sustains only ~85
+// returning atomics per microsecond chip-wide (the stage-1 kernel's range tickets met the same wall), and 10^5 blocks
+// on one word made the depth pass 1.26 ms per GiB minified instead of 0.3.  Counters 4 KiB apart; a list's capacity is
+// what its blocks can hold at most.
+constexpr uint32_t kSurvivorShards = 256;
+constexpr uint32_t kSurvivorStride = 1024;  // words between two counters
+__host__ __device__ inline uint64_t survivor_capacity(uint64_t nblocks) { return (uint64_t)(kThreads * kPer) * (nblocks / kSurvivorShards + 1u); }
 __global__ __launch_bounds__(256) void scan_super(const int32_t *__restrict__ block_agg, uint32_t nblocks, int32_t *__restrict__ rel_start,
                                                   uint32_t *__restrict__ rel_open, int32_t *__restrict__ super_agg) {
     __shared__ Agg wave_agg[4];
@@ -277,8 +285,9 @@ __global__ __launch_bounds__(1024) void scan_blocks(const int32_t *__restrict__ 
         result->min_depth = none ? 0 : mn;
         result->max_depth = none ? 0 : mx;
         result->reserved = carry_opens;  // number of opening brackets
-        if (survivors) *survivors = 0u;  // apply_depth<true> appends the brackets it could not pair inside their block
     }
+    // apply_depth<true> appends the opening brackets it could not pair inside their block: one counter per list shard
+    if (survivors && threadIdx.x < kSurvivorShards) survivors[threadIdx.x * kSurvivorStride] = 0u;
 }
 
 // (3) depth of every token -- and, kMatch, the partner of every bracket whose container closes inside the block:
@@ -303,12 +312,13 @@ __global__ __launch_bounds__(kThreads) void apply_depth(const uint8_t *__restric
                                                         int32_t *__restrict__ block_mm, const msj_tokens_result *__restrict__ prev,
                                                         uint32_t *__restrict__ match, uint32_t *__restrict__ survivors) {
     __shared__ uint32_t bm[kMatch ? kMatchLevels : 1][kMatch ? kBlock / 32 : 1];  // opening brackets per level, one bit per token
-    __shared__ uint64_t bm_words[kMatch ? kMatchLevels : 1];                        // ... and which of a level's 64 words are not empty
+    __shared__ unsigned long long bm_words[kMatch ? kMatchLevels : 1];              // ... and which of a level's 64 words are not empty
     __shared__ __attribute__((aligned(16))) uint32_t s_match[kMatch ? kBlock : 4];
     if (kMatch) {
         uint32_t *z = &bm[0][0];
 #pragma unroll
         for (int k = 0; k < kMatchLevels * (int)(kBlock / 32) / kThreads; k++) z[threadIdx.x + k * kThreads] = 0u;
+        if (threadIdx.x < kMatchLevels) bm_words[threadIdx.x] = 0ull;
         *reinterpret_cast<uint4 *>(&s_match[8 * threadIdx.x]) = make_uint4(~0u, ~0u, ~0u, ~0u);
         *reinterpret_cast<uint4 *>(&s_match[8 * threadIdx.x + 4]) = make_uint4(~0u, ~0u, ~0u, ~0u);
     }
@@ -358,6 +368,8 @@ __global__ __launch_bounds__(kThreads) void apply_depth(const uint8_t *__restric
             rmx = max(rmx, before);
         }
     }
+    bool surv_any = false;
+    uint32_t surv_incl = 0, surv_slot = 0, surv_mine = 0, surv_mask = 0;
     if (kMatch) {
         const int level0 = block_depth0 - kMatchBelow;
         const uint32_t t0 = 8u * threadIdx.x;  // this thread's first token inside the block
@@ -365,13 +377,10 @@ __global__ __launch_bounds__(kThreads) void apply_depth(const uint8_t *__restric
 #pragma unroll
         for (int k = 0; k < kPer; k++) {
             const uint32_t lv = (uint32_t)(out[k] - level0);
-            if (d[k] > 0 && lv < (uint32_t)kMatchLevels && base + k < n) atomicOr(&bm[lv][(t0 + k) >> 5], 1u << ((t0 + k) & 31u));
-        }
-        __syncthreads();
-        // (b) per level, the words that hold a bit
-        for (int lv = wave; lv < kMatchLevels; lv += kThreads / 64) {
-            const uint64_t nz = __ballot(bm[lv][lane] != 0u);
-            if (lane == 0) bm_words[lv] = nz;
+            if (d[k] > 0 && lv < (uint32_t)kMatchLevels && base + k < n) {
+                atomicOr(&bm[lv][(t0 + k) >> 5], 1u << ((t0 + k) & 31u));
+                atomicOr(&bm_words[lv], 1ull << ((t0 + k) >> 5));  // (b) ... and the level's words that hold a bit
+            }
         }
         __syncthreads();
         // (c) every closing bracket looks for the most recent opening one of its level
@@ -405,16 +414,16 @@ __global__ __launch_bounds__(kThreads) void apply_depth(const uint8_t *__restric
         const uint32_t mk[8] = {ma.x, ma.y, ma.z, ma.w, mb.x, mb.y, mb.z, mb.w};
 #pragma unroll
         for (int k = 0; k < kPer; k++) mine += (d[k] > 0 && mk[k] == ~0u && base + k < n) ? 1u : 0u;
-        const uint64_t any = __ballot(mine != 0u);
-        if (any != 0ull) {  // uniform per wave
-            const uint32_t incl_m = wave_incl_sum(mine);
-            uint32_t slot0 = 0;
-            if (lane == 63) slot0 = atomicAdd(survivors, incl_m);
-            slot0 = (uint32_t)__builtin_amdgcn_readlane((int)slot0, 63) + incl_m - mine;
-#pragma unroll
-            for (int k = 0; k < kPer; k++)
-                if (d[k] > 0 && mk[k] == ~0u && base + k < n) opens[slot0++] = (uint32_t)(base + k);
+        // the slot is DRAWN here (one returning atomic per wave that has any) and USED at the very end of the kernel: its
+        // round trip overlaps the stores of match[] and depth[] and the aggregates below
+        surv_any = __ballot(mine != 0u) != 0ull;  // uniform per wave
+        if (surv_any) {
+            surv_incl = wave_incl_sum(mine);
+            if (lane == 63) surv_slot = atomicAdd(survivors + (blockIdx.x % kSurvivorShards) * kSurvivorStride, surv_incl);
         }
+        surv_mine = mine;
+#pragma unroll
+        for (int k = 0; k < kPer; k++) surv_mask |= (d[k] > 0 && mk[k] == ~0u && base + k < n) ? 1u << k : 0u;
         // (e) the block's slice of match[]: 1 KiB contiguous per store instruction, like the depths below
         const uint64_t wb = (uint64_t)blockIdx.x * kBlock + (uint64_t)wave * 512u;
         if (wb + 512u <= n) {  // uniform per wave
@@ -518,6 +527,14 @@ __global__ __launch_bounds__(kThreads) void apply_depth(const uint8_t *__restric
         m = min(m, __shfl_xor(m, 32));
         if ((threadIdx.x & 63) == 0 && base < n) min512[base >> 9] = m;  // 512 tokens = this wave
     }
+    if (kMatch && surv_any) {  // uniform per wave: the opening brackets left to match_brackets, at the slot drawn above
+        const uint32_t shard = blockIdx.x % kSurvivorShards;
+        uint32_t *list = opens + (uint64_t)shard * survivor_capacity(gridDim.x);
+        uint32_t slot = (uint32_t)__builtin_amdgcn_readlane((int)surv_slot, 63) + surv_incl - surv_mine;
+#pragma unroll
+        for (int k = 0; k < kPer; k++)
+            if ((surv_mask >> k) & 1u) list[slot++] = (uint32_t)(base + k);
+    }
 }
 
 // (4) minimum / maximum of the running depth over the stream, from the per-block values apply_depth left in the block
@@ -575,18 +592,43 @@ __global__ __launch_bounds__(256) void build_level(const int32_t *__restrict__ i
     out[o] = m;
 }
 
-// the 8 entries of group g at one level (levels >= 1 are padded to a multiple of 8 with kNone;
-// level 0 is the caller's depth array and is read with a guard at its end)
+// levels 6 .. of the tree in ONE single-workgroup launch (they hold n / 262 144 entries and less; one launch of
+// build_level each cost 28 us of launch latency per call, one workgroup from level 5 on 30 us: level 5 is too long for it)
+struct UpperLevels {
+    int32_t *lv[kMaxLevels];
+    uint32_t cnt[kMaxLevels];
+    int first, nlev;  // builds lv[first .. nlev) from lv[first - 1]
+};
+__global__ __launch_bounds__(1024) void build_upper_levels(const UpperLevels u) {
+    for (int k = u.first; k < u.nlev; k++) {
+        const int32_t *in = u.lv[k - 1];
+        const uint32_t n_in = u.cnt[k - 1], n_out = u.cnt[k];
+        for (uint32_t o = threadIdx.x; o < n_out; o += 1024u) {
+            int m = kNone;
+            for (uint32_t j = 0; j <= kFanMask; j++) {
+                const uint32_t i = (o << kFanShift) + j;
+                if (i < n_in) m = min(m, in[i]);
+            }
+            u.lv[k][o] = m;
+        }
+        __threadfence_block();
+        __syncthreads();
+    }
+}
+
+// the 8 entries of group g at one level; a level's last group is read with a guard at its end (the padding of a
+// level is never written: only the brackets a block could not pair walk the tree, so the guard costs nothing that
+// shows and saves a fill of the tree in front of every call)
 __device__ __forceinline__ void load_group(const MinTree &t, int lev, uint32_t g, int v[8]) {
     const int32_t *p = t.lv[lev] + ((uint64_t)g << kFanShift);
-    if (lev > 0 || ((uint64_t)g << kFanShift) + 8u <= t.cnt[0]) {
+    if (((uint64_t)g << kFanShift) + 8u <= t.cnt[lev]) {
         const int4 a = *reinterpret_cast<const int4 *>(p);
         const int4 b = *reinterpret_cast<const int4 *>(p + 4);
         v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w;
         v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
     } else {
 #pragma unroll
-        for (int k = 0; k < 8; k++) v[k] = (((uint64_t)g << kFanShift) + k < t.cnt[0]) ? p[k] : kNone;
+        for (int k = 0; k < 8; k++) v[k] = (((uint64_t)g << kFanShift) + k < t.cnt[lev]) ? p[k] : kNone;
     }
 }
 // first k >= from with v[k] <= target, 8 if none
@@ -598,44 +640,111 @@ __device__ __forceinline__ uint32_t first_le(const int v[8], uint32_t from, int 
     return m ? (uint32_t)__builtin_ctz(m) : 8u;
 }
 
-// one thread per OPENING bracket (a dense work list: with one thread per token only a few lanes of
-// a wave would walk the tree, each through a chain of dependent loads)
+// EIGHT LANES per opening bracket the depth pass could not pair inside its block (1.4 % of the containers of the
+// BASELINE workloads: those that span a block border; their partner is a median 12, at the 99th percentile 146 tokens
+// away).  The eight first look at the next kLinear tokens, 32 coalesced bytes of depth[] per step and a ballot; only a
+// container longer than that climbs the min tree (the group's first lane), from where the scan stopped.  Measured per
+// GiB minified, 180 000 such brackets: one THREAD per bracket walking the tree 93 us (every load instruction of such a
+// wave is 64 scattered 32-byte reads), sixteen lanes per bracket with one step of the scan and one level of the climb
+// per round trip 84 us -- the longest chain of one bracket, whatever the grid -- and with the rounds below ...
+#ifndef MSJ_MATCH_GRID
+#define MSJ_MATCH_GRID 32
+#endif
+#ifndef MSJ_MATCH_LINEAR
+#define MSJ_MATCH_LINEAR 256
+#endif
+constexpr uint32_t kLinear = MSJ_MATCH_LINEAR, kGroup = 8, kSteps = 8;  // 64 tokens per group and round
 __global__ __launch_bounds__(256) void match_brackets(const uint8_t *__restrict__ type, const uint32_t *__restrict__ opens,
                                                       const uint32_t *__restrict__ n_opens, const MinTree t,
-                                                      uint32_t *__restrict__ match) {
-    const uint32_t total = *n_opens;
-    for (uint64_t w = (uint64_t)blockIdx.x * 256u + threadIdx.x; w < total; w += (uint64_t)gridDim.x * 256u) {
-    const uint32_t i = opens[w];
-    const int target = t.lv[0][i];
-    uint32_t pos = i + 1u;
-    int lev = 0;
-    int v[8];
-    bool found = false;
-    for (;;) {  // climb: one aligned 32-byte read per level
-        const uint32_t g = pos >> kFanShift;
-        if (((uint64_t)g << kFanShift) >= t.cnt[lev]) break;
-        load_group(t, lev, g, v);
-        const uint32_t k = first_le(v, pos & kFanMask, target);
-        if (k < 8u) {
-            pos = (g << kFanShift) + k;
-            found = true;
-            break;
+                                                      uint32_t *__restrict__ match, uint64_t list_capacity) {
+    // one list per blockIdx.y (kSurvivorShards of them), the lane groups of its workgroups stride over it
+    const uint32_t total = n_opens[blockIdx.y * kSurvivorStride];
+    opens += (uint64_t)blockIdx.y * list_capacity;
+    const uint32_t lane = threadIdx.x & 63u, sub = lane & (kGroup - 1u), grp = lane / kGroup;
+    const uint32_t n = t.cnt[0];
+    constexpr uint32_t per_wave = 64u / kGroup;
+    const uint64_t wave0 = ((uint64_t)blockIdx.x * 4u + (threadIdx.x >> 6)) * per_wave, stride = (uint64_t)gridDim.x * 4u * per_wave;
+    for (uint64_t w0 = wave0; w0 < total; w0 += stride) {  // uniform per wave
+        const uint64_t w = w0 + grp;
+        const bool have = w < total;
+        const uint32_t i = have ? opens[w] : 0u;
+        const int target = have ? t.lv[0][i] : kNone;
+        uint32_t pos = i + 1u;
+        bool found = false;
+        // What bounds this kernel is the LONGEST dependent chain of loads of any one bracket (the root array of a 64 MiB
+        // document: 84 us, whatever the grid), so loads whose addresses do not depend on loaded data go out together:
+        // four steps of the linear scan per round, and every level of the climb at once.
+        for (uint32_t round = 0; round < kLinear / (kSteps * kGroup); round++) {  // uniform
+            int v4[kSteps];
+#pragma unroll
+            for (uint32_t q = 0; q < kSteps; q++) {
+                const uint32_t j = pos + q * kGroup + sub;
+                v4[q] = (have && !found && j < n) ? t.lv[0][j] : kNone;
+            }
+            uint32_t first = 0xFFFFFFFFu;
+#pragma unroll
+            for (uint32_t q = 0; q < kSteps; q++) {
+                const uint64_t hit = __ballot(v4[q] <= target && v4[q] != kNone);
+                const uint32_t mine = (uint32_t)(hit >> (kGroup * grp)) & ((1u << kGroup) - 1u);
+                if (mine != 0u && first == 0xFFFFFFFFu) first = q * kGroup + (uint32_t)__builtin_ctz(mine);
+            }
+            if (have && !found) {
+                if (first != 0xFFFFFFFFu) {
+                    pos += first;
+                    found = true;
+                } else {
+                    pos += kSteps * kGroup;
+                }
+            }
+            if (__ballot(have && !found && pos < n) == 0ull) break;  // uniform: every group of the wave is done
         }
-        if (lev + 1 == t.nlev) break;
-        pos = g + 1u;  // the rest of this group holds nothing: next node one level up
-        lev++;
-    }
-    if (!found) continue;
-    while (lev > 0) {  // descend: the first child that qualifies
-        lev--;
-        load_group(t, lev, pos, v);
-        pos = (pos << kFanShift) + first_le(v, 0u, target);
-    }
-    const uint32_t cj = type[pos];
-    if (cj == '}' || cj == ']') {
-        match[i] = pos;
-        match[pos] = i;
-    }
+        if (have && !found && pos < n && sub == 0u) {  // a long container: the tree, from where the scan stopped
+            // climb: the node visited at level k + 1 is (node at level k >> 3) + 1 whatever level k holds -- all levels'
+            // groups are requested at once, the first level with an entry <= target decides
+            uint32_t at[kMaxLevels];
+            int4 ga[kMaxLevels], gb[kMaxLevels];
+            uint32_t p = pos;
+#pragma unroll
+            for (int lev = 0; lev < kMaxLevels; lev++) {
+                at[lev] = p;
+                const uint32_t g = p >> kFanShift;
+                const bool in = lev < t.nlev && ((uint64_t)g << kFanShift) < t.cnt[lev];
+                ga[lev] = gb[lev] = make_int4(kNone, kNone, kNone, kNone);
+                if (in) {
+                    int v[8];
+                    load_group(t, lev, g, v);
+                    ga[lev] = make_int4(v[0], v[1], v[2], v[3]);
+                    gb[lev] = make_int4(v[4], v[5], v[6], v[7]);
+                }
+                p = g + 1u;
+            }
+            int lev_hit = -1;
+#pragma unroll
+            for (int lev = kMaxLevels - 1; lev >= 0; lev--) {
+                const int v[8] = {ga[lev].x, ga[lev].y, ga[lev].z, ga[lev].w, gb[lev].x, gb[lev].y, gb[lev].z, gb[lev].w};
+                const uint32_t k = first_le(v, at[lev] & kFanMask, target);
+                if (k < 8u) {  // the LOWEST level that qualifies wins (the loop runs downwards)
+                    lev_hit = lev;
+                    pos = ((at[lev] >> kFanShift) << kFanShift) + k;
+                }
+            }
+            if (lev_hit >= 0) {
+                found = true;
+                int v[8];
+                for (int lev = lev_hit; lev > 0;) {  // descend: the first child that qualifies
+                    lev--;
+                    load_group(t, lev, pos, v);
+                    pos = (pos << kFanShift) + first_le(v, 0u, target);
+                }
+            }
+        }
+        if (have && found && sub == 0u) {
+            const uint32_t cj = type[pos];
+            if (cj == '}' || cj == ']') {
+                match[i] = pos;
+                match[pos] = i;
+            }
+        }
     }
 }
 
@@ -672,7 +781,10 @@ static uint64_t head_words(uint64_t n) {  // ... + the same six words per run of
 extern "C" uint64_t msj_tokens_workspace_bytes(uint64_t n, int with_match) {
     // (matching: the min tree, 64 scratch words, the list of opening brackets left to the tree -- one uint32 per token
     // at most -- and its counter)
-    return (head_words(n) + (with_match ? tree_words(n) + 64 + n + 8 : 0)) * sizeof(int32_t);
+    const uint64_t nb = (n + msj_tokens::kBlock - 1) / msj_tokens::kBlock;
+    return (head_words(n) + (with_match ? tree_words(n) + 64 + msj_tokens::kSurvivorShards * msj_tokens::survivor_capacity(nb) +
+                                              (uint64_t)msj_tokens::kSurvivorShards * msj_tokens::kSurvivorStride
+                                        : 0)) * sizeof(int32_t);
 }
 
 // scan of the block aggregates (already in d_ws), depth of every token, bracket partners
@@ -688,7 +800,8 @@ static int launch_depth_passes(const uint32_t *d_idx, uint64_t n, uint8_t *d_typ
     int32_t *tree = d_ws + head_words(n);  // 32-byte aligned inside the workspace
     const bool want_match = d_match != nullptr && n > 0;
     uint32_t *opens = want_match ? reinterpret_cast<uint32_t *>(tree + tree_words(n) + 64) : nullptr;
-    uint32_t *survivors = want_match ? opens + n : nullptr;  // how many of them there are (zeroed by scan_blocks)
+    // ... kSurvivorShards lists, then their counters (zeroed by scan_blocks)
+    uint32_t *survivors = want_match ? opens + kSurvivorShards * survivor_capacity(nb) : nullptr;
     const uint32_t nsuper = (uint32_t)super_count(n);
     int32_t *super_agg = d_ws + block_words(n), *super_start = super_agg + 4 * (uint64_t)nsuper;
     uint32_t *super_open = reinterpret_cast<uint32_t *>(super_start + nsuper);
@@ -716,8 +829,6 @@ static int launch_depth_passes(const uint32_t *d_idx, uint64_t n, uint8_t *d_typ
     int32_t *l1 = want_match ? (t.nlev > 1 ? lvl[1] : tree) : nullptr;
     int32_t *l2 = want_match ? (t.nlev > 2 ? lvl[2] : tree + tree_words(n) + 8) : nullptr;
     int32_t *l3 = want_match ? (t.nlev > 3 ? lvl[3] : tree + tree_words(n) + 40) : nullptr;
-    if (want_match)  // padding entries of the tree levels must never qualify: 0x7F7F7F7F
-        (void)hipMemsetAsync(tree, 0x7F, (tree_words(n) + 64) * sizeof(int32_t), s);
     if (nb && want_match)
         hipLaunchKernelGGL(apply_depth<true>, dim3(nb), dim3(kThreads), 0, s, d_type, n, start, super_start, super_open, d_depth, l1, l2, l3,
                            open_start, opens, doc_agg, agg, o.d_prev, d_match, survivors);
@@ -726,12 +837,22 @@ static int launch_depth_passes(const uint32_t *d_idx, uint64_t n, uint8_t *d_typ
                            open_start, opens, doc_agg, agg, o.d_prev, d_match, survivors);
     if (nb) hipLaunchKernelGGL(min_max_depth, dim3(nb < kMinMaxGroups * 256u ? (nb + 255u) / 256u : kMinMaxGroups), dim3(256), 0, s, agg, nb, d_result);
     if (want_match) {
-        for (int k = 4; k < t.nlev; k++)
+        for (int k = 4; k < t.nlev && k < 6; k++)
             hipLaunchKernelGGL(build_level, dim3((t.cnt[k] + 255u) / 256u), dim3(256), 0, s, t.lv[k - 1], t.cnt[k - 1], lvl[k], t.cnt[k]);
+        if (t.nlev > 6) {
+            UpperLevels u;
+            for (int k = 0; k < kMaxLevels; k++) {
+                u.lv[k] = k < t.nlev ? const_cast<int32_t *>(t.lv[k]) : nullptr;
+                u.cnt[k] = k < t.nlev ? t.cnt[k] : 0u;
+            }
+            u.first = 6;
+            u.nlev = t.nlev;
+            hipLaunchKernelGGL(build_upper_levels, dim3(1), dim3(1024), 0, s, u);
+        }
         // match[] is complete for every container that closes inside a block (apply_depth<true> wrote the whole array);
-        // what is left -- a container that spans a block border, or lies outside the levels a block keeps -- walks the tree.
-        // The grid covers the worst case (every 8th token an unpaired opening bracket would need more: the kernel strides)
-        hipLaunchKernelGGL(match_brackets, dim3((uint32_t)((n / 8 + 255) / 256) + 1u), dim3(256), 0, s, d_type, opens, survivors, t, d_match);
+        // what is left -- a container that spans a block border, or lies outside the levels a block keeps -- walks the tree
+        // (the lane groups of 32 workgroups stride over each of the lists)
+        hipLaunchKernelGGL(match_brackets, dim3(MSJ_MATCH_GRID, kSurvivorShards), dim3(256), 0, s, d_type, opens, survivors, t, d_match, survivor_capacity(nb));
     }
     return (int)hipGetLastError();
 }
