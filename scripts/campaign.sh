@@ -1,7 +1,7 @@
 #!/bin/bash
 # After a change of the stage-1 kernel (round 4): GPU tests, every stress tool, rocprofv3 stats + PMC of the three BASELINE
 # workloads with the traffic entries for the new source hash, the ceilings table, density / size sweeps with same-box
-# ceilings, the default and the 8 GiB bench lines, the stitch overlap on one GPU.   scripts/r04_campaign.sh <tag> [part]
+# ceilings, the default and the 8 GiB bench lines, the stitch overlap on one GPU.   scripts/campaign.sh <tag> [part]
 cd "$(dirname "$0")/.."
 T=${1:-r04}; PART=${2:-all}; O=gpurun_out/$T; mkdir -p $O
 if [ $PART = all ] || [ $PART = 1 ]; then

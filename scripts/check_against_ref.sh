@@ -1,7 +1,7 @@
 #!/bin/bash
 # the token tests against another build of the library (a variant under test, or one without a fix: they must fail
 # there), then the product build against it on a 1 GiB workload:  scripts/check_against_ref.sh <lib.so> [workload] [pytest -k expression]
-cd "$GRAFT_REPO_ROOT"
+cd "$(dirname "$0")/.."
 REF=$(readlink -f "$1"); W=${2:-minified}; K=${3:-tile_groups or token_spans or stage2_prep or fixtures}
 echo "--- tests/test_tokens.py -k '$K' against $1:"
 python3 - "$REF" "$K" <<'PY'
@@ -17,4 +17,4 @@ sys.exit(pytest.main(["tests/test_tokens.py", "-x", "-q", "-m", "gpu", "-k", {sy
 r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True)
 print(r.stdout[-900:])
 PY
-bash scripts/prep_lib_ab.sh $W "$1" 2>&1 | grep -v amdgpu | cut -c1-110
+bash scripts/prep_ab.sh libs $W "$1" 2>&1 | grep -v amdgpu | cut -c1-110

@@ -2,7 +2,7 @@
 # PMC passes for msj_stage2_prep_device's kernels (run on the GPU box): scripts/prep_pmc.sh <tag> [workload] [--match]
 set -o pipefail
 TAG=${1:-prep}; shift
-cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
+REPO="$(cd "$(dirname "$0")/.." && pwd)"; cd /tmp && export TMPDIR=/tmp && cd "$REPO"
 OUT=gpurun_out/prof/$TAG
 mkdir -p "$OUT"
 i=0

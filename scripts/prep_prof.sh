@@ -2,7 +2,7 @@
 # kernel split of msj_stage2_prep_device on a 1 GiB workload (run on the GPU box): scripts/prep_prof.sh <tag> [workload] [--match]
 set -o pipefail
 TAG=${1:-prep}; shift
-cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
+REPO="$(cd "$(dirname "$0")/.." && pwd)"; cd /tmp && export TMPDIR=/tmp && cd "$REPO"
 OUT=gpurun_out/prof/$TAG
 mkdir -p "$OUT"
 timeout -k 10 300 python3 scripts/prep_prof.py "$@" | tee "$OUT/rate.txt" || exit 1

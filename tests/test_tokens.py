@@ -619,3 +619,75 @@ def test_prep_segments_of_one_shard(dev):
         assert depth0 == 0  # the document is closed at the end of the shard
     finally:
         assert L.msj_debug_set_segment_bytes(dev.ctx, 0xFFFF0000) == 0
+
+
+@pytest.mark.gpu
+def test_prep_segments_over_4gib(dev):
+    """config 5's own data through the rows marked "next".  A 4.5 GiB minified stream = one
+    shard of TWO uint32 segments (cut inside a unit, inside a container) -> msj_stage2_prep_segments: type, depth (carried
+    over the cut on the device), spans, partners of 0.9 G tokens, compared ON THE DEVICE with the definition by the
+    replication property: a unit is a complete document, so token j of repetition k has the unit's type / depth / flags,
+    the unit's end + k * unit_len (relative to its segment's first byte) and the unit's partner + k * unit_tokens
+    (relative to its segment's first token; a container cut by the segment border has no partner in either part)."""
+    import torch
+    from mojo_simdjson_amd import synth
+
+    oracle = helpers.load_oracle()
+    SEG = 0xFFFF0000
+    u = synth.workload("minified", 64 << 20)
+    b = u.tobytes()
+    L = len(b)
+    idx_u = _stage1(oracle, b)
+    nu = int(idx_u.size)
+    wt, wd, (final, _, _) = helpers.oracle_tokens(b, idx_u)
+    assert final == 0
+    wm = helpers.oracle_match(wt)
+    we, wf = helpers.oracle_token_spans(b, idx_u)
+    reps = SEG // L + 4
+    dv = dev.device
+    d_buf = torch.from_numpy(u).to(dv).repeat(reps)
+    total = int(d_buf.numel())
+    d_idx = torch.empty(nu * reps + 8, dtype=torch.int32, device=dv)
+    d_seg = torch.zeros(4 * 32, dtype=torch.uint8, device=dv)
+    cin, cout = dev.new_carry(), dev.new_carry()
+    rc, nseg = dev.shard(d_buf, total, d_idx, cin, cout, segments=d_seg, is_final=True, trailer_len=total)
+    assert rc == 0 and nseg == 2 and dev.fetch(cout).code == 0
+    table = np.frombuffer(d_seg.cpu().numpy().tobytes(), dtype=np.uint64).reshape(4, 4)[:2]
+    segs = [tuple(int(x) for x in row) for row in table]
+    c0, c1 = segs[0][3], segs[1][3]
+    assert c0 + c1 == nu * reps and segs[1][0] == SEG
+    offs, t, d, m, e, f, results = dev.stage2_prep_segments(d_buf, segs, d_idx, match=True)
+    assert (results[1].final_depth, results[1].min_depth) == (0, 0) and results[0].final_depth > 0  # the cut is inside a container
+    g_t = torch.from_numpy(wt).to(dv)
+    g_d = torch.from_numpy(wd).to(dv)
+    g_f = torch.from_numpy(wf).to(dv)
+    g_e = torch.from_numpy(we.astype(np.int64)).to(dv)
+    g_m = torch.from_numpy(wm.astype(np.int64)).to(dv)       # 0xFFFFFFFF = none
+    g_start = torch.from_numpy(idx_u.astype(np.int64)).to(dv)
+    g_next = torch.cat([g_start[1:], torch.tensor([L], dtype=torch.int64, device=dv)])  # where the token's extent ends
+    NONE = 0xFFFFFFFF
+    for k in range(reps):
+        J0 = k * nu  # global token index of the repetition's first token
+        for s, (bb, bl, ib, cnt) in enumerate(segs):
+            lo, hi = max(J0, ib), min(J0 + nu, ib + cnt)  # the repetition's tokens inside this segment
+            if lo >= hi:
+                continue
+            r0, r1 = lo - J0, hi - J0
+            o = offs[s] + (lo - ib)
+            where = f"repetition {k}, segment {s}"
+            assert torch.equal(t[o:o + hi - lo], g_t[r0:r1]), where
+            assert torch.equal(d[o:o + hi - lo], g_d[r0:r1]), where
+            # spans: tokens whose extent [start, next structural) lies inside the segment's bytes
+            start_g = g_start[r0:r1] + k * L
+            inside = (g_next[r0:r1] + k * L <= bb + bl) & (start_g >= bb)
+            got_f, got_e = f[o:o + hi - lo], e[o:o + hi - lo].to(torch.int64) & 0xFFFFFFFF
+            want_e = torch.where(g_e[r0:r1] != 0, g_e[r0:r1] + k * L - bb, torch.zeros_like(start_g))
+            assert torch.equal(got_f[inside], g_f[r0:r1][inside]) and torch.equal(got_e[inside], want_e[inside]), where
+            assert int((~inside).sum()) <= 1, where
+            # partners: global index of the unit's partner, local to the segment, none when it lies in the other one
+            pg = g_m[r0:r1] + J0
+            has = g_m[r0:r1] != NONE
+            same = has & (pg >= ib) & (pg < ib + cnt)
+            want_m = torch.where(same, pg - ib, torch.full_like(pg, NONE))
+            got_m = m[o:o + hi - lo].to(torch.int64) & 0xFFFFFFFF
+            assert torch.equal(got_m, want_m), where
