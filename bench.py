@@ -658,7 +658,7 @@ def main():
                           "exchange's bare latency; rank_skew_us = per step, max - min of that figure over the ranks = how "
                           "far apart the ranks' kernels end; standalone_ms = each rank's shard through msj_stage1_shard_device "
                           "with its exact carry, no exchange, no host turn (K steps after the timed window)"}
-        scaling_eff = {"value": round(total_len / dt_max / 1e9 / alone_rate, 4),
+        scaling_eff = {"value": round(total_len * args.steps / dt_max / 1e9 / alone_rate, 4),
                        "basis": f"whole-job GB/s / sum over the {world} ranks of (shard bytes / standalone_ms): the same "
                                 f"{args.gib_per_gpu:g} GiB/GPU shards on the same GPUs in the same process without the stitch "
                                 f"(= {world} x the N = 1 configuration at this size per GPU, measured here rather than assumed)",

@@ -41,8 +41,8 @@ rec = {
     "gib": c["gib"], "grid": c["grid"],
     "_note": "trivial kernels on the product's persistent grid, tile walk and store shape (whole-line non-temporal stores), "
              "400 back-to-back launches behind 400 untimed ones; GB/s of (bytes read + bytes written); the better of two "
-             "repetitions.  Ratios up to ~1:0.45 profit from the 256 MiB Infinity Cache absorbing part of the re-written "
-             "output on replay -- as the product's bench does.  bench.py measures the same on its own box when it can.",
+             "repetitions; the serial sum takes the best pure read and the pure write rate of a 4 N launch.  bench.py "
+             "measures the same on its own box when it can.",
     "read_plain": best("read_plain"), "read_nt": best("read_nt"),
     "by_workload": {w: by_workload(k) for w, k in mix.items()},
     "table": {k: v["settled"] for k, v in g.items()},
