@@ -4,7 +4,7 @@
 Byte soups (tests/stress.py's alphabets plus number- and string-heavy ones) through stage 1, then
 msj_stage2_prep_device with bracket matching, msj_tokens_device and msj_token_spans_device, each compared with
 the definitions in oracle/tokens_oracle.c token by token: type, depth, final / min / max depth, partner, span end,
-span flags.  Every third case runs with a lowered MSJ_SPANS_LDS_LIMIT-like stretch length (long strings) so that the
+span flags; every fourth case also in two or three chained pieces (the depth carried from call to call).  Every third case runs with a lowered MSJ_SPANS_LDS_LIMIT-like stretch length (long strings) so that the
 per-token path from global memory is taken too.
 usage: tests/stress_tokens.py [seconds] [seed]
 """
@@ -71,6 +71,24 @@ def main():
         assert np.array_equal(t2.cpu().numpy(), wt) and np.array_equal(d2.cpu().numpy(), wd), tag + ": msj_tokens_device"
         e2, f2 = dev.token_spans(d_buf, n, d_idx, k)
         assert np.array_equal(f2.cpu().numpy(), wf) and np.array_equal(e2.cpu().numpy().view(np.uint32), we), tag + ": msj_token_spans_device"
+        if cases % 4 == 1 and k >= 8:
+            # the same tokens handed over in two or three pieces (msj_stage2_prep_chain_device / msj_tokens_chain_device):
+            # depths and final / min / max of the whole, partners of each piece alone
+            cuts = sorted(set([0, k] + [int(c) // 4 * 4 for c in rng.integers(1, k, int(rng.integers(1, 3)))]))
+            prev = None
+            for a, b in zip(cuts[:-1], cuts[1:]):
+                buf = torch.zeros(24, dtype=torch.uint8, device=dev.device)
+                if cases % 8 == 1:
+                    tp, dp, _, mp, _, _ = dev.stage2_prep(d_buf, n, d_idx[a:], b - a, match=True, d_prev=prev, d_result=buf)
+                else:
+                    tp, dp, _, mp = dev.tokens(d_buf, n, d_idx[a:], b - a, match=True, d_result=buf, sync=False, d_prev=prev)
+                assert np.array_equal(tp.cpu().numpy(), wt[a:b]) and np.array_equal(dp.cpu().numpy(), wd[a:b]), f"{tag}: chained [{a}, {b})"
+                assert np.array_equal(mp.cpu().numpy().view(np.uint32), helpers.oracle_match(wt[a:b])), f"{tag}: chained partners [{a}, {b})"
+                prev = buf
+            from mojo_simdjson_amd import _lib
+
+            r = _lib.MsjTokensResult.from_buffer_copy(prev.cpu().numpy().tobytes())
+            assert (r.final_depth, r.min_depth, r.max_depth) == (final, mn, mx), f"{tag}: chained result {cuts}"
         cases += 1
         tokens += k
         if cases % 50 == 0:

@@ -430,9 +430,10 @@ def test_full_size_1gib_replication_property(torch_mod, dev, oracle, name):
 
 @pytest.mark.parametrize("kind,density", [(5, 0.4), (4, 0.5), (1, 2 / 3), (0, 1.0)])
 def test_full_size_density_extremes(torch_mod, dev, oracle, kind, density):
-    """BASELINE.json config 4's synthetic extremes at full size (1 GiB): [1234,...] d = 0.4 and [123,...]
-    d = 0.5 (one staging round of 16-bit slots per tile, or rounds when the alignment shift pushes a
-    tile over), [10,...] d = 0.67 and [[[[...]]]] d = 1.0 (staging in rounds over groups of lanes).
+    """BASELINE.json config 4's synthetic extremes at full size (1 GiB): [1234,...] d = 0.4 (two rounds of the 32-bit
+    staging slice per tile, kEmitStaged2), [123,...] d = 0.5 (every block holds 32 indices: all lanes on one LDS bank,
+    so the tile is left to the block-wise form), [10,...] d = 0.67 and [[[[...]]]] d = 1.0 (emit_dense: block by block,
+    the block's mask as EXEC, straight to the output).
     Same replication property as the workloads above: every unit ends with all carries at zero, so
     the expected index array is unit_idx + k * unit_len, compared index by index on the device."""
     torch = torch_mod
