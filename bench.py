@@ -310,6 +310,10 @@ def main():
                          "steps, so that the timed window sees the clocks the GPU holds under load instead of the "
                          "transient after idle (DESIGN.md section 4); 0 = none.  The K steps right after the warm-up "
                          "are timed too and reported as 'unsettled'")
+    ap.add_argument("--rehearse-sharded", action="store_true",
+                    help="N = 1 only: run the N > 1 code path -- process group over RCCL with one rank, msj_stage1_sharded_submit / "
+                         "_result with the library's own ncclAllGather, three submissions in flight, the per-rank fields of the "
+                         "line -- on one GPU (a rehearsal of the line the driver gets at N > 1, never the headline)")
     ap.add_argument("--no-ceilings", action="store_true",
                     help="skip the trivial HBM-ceiling kernels behind the verification (profiling passes: 6 000 launches less)")
     ap.add_argument("--no-emit", action="store_true",
@@ -335,10 +339,19 @@ def main():
     torch.cuda.set_device(dev_index)
     device = torch.device("cuda", dev_index)
     dist = None
-    if world > 1:
+    sharded = world > 1 or args.rehearse_sharded  # the N > 1 code path (always at N > 1)
+    if sharded:
         import torch.distributed as dist_mod
 
         dist = dist_mod
+        if world == 1:  # --rehearse-sharded from a plain command line: a one-rank group
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            if "MASTER_PORT" not in os.environ:
+                with socket.socket() as sk:
+                    sk.bind(("127.0.0.1", 0))
+                    os.environ["MASTER_PORT"] = str(sk.getsockname()[1])
+            os.environ.setdefault("RANK", "0")
+            os.environ.setdefault("WORLD_SIZE", "1")
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=device)
         else:
@@ -381,18 +394,18 @@ def main():
     d_seg = torch.zeros(n_seg_max * 32, dtype=torch.uint8, device=device)  # msj_segment table of the shard
     sh = None
 
-    if world == 1 and args.no_emit:
+    if not sharded and args.no_emit:
         d_zero = dev.new_carry()
 
         def step():
             dev.shard(d_shard, shard_len, d_idx, d_zero, d_res, is_final=True, no_emit=True, trailer_len=total_len,
                       flags=flags)
             return None
-    elif world == 1 and shard_len <= 0xFFFFFFFF:
+    elif not sharded and shard_len <= 0xFFFFFFFF:
         def step():
             dev.index(d_shard, d_idx, d_res, flags=flags, length=shard_len)
             return None
-    elif world == 1:
+    elif not sharded:
         # longer than one uint32 segment: the shard entry point chains segments on the device
         d_zero = dev.new_carry()
 
@@ -403,7 +416,7 @@ def main():
     else:
         from mojo_simdjson_amd.sharded import ShardedStage1
 
-        sh = ShardedStage1(dev, rank, world)
+        sh = ShardedStage1(dev, rank, world, always_gather=(world == 1))
         # the host that placed the shard had these bytes in host memory (they are part of
         # what it copied to the GPU): the 64-byte halo and the shard's first 4 KiB
         host_halo = d_alloc[:halo].cpu().numpy().tobytes() if halo else None
@@ -443,7 +456,7 @@ def main():
         ev1 = torch.cuda.Event(enable_timing=True)
         t0 = time.perf_counter()
         ev0.record()
-        if world == 1:
+        if not sharded:
             for _ in range(args.steps):
                 last = step()
         else:
@@ -501,7 +514,7 @@ def main():
 
     step_dist = None
     standalone = None
-    if world == 1:
+    if not sharded:
         n_dist = max(args.steps, 50)
         evs = [torch.cuda.Event(enable_timing=True) for _ in range(n_dist + 1)]
         evs[0].record()
@@ -532,7 +545,7 @@ def main():
         torch.cuda.synchronize()
         standalone = e0.elapsed_time(e1) / args.steps  # ms per pass of this rank's shard, nothing else on the GPU
         barrier()
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and not args.rehearse_sharded:
         torch.cuda.synchronize()
         cpu = cpu_baseline(unit)  # timed CPU baseline on rank 0 at N = 1 only; the GPU is idle meanwhile
         try:
@@ -541,7 +554,7 @@ def main():
             e2e = {"error": repr(exc)}
 
     # ---- result check (outside the timed region)
-    if world == 1:
+    if not sharded:
         res = dev.fetch(d_res)
         code, total_count = int(res.code), int(res.count)
         assert res.internal_error == 0
@@ -553,7 +566,7 @@ def main():
     reps = total_len // unit_len
     # (wrong results do not raise here: they go into the printed line as a failed verification, exit code 3)
     count_ok = code == 0 and total_count == unit_n * reps
-    local_count = int(res.count) if world > 1 else total_count
+    local_count = int(res.count) if sharded else total_count
 
     # ---- every index of this rank's shard, on the device, placed with the offsets the stitch returned
     #      (tests/replication.py; SURVEY.md section 8d config 5: device-side checker + 64-bit hash)
@@ -566,7 +579,7 @@ def main():
         # nothing in here raises before the all-gather below: a rank that found something wrong still takes part
         place_ok = (byte_base, cnt, nbytes) == (start, local_count, shard_len)
         segs = None
-        if world > 1 or shard_len > 0xFFFFFFFF:
+        if sharded or shard_len > 0xFFFFFFFF:
             nseg = -(-shard_len // 0xFFFF0000)
             table = np.frombuffer(d_seg.cpu().numpy().tobytes(), dtype=np.uint64).reshape(n_seg_max, 4)[:nseg]
             segs = [(int(r[0]), int(r[2]), int(r[3])) for r in table]
@@ -602,7 +615,7 @@ def main():
 
     # ---- the box's own ceilings for this launch's bytes (N = 1; the index array is verified: its buffer is scratch now)
     ceil_box = None
-    if world == 1 and rank == 0 and not args.no_emit and not args.no_ceilings:
+    if world == 1 and rank == 0 and not args.no_emit and not args.no_ceilings and not args.rehearse_sharded:
         try:
             ceil_box = same_box_ceilings(torch, device, d_shard, min(shard_len, 0xFFFF0000) // 4096 * 4096,
                                          int(total_count * (min(shard_len, 0xFFFF0000) / shard_len)), d_idx)
@@ -720,6 +733,8 @@ def main():
                 "dvfs_settle": (f"{settle_steps} untimed passes ({args.settle_ms:g} ms) between the {args.warmup} warm-up "
                                 f"steps and the {args.steps} timed ones; see 'unsettled'") if args.settle_ms > 0 else "none",
                 **({"diagnostic": "no-emit summary pass: not a stage-1 result"} if args.no_emit else {}),
+                **({"rehearsal": "--rehearse-sharded: the N > 1 code path on one rank (RCCL world 1): not the headline"}
+                   if args.rehearse_sharded else {}),
                 "sharding": "single GPU" if world == 1 else f"{world} byte-range shards of {shard_len_nominal} B "
                                                              f"({-(-shard_len_nominal // 0xFFFF0000)} uint32 segments each), cut inside units; "
                                                              f"one all-gather of 128 B per rank and step",
@@ -769,7 +784,7 @@ def main():
             }
         print(json.dumps(out), flush=True)
     verify_failed = verified.startswith("FAILED")
-    if world > 1:
+    if sharded:
         barrier()
         sh.close()  # the RCCL communicator of the stitch goes before torch's process group does
     dev.close()

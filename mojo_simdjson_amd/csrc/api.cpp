@@ -561,7 +561,7 @@ extern "C" {
 #endif
 // "... src:<hash>": the first 12 hex digits of the SHA-256 of the stage-1 kernel's sources (csrc/Makefile), so that
 // measurements kept beside the code (profiles/traffic.json) can say which kernel they were taken with
-const char *msj_version(void) { return "mojo-simdjson_amd stage1 0.3 (gfx950) src:" MSJ_SOURCE_HASH; }
+const char *msj_version(void) { return "mojo-simdjson_amd stage1 0.4 (gfx950) src:" MSJ_SOURCE_HASH; }
 
 uint32_t msj_tile_bytes(void) { return msj::kTileBytes; }
 

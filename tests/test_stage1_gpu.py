@@ -1158,6 +1158,29 @@ def test_sharded_result_does_not_drain_later_submissions(oracle):
           f"kernel end -> reports in {r['last_stitch_us']:.1f} us")
 
 
+def test_bench_line_of_the_sharded_path_rehearsed_on_one_rank():
+    """The line the driver gets at N > 1 -- process group over RCCL, msj_stage1_sharded_submit / _result with the
+    library's own ncclAllGather on the side stream, three submissions in flight, per-rank kernel-only time, stitch
+    latency, skew, standalone rate and efficiency, device-side verification with the stitched offsets -- produced by
+    `bench.py --rehearse-sharded` with ONE rank (all this box has): every field present and sane."""
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--rehearse-sharded", "--steps", "8", "--warmup", "2",
+                        "--settle-ms", "50", "--gib-per-gpu", "1"], capture_output=True, text=True, timeout=600, cwd=root)
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = json.loads([l for l in r.stdout.splitlines() if l.startswith('{"metric"')][-1])
+    cfg, st = line["config"], line["config"]["stitch"]
+    assert cfg["verified"] == "indices" and cfg["verify"]["mismatches"] == 0, cfg
+    assert st["exchange"] == "rccl" and st["rccl_ranks"] == 1 and st["reruns"] == 0 and st["in_flight"] == 3, st
+    assert st["allgather_rounds"] == 8 and len(st["kernel_only_ms"]) == 1 and 0.2 < st["kernel_only_ms"][0] < 1.0, st
+    assert 0.2 < st["standalone_ms"][0] < 1.0 and st["reports_in_us"]["min_rank_median"] > 0, st
+    eff = line["scaling_efficiency"]["value"]
+    assert 0.7 < eff < 1.1, line["scaling_efficiency"]
+    assert line["n_gpus"] == 1 and line["roofline"]["frac"] > 0.3 and "rehearsal" in cfg
+
+
 def _shared_gpu_worker(k, barrier, q):
     """One of several processes hammering the same GPU at once: every kernel then has only part
     of its persistent workgroups resident, which is what the deadlock-freedom argument is about."""
