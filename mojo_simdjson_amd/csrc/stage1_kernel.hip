@@ -285,10 +285,15 @@ struct Block {
 //       session (1 GiB, settled clocks, profiles/r03/load_shape_ab.txt) sparse input 0.221 -> 0.210 ms, pretty-printed
 //       0.286 -> 0.276, minified 0.354 -> 0.346, UTF-8-heavy 0.317 -> 0.308.  A bare read loop shows no difference
 //       between the two shapes (6.2 TB/s both, scripts/ubench/read_shape.hip): what the kernel gains is the texture
-//       path's time, which its stores and descriptor traffic share.  Non-temporal loads were tried on top (the bare
-//       loop reads 6.9 TB/s with them): no further gain on these workloads and 4-6 % LOST on the dense extremes
-//       (`[10,10,...` 0.759 -> 0.807 ms), so the loads are plain.
-template <bool kCoalesced>
+//       path's time, which its stores and descriptor traffic share.
+//   kNt (coalesced shape only): NON-TEMPORAL loads.  A bare loop reads 6.9 TB/s with them against 6.2.  Round 3 found
+//       no gain in the kernel and 4-6 % lost on the dense extremes; with the wave priorities in place (round 4, same
+//       box, alternating: profiles/r04/ab_nt_loads.txt) they are worth +2.5 .. +3.5 % on the minified workload, +2 .. +3 %
+//       on pretty-printed input, +1 % on UTF-8-heavy (instruction-bound), and still COST the dense extremes 3 - 6 %
+//       (d >= 0.5: the index stream is twice the input and more).  So the policy
+//       follows the data: a wave requests its next range's bytes non-temporally unless the range it has just computed
+//       was dense (worker_wave: more than kNtMaxIndices structurals in its two tiles).
+template <bool kCoalesced, bool kNt = false>
 __device__ __forceinline__ void load_block(const KernelArgs &a, const uint32_t tile, const uint32_t (&lane_off)[4],
                                            const uint32_t lane, Block &b) {
     // one launch covers < 2^32 bytes (kSegmentBytes), so offsets fit 32 bits
@@ -301,7 +306,8 @@ __device__ __forceinline__ void load_block(const KernelArgs &a, const uint32_t t
         const uint32_t off = lane_off[k] < lim ? lane_off[k] : lim;
         if (kCoalesced) {
             typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-            const u32x4 v = *reinterpret_cast<const u32x4 *>(base + off);
+            const u32x4 *src = reinterpret_cast<const u32x4 *>(base + off);
+            const u32x4 v = kNt ? __builtin_nontemporal_load(src) : *src;
             b.q[k] = make_uint4(v.x, v.y, v.z, v.w);
         } else {
             b.q[k] = *reinterpret_cast<const uint4 *>(base + off);
@@ -350,15 +356,19 @@ __device__ __forceinline__ void chunks_to_block(Block &b, const ChunkAddr &ca) {
 }
 
 // The kBatch tiles of this wave in the range that starts at tile `lo`.
+template <bool kNt>
 __device__ __forceinline__ void load_range(const KernelArgs &a, const uint32_t lo, const uint32_t wave,
                                            const uint32_t (&lane_off)[4], const uint32_t lane, Block (&blk)[kBatch]) {
     const uint32_t ntiles = a.ntiles;
 #pragma unroll
     for (uint32_t j = 0; j < kBatch; j++) {
         const uint32_t t = lo + kWaves * j + wave;
-        load_block<true>(a, t < ntiles ? t : ntiles - 1u, lane_off, lane, blk[j]);  // past the end: harmless re-read
+        load_block<true, kNt>(a, t < ntiles ? t : ntiles - 1u, lane_off, lane, blk[j]);  // past the end: harmless re-read
     }
 }
+// structurals in a wave's two tiles of a range (either in-string state) from which on the NEXT range's bytes are
+// requested with plain loads: 0.37 of the bytes (`[1234,` = 0.40 is neutral to -1 % non-temporally, `[123,` = 0.50 loses 3 %)
+constexpr uint32_t kNtMaxIndices = 3000;
 
 // Forces the wait for prefetched registers HERE (their loads were issued a whole
 // compute phase ago, so this costs nothing) instead of at their first use in the
@@ -1081,7 +1091,7 @@ __device__ __forceinline__ void worker_wave(const KernelArgs &a, Shared &sh, con
     uint32_t timeout = 0;
 
     Block blk[kBatch];
-    load_range(a, lo_cur, wave, lane_off, lane, blk);
+    load_range<true>(a, lo_cur, wave, lane_off, lane, blk);
 #pragma unroll
     for (uint32_t j = 0; j < kBatch; j++) touch_block(blk[j]);  // loop invariant: the bytes have arrived
     MSJ_RSTAMP(a.ntiles + 4096u + blockIdx.x, 3, tid == 0);  // first bytes in registers
@@ -1239,7 +1249,20 @@ __device__ __forceinline__ void worker_wave(const KernelArgs &a, Shared &sh, con
             }
             lo_next = (uint32_t)h;
         }
-        load_range(a, lo_next, wave, lane_off, lane, blk);
+        {
+            // the load policy follows the data (load_block): dense input -> plain loads
+            const uint32_t c0 = now[0].tile_cnt, c1 = now[1].tile_cnt;
+            const uint32_t n0 = (c0 & 0xFFFFu) > (c0 >> 16) ? (c0 & 0xFFFFu) : (c0 >> 16);
+            const uint32_t n1 = (c1 & 0xFFFFu) > (c1 >> 16) ? (c1 & 0xFFFFu) : (c1 >> 16);
+            // (the two markers keep the compiler from merging the branches: merged loads lose the non-temporal hint)
+            if (uniform32(n0 + n1) > kNtMaxIndices) {  // uniform
+                load_range<false>(a, lo_next, wave, lane_off, lane, blk);
+            } else {
+                asm volatile("; non-temporal range loads");
+                load_range<true>(a, lo_next, wave, lane_off, lane, blk);
+                asm volatile("; end of non-temporal range loads");
+            }
+        }
         MSJ_RSTAMP(lo_cur, 8, tid == 0);  // range aggregate published (real time)
         // ---- 3. emit the range parked kDefer iterations ago; hand the next range over in between
         if (have_old) {
