@@ -292,7 +292,7 @@ struct Block {
 //       on pretty-printed input, +1 % on UTF-8-heavy (instruction-bound), and still COST the dense extremes 3 - 6 %
 //       (d >= 0.5: the index stream is twice the input and more).  So the policy
 //       follows the data: a wave requests its next range's bytes non-temporally unless the range it has just computed
-//       was dense (worker_wave: more than kNtMaxIndices structurals in its two tiles).
+//       was dense (worker_wave: more than kNtMaxIndices structurals in its two tiles) or the launch is short (kNtMinTiles).
 template <bool kCoalesced, bool kNt = false>
 __device__ __forceinline__ void load_block(const KernelArgs &a, const uint32_t tile, const uint32_t (&lane_off)[4],
                                            const uint32_t lane, Block &b) {
@@ -369,6 +369,11 @@ __device__ __forceinline__ void load_range(const KernelArgs &a, const uint32_t l
 // structurals in a wave's two tiles of a range (either in-string state) from which on the NEXT range's bytes are
 // requested with plain loads: 0.37 of the bytes (`[1234,` = 0.40 is neutral to -1 % non-temporally, `[123,` = 0.50 loses 3 %)
 constexpr uint32_t kNtMaxIndices = 3000;
+// ... and launches shorter than this many tiles (0.375 GiB) use plain loads throughout: a short launch is mostly start-up
+// and tail, where a non-temporal load's bytes arrive later -- distinct 1/8 GiB inputs in turn (nothing to find in a
+// cache): 0.0507 ms plain, 0.0551 non-temporal; 1/4 GiB 0.0886 / 0.0912; 1/2 GiB 0.1673 / 0.1652; 1 GiB 0.3216 / 0.3126
+// (profiles/r04/small_launch_variants.txt)
+constexpr uint32_t kNtMinTiles = 98304;
 
 // Forces the wait for prefetched registers HERE (their loads were issued a whole
 // compute phase ago, so this costs nothing) instead of at their first use in the
@@ -1091,7 +1096,7 @@ __device__ __forceinline__ void worker_wave(const KernelArgs &a, Shared &sh, con
     uint32_t timeout = 0;
 
     Block blk[kBatch];
-    load_range<true>(a, lo_cur, wave, lane_off, lane, blk);
+    load_range<false>(a, lo_cur, wave, lane_off, lane, blk);  // the first range: plain (all waves ask at once: + 0.2 .. 0.7 %)
 #pragma unroll
     for (uint32_t j = 0; j < kBatch; j++) touch_block(blk[j]);  // loop invariant: the bytes have arrived
     MSJ_RSTAMP(a.ntiles + 4096u + blockIdx.x, 3, tid == 0);  // first bytes in registers
@@ -1255,7 +1260,7 @@ __device__ __forceinline__ void worker_wave(const KernelArgs &a, Shared &sh, con
             const uint32_t n0 = (c0 & 0xFFFFu) > (c0 >> 16) ? (c0 & 0xFFFFu) : (c0 >> 16);
             const uint32_t n1 = (c1 & 0xFFFFu) > (c1 >> 16) ? (c1 & 0xFFFFu) : (c1 >> 16);
             // (the two markers keep the compiler from merging the branches: merged loads lose the non-temporal hint)
-            if (uniform32(n0 + n1) > kNtMaxIndices) {  // uniform
+            if (uniform32(n0 + n1) > kNtMaxIndices || ntiles < kNtMinTiles) {  // uniform
                 load_range<false>(a, lo_next, wave, lane_off, lane, blk);
             } else {
                 asm volatile("; non-temporal range loads");

@@ -347,6 +347,20 @@ uint64_t msj_gen_extreme(uint8_t *out, uint64_t n, int kind) {
             out[p++] = ']';
             return p;
         }
+        case 6:    /* [123,1234,123,1234,...,7] : d = 4/9 = 0.444, NOT a whole number of indices per 64-byte block */
+        case 7: {  /* [12,123,12,123,...,7]     : d = 4/7 = 0.571 (2 341 structurals per tile: the block-wise emission) */
+            const char *pat = kind == 6 ? "123,1234," : "12,123,";
+            const uint64_t pl = strlen(pat);
+            uint64_t p = 0;
+            out[p++] = '[';
+            while (p + pl + 2 < n) {
+                memcpy(out + p, pat, pl);
+                p += pl;
+            }
+            out[p++] = '7';
+            out[p++] = ']';
+            return p;
+        }
         case 2:
             out[0] = '"';
             memset(out + 1, 'a', n - 2);

@@ -28,6 +28,7 @@ fi
 if [ $PART = all ] || [ $PART = 3 ]; then
 timeout -k 10 400 python tests/density_sweep.py > $O/density_sweep_$T.txt 2>&1; grep -v amdgpu $O/density_sweep_$T.txt | cut -c1-24,60-400
 bash scripts/size_sweep.sh mojo_simdjson_amd/libmsj_stage1.so 0.25 0.5 1 2 3.9 > $O/size_sweep_$T.txt 2>&1; tail -8 $O/size_sweep_$T.txt
+timeout -k 10 200 python scripts/small_launch.py 2>&1 | grep -v amdgpu > $O/small_launch_$T.txt; cat $O/small_launch_$T.txt
 timeout -k 10 300 python bench.py --steps 20 --warmup 5 > $O/bench_${T}_default.json 2> $O/bench.err; cut -c1-400 $O/bench_${T}_default.json
 timeout -k 10 200 python bench.py --gib-per-gpu 8 --steps 20 --warmup 5 --no-cpu-baseline > $O/bench_${T}_minified_8gib.json 2> $O/bench8.err; cut -c1-200 $O/bench_${T}_minified_8gib.json
 timeout -k 10 300 python scripts/stitch_overlap.py 1 8 2>&1 | grep "GiB" > $O/stitch_overlap.txt; cat $O/stitch_overlap.txt

@@ -17,6 +17,7 @@ timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/
 grep "\"metric\"" "$OUT/kt.log" | tail -1 > "$OUT/bench_line.json"
 ARGS="$ARGS --settle-ms 0 --no-ceilings"               # counters do not depend on the clocks: short runs for the PMC passes
 i=0
+[ -n "$PROF_SKIP_PMC" ] && { KEEP=gpurun_out/prof/$TAG; mkdir -p "$KEEP"; cp "$OUT/bench_line.json" "$KEEP/"; for f in "$OUT"/kt/*/*_kernel_stats.csv; do cp "$f" "$KEEP/kernel_stats.csv"; done; exit 0; }   # PROF_SKIP_PMC=1: the kernel-trace pass only
 for PMC in "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU" \
            "SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_LDS SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_INST_CYCLES_SALU" \
            "FETCH_SIZE GRBM_GUI_ACTIVE" \

@@ -23,7 +23,8 @@ CASES = [("spaces + one scalar", lambda: synth.extreme(UNIT, 3)), ("one giant st
          ("pretty, indent 8", lambda: synth.workload("pretty8", UNIT)), ("pretty, indent 4", lambda: synth.workload("pretty4", UNIT)),
          ("pretty, tab + CRLF", lambda: synth.workload("pretty_tab_crlf", UNIT)),
          ("pretty, indent 2", lambda: synth.workload("pretty2", UNIT)), ("UTF-8 heavy", lambda: synth.workload("utf8", UNIT)),
-         ("minified", lambda: synth.workload("minified", UNIT)), ("[1234,1234,...]", lambda: synth.extreme(UNIT, 5)), ("[123,123,...]", lambda: synth.extreme(UNIT, 4)),
+         ("minified", lambda: synth.workload("minified", UNIT)), ("[1234,1234,...]", lambda: synth.extreme(UNIT, 5)), ("[123,1234,123,...]", lambda: synth.extreme(UNIT, 6)),
+         ("[123,123,...]", lambda: synth.extreme(UNIT, 4)), ("[12,123,12,...]", lambda: synth.extreme(UNIT, 7)),
          ("[10,10,...]", lambda: synth.extreme(UNIT, 1)), ("[[[[...]]]]", lambda: synth.extreme(UNIT, 0))]
 
 
