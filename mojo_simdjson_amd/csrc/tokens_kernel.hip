@@ -296,7 +296,8 @@ __global__ __launch_bounds__(1024) void scan_blocks(const int32_t *__restrict__ 
 // of one depth alternate: between two closing ones the running depth must come back up through an opening one), so
 // per depth level of the block a bitmap of its opening brackets (LDS, one bit per token, kMatchLevels levels from 4
 // below the depth at the block's start) and a 64-bit summary of its non-empty words answer every closing bracket
-// with at most three LDS reads and no loop.  Both ends are written into an LDS copy of the block's match[] slice,
+// with at most three LDS reads and no loop.  Both ends are written into an LDS copy of the block's match[] slice
+// (never initialised: one bit per token in s_paired says which of its words hold a partner),
 // which leaves as one coalesced stream (no fill of match[] in front, no scattered writes); opening brackets nobody
 // claimed (their container ends in a later block, or lies outside the levels) go on the survivors' list, which
 // match_brackets resolves through the min tree as before.  1 GiB minified: of 8.6 M containers ... survive.
@@ -314,13 +315,13 @@ __global__ __launch_bounds__(kThreads) void apply_depth(const uint8_t *__restric
     __shared__ uint32_t bm[kMatch ? kMatchLevels : 1][kMatch ? kBlock / 32 : 1];  // opening brackets per level, one bit per token
     __shared__ unsigned long long bm_words[kMatch ? kMatchLevels : 1];              // ... and which of a level's 64 words are not empty
     __shared__ __attribute__((aligned(16))) uint32_t s_match[kMatch ? kBlock : 4];
+    __shared__ uint32_t s_paired[kMatch ? kBlock / 32 : 1];                         // one bit per token: it has a partner in s_match
     if (kMatch) {
         uint32_t *z = &bm[0][0];
 #pragma unroll
         for (int k = 0; k < kMatchLevels * (int)(kBlock / 32) / kThreads; k++) z[threadIdx.x + k * kThreads] = 0u;
         if (threadIdx.x < kMatchLevels) bm_words[threadIdx.x] = 0ull;
-        *reinterpret_cast<uint4 *>(&s_match[8 * threadIdx.x]) = make_uint4(~0u, ~0u, ~0u, ~0u);
-        *reinterpret_cast<uint4 *>(&s_match[8 * threadIdx.x + 4]) = make_uint4(~0u, ~0u, ~0u, ~0u);
+        if (threadIdx.x < kBlock / 32) s_paired[threadIdx.x] = 0u;  // s_match itself is not initialised: s_paired says which words count
     }
     __shared__ int wave_sum[kThreads / 64];
     __shared__ int wave_no[kThreads / 64];
@@ -373,47 +374,65 @@ __global__ __launch_bounds__(kThreads) void apply_depth(const uint8_t *__restric
     if (kMatch) {
         const int level0 = block_depth0 - kMatchBelow;
         const uint32_t t0 = 8u * threadIdx.x;  // this thread's first token inside the block
-        // (a) the opening brackets' bits (the zeroing above is behind the barrier that published wave_sum)
+        // (a) the opening brackets' bits (the zeroing above is behind the barrier that published wave_sum).  Brackets are
+        // few (4 % of the tokens of the minified workload are opening ones): a thread walks the SET BITS of its eight
+        // tokens' bracket masks, so a wave runs max-over-lanes(brackets per thread) rounds, not eight; the depth of
+        // token k follows from the masks (depth in front of the thread + opening - closing brackets below k).
+        uint32_t om = 0, cm = 0;
 #pragma unroll
         for (int k = 0; k < kPer; k++) {
-            const uint32_t lv = (uint32_t)(out[k] - level0);
-            if (d[k] > 0 && lv < (uint32_t)kMatchLevels && base + k < n) {
-                atomicOr(&bm[lv][(t0 + k) >> 5], 1u << ((t0 + k) & 31u));
-                atomicOr(&bm_words[lv], 1ull << ((t0 + k) >> 5));  // (b) ... and the level's words that hold a bit
+            if (base + k < n) {
+                om |= d[k] > 0 ? 1u << k : 0u;
+                cm |= d[k] < 0 ? 1u << k : 0u;
+            }
+        }
+        const int before0 = out[0] + (d[0] < 0 ? 1 : 0);  // the running depth in front of this thread's first token
+        for (uint32_t rem = om; __ballot(rem != 0u) != 0ull;) {  // uniform
+            if (rem != 0u) {
+                const uint32_t k = (uint32_t)__builtin_ctz(rem), below = (1u << k) - 1u;
+                rem &= rem - 1u;
+                const uint32_t lv = (uint32_t)(before0 + (int)__builtin_popcount(om & below) - (int)__builtin_popcount(cm & below) - level0);
+                if (lv < (uint32_t)kMatchLevels) {
+                    atomicOr(&bm[lv][(t0 + k) >> 5], 1u << ((t0 + k) & 31u));
+                    atomicOr(&bm_words[lv], 1ull << ((t0 + k) >> 5));  // (b) ... and the level's words that hold a bit
+                }
             }
         }
         __syncthreads();
         // (c) every closing bracket looks for the most recent opening one of its level
-#pragma unroll
-        for (int k = 0; k < kPer; k++) {
-            const uint32_t lv = (uint32_t)(out[k] - level0);
-            if (d[k] < 0 && lv < (uint32_t)kMatchLevels && base + k < n) {
-                const uint32_t t = t0 + k, w = t >> 5;
-                uint32_t m = bm[lv][w] & ((1u << (t & 31u)) - 1u);
-                uint32_t wi = w;
-                if (m == 0u) {
-                    const uint64_t nz = bm_words[lv] & ((1ull << w) - 1ull);
-                    if (nz != 0ull) {
-                        wi = 63u - (uint32_t)__clzll((long long)nz);
-                        m = bm[lv][wi];
+        for (uint32_t rem = cm; __ballot(rem != 0u) != 0ull;) {  // uniform
+            if (rem != 0u) {
+                const uint32_t k = (uint32_t)__builtin_ctz(rem), below = (1u << k) - 1u;
+                rem &= rem - 1u;
+                // a closing bracket sits at the depth of its container: one below the running depth in front of it
+                const uint32_t lv = (uint32_t)(before0 + (int)__builtin_popcount(om & below) - (int)__builtin_popcount(cm & below) - 1 - level0);
+                if (lv < (uint32_t)kMatchLevels) {
+                    const uint32_t t = t0 + k, w = t >> 5;
+                    uint32_t m = bm[lv][w] & ((1u << (t & 31u)) - 1u);
+                    uint32_t wi = w;
+                    if (m == 0u) {
+                        const uint64_t nz = bm_words[lv] & ((1ull << w) - 1ull);
+                        if (nz != 0ull) {
+                            wi = 63u - (uint32_t)__clzll((long long)nz);
+                            m = bm[lv][wi];
+                        }
                     }
-                }
-                if (m != 0u) {
-                    const uint32_t i = 32u * wi + 31u - (uint32_t)__clz((int)m);
-                    const uint32_t blk0 = blockIdx.x * kBlock;  // token indices are < 2^31
-                    s_match[t] = blk0 + i;
-                    s_match[i] = blk0 + t;
+                    if (m != 0u) {
+                        const uint32_t i = 32u * wi + 31u - (uint32_t)__clz((int)m);
+                        const uint32_t blk0 = blockIdx.x * kBlock;  // token indices are < 2^31
+                        s_match[t] = blk0 + i;
+                        s_match[i] = blk0 + t;
+                        atomicOr(&s_paired[w], 1u << (t & 31u));
+                        atomicOr(&s_paired[wi], 1u << (i & 31u));
+                    }
                 }
             }
         }
         __syncthreads();
         // (d) the opening brackets nobody claimed: to the list match_brackets works through (any order)
-        uint32_t mine = 0;
-        const uint4 ma = *reinterpret_cast<const uint4 *>(&s_match[t0]);
-        const uint4 mb = *reinterpret_cast<const uint4 *>(&s_match[t0 + 4]);
-        const uint32_t mk[8] = {ma.x, ma.y, ma.z, ma.w, mb.x, mb.y, mb.z, mb.w};
-#pragma unroll
-        for (int k = 0; k < kPer; k++) mine += (d[k] > 0 && mk[k] == ~0u && base + k < n) ? 1u : 0u;
+        // (the thread's eight tokens are one byte of a word of s_paired)
+        surv_mask = om & ~(s_paired[t0 >> 5] >> (t0 & 31u));
+        const uint32_t mine = (uint32_t)__builtin_popcount(surv_mask);
         // the slot is DRAWN here (one returning atomic per wave that has any) and USED at the very end of the kernel: its
         // round trip overlaps the stores of match[] and depth[] and the aggregates below
         surv_any = __ballot(mine != 0u) != 0ull;  // uniform per wave
@@ -422,38 +441,46 @@ __global__ __launch_bounds__(kThreads) void apply_depth(const uint8_t *__restric
             if (lane == 63) surv_slot = atomicAdd(survivors + (blockIdx.x % kSurvivorShards) * kSurvivorStride, surv_incl);
         }
         surv_mine = mine;
-#pragma unroll
-        for (int k = 0; k < kPer; k++) surv_mask |= (d[k] > 0 && mk[k] == ~0u && base + k < n) ? 1u << k : 0u;
         // (e) the block's slice of match[]: 1 KiB contiguous per store instruction, like the depths below
         const uint64_t wb = (uint64_t)blockIdx.x * kBlock + (uint64_t)wave * 512u;
         if (wb + 512u <= n) {  // uniform per wave
             typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-            const uint4 a = *reinterpret_cast<const uint4 *>(&s_match[wave * 512 + 4 * lane]);
-            const uint4 b = *reinterpret_cast<const uint4 *>(&s_match[wave * 512 + 256 + 4 * lane]);
+            // tokens 4 lane .. 4 lane + 3 of the wave's first and second half: a nibble of s_paired each
+            const uint32_t q0 = wave * 512u + 4u * lane, q1 = q0 + 256u;
+            uint4 a = *reinterpret_cast<const uint4 *>(&s_match[q0]);
+            uint4 b = *reinterpret_cast<const uint4 *>(&s_match[q1]);
+            const uint32_t pa = s_paired[q0 >> 5] >> (q0 & 31u), pb = s_paired[q1 >> 5] >> (q1 & 31u);
+            a.x = (pa & 1u) ? a.x : ~0u; a.y = (pa & 2u) ? a.y : ~0u; a.z = (pa & 4u) ? a.z : ~0u; a.w = (pa & 8u) ? a.w : ~0u;
+            b.x = (pb & 1u) ? b.x : ~0u; b.y = (pb & 2u) ? b.y : ~0u; b.z = (pb & 4u) ? b.z : ~0u; b.w = (pb & 8u) ? b.w : ~0u;
             const u32x4 o0 = {a.x, a.y, a.z, a.w}, o1 = {b.x, b.y, b.z, b.w};
             __builtin_nontemporal_store(o0, reinterpret_cast<u32x4 *>(match + wb + 4 * lane));
             __builtin_nontemporal_store(o1, reinterpret_cast<u32x4 *>(match + wb + 256 + 4 * lane));
         } else {
+            const uint32_t pm = s_paired[t0 >> 5] >> (t0 & 31u);
 #pragma unroll
             for (int k = 0; k < kPer; k++)
-                if (base + k < n) match[base + k] = mk[k];
+                if (base + k < n) match[base + k] = ((pm >> k) & 1u) ? s_match[t0 + k] : ~0u;
         }
     }
     // The depths leave through LDS, so that each store instruction of a wave writes 1 KiB contiguous instead of 16 bytes
     // per lane at a 32-byte stride (a thread's eight tokens): msj_stage2_prep_device 0.865 -> 0.842 ms per GiB minified,
     // same box, alternating (plain instead of non-temporal stores: 0.90).  Write-once stream, far larger than L2 / MALL:
     // non-temporal stores.
+    // (Round 4, measured with rocprofv3 on one box, alternating: letting the wave's quarter of s_match double as this
+    // staging slice -- 13 KiB of LDS per workgroup instead of 21, eight resident workgroups per CU instead of seven --
+    // changes nothing, 473 / 489 us either way; FEWER resident workgroups cost: six 533 us, four 616, three 752.)
     __shared__ __attribute__((aligned(16))) int s_out[kThreads / 64][512];
+    int *const stage = &s_out[wave][0];
     const uint64_t wave_base = (uint64_t)blockIdx.x * kBlock + (uint64_t)wave * 512u;
     if (wave_base + 512u <= n) {  // uniform per wave
         typedef int i32x4 __attribute__((ext_vector_type(4)));
-        *reinterpret_cast<int4 *>(&s_out[wave][8 * lane]) = make_int4(out[0], out[1], out[2], out[3]);
-        *reinterpret_cast<int4 *>(&s_out[wave][8 * lane + 4]) = make_int4(out[4], out[5], out[6], out[7]);
+        *reinterpret_cast<int4 *>(&stage[8 * lane]) = make_int4(out[0], out[1], out[2], out[3]);
+        *reinterpret_cast<int4 *>(&stage[8 * lane + 4]) = make_int4(out[4], out[5], out[6], out[7]);
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        const int4 a = *reinterpret_cast<const int4 *>(&s_out[wave][4 * lane]);
-        const int4 b = *reinterpret_cast<const int4 *>(&s_out[wave][256 + 4 * lane]);
+        const int4 a = *reinterpret_cast<const int4 *>(&stage[4 * lane]);
+        const int4 b = *reinterpret_cast<const int4 *>(&stage[256 + 4 * lane]);
         const i32x4 o0 = {a.x, a.y, a.z, a.w}, o1 = {b.x, b.y, b.z, b.w};
         __builtin_nontemporal_store(o0, reinterpret_cast<i32x4 *>(depth + wave_base + 4 * lane));
         __builtin_nontemporal_store(o1, reinterpret_cast<i32x4 *>(depth + wave_base + 256 + 4 * lane));

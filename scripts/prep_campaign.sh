@@ -1,22 +1,11 @@
-#!/bin/bash
-# round 4: the token rows -- tests, the uint32-edge test, msj_stage2_prep_device with bracket partners: rate and split
-cd "$(dirname "$0")/.."
-out=gpurun_out/r04f
-mkdir -p $out
-python -m pytest tests/test_tokens.py tests/test_documents.py -x -q -m gpu > $out/gpu_tests_tokens.txt 2>&1 || { tail -40 $out/gpu_tests_tokens.txt; exit 1; }
-tail -3 $out/gpu_tests_tokens.txt
-python -m pytest tests/test_stage1_gpu.py -x -q -m gpu -k "uint32_edge" > $out/gpu_tests_edge.txt 2>&1 || { tail -40 $out/gpu_tests_edge.txt; exit 1; }
-tail -3 $out/gpu_tests_edge.txt
+out=gpurun_out/r04n; mkdir -p $out
+timeout -k 10 600 python -m pytest tests/test_tokens.py tests/test_documents.py -x -q -m gpu > $out/gpu_tests_tokens.txt 2>&1 || { tail -40 $out/gpu_tests_tokens.txt; exit 1; }
+tail -2 $out/gpu_tests_tokens.txt
+timeout -k 10 150 python tests/stress_tokens.py 60 304 > $out/stress_tokens_304.txt 2>&1; tail -1 $out/stress_tokens_304.txt
+timeout -k 10 120 python tests/stress_documents.py 30 305 > $out/stress_documents_305.txt 2>&1; tail -1 $out/stress_documents_305.txt
 for w in minified utf8 pretty4; do
-  python scripts/prep_prof.py $w > $out/prep_$w.txt 2>&1; tail -1 $out/prep_$w.txt
-  python scripts/prep_prof.py $w --match > $out/prep_match_$w.txt 2>&1; tail -1 $out/prep_match_$w.txt
+  python scripts/prep_prof.py $w 2>&1 | grep -v amdgpu | tail -1 | tee -a $out/rates.txt
+  python scripts/prep_prof.py $w --match 2>&1 | grep -v amdgpu | tail -1 | tee -a $out/rates.txt
 done
-cd /tmp && export TMPDIR=/tmp && cd - > /dev/null
-rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prep_kt -- python3 scripts/prep_prof.py minified --match --iters 100 --warm 50 > /tmp/prep_kt.log 2>&1
-python3 - <<'PY' > gpurun_out/r04f/prep_match_minified_split.txt
-import csv, glob
-for f in glob.glob('/tmp/prep_kt/**/*kernel_stats.csv', recursive=True):
-    for r in csv.DictReader(open(f)):
-        print(f"{r['Name'][:70]:70s} calls={r['Calls']:>5s} avg_us={float(r['AverageNs'])/1e3:9.1f} total_ms={float(r['TotalDurationNs'])/1e6:9.2f}")
-PY
-cat gpurun_out/r04f/prep_match_minified_split.txt
+MATCH=1 bash scripts/prep_ab.sh libs minified variants/cur.so 2>&1 | grep -v amdgpu | tee $out/ab_match.txt
+bash scripts/prep_split.sh minified "" 2>&1 | grep -E "^==|msj_tokens" | tee $out/split.txt
