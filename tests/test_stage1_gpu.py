@@ -214,14 +214,15 @@ def test_quiet_tiles(oracle):
 def test_density_extremes(oracle):
     from mojo_simdjson_amd import synth
 
-    # kinds 0/1/4/5: more than 1 020 structurals per tile (block-wise dense emission: 4 096, 2 731, 2 048, 1 638 per tile)
-    # 2/3: none
-    for kind in range(6):
+    # kinds 0/1/4/5/6/7: more than 1 020 structurals per tile (4 096, 2 731, 2 048, 1 638, 1 820, 2 341 per tile; 6 and 7
+    # with a number of indices per 64-byte block that is not whole: two-round staging near its limit / block-wise
+    # emission with a different count in every block); 2/3: none
+    for kind in range(8):
         for n in (3 * TILE + 1000, 40 * TILE + 123):
             d = synth.extreme(n, kind).tobytes()
             assert_matches_oracle(oracle, d, f"extreme kind {kind} len {n}")
     # density changing from tile to tile: every emission path next to every other one
-    parts = [synth.extreme(TILE + 7 * k, k % 6).tobytes() for k in range(24)]
+    parts = [synth.extreme(TILE + 7 * k, k % 8).tobytes() for k in range(32)]
     assert_matches_oracle(oracle, b" ".join(parts), "mixed densities")
 
 
@@ -428,12 +429,13 @@ def test_full_size_1gib_replication_property(torch_mod, dev, oracle, name):
 
 
 
-@pytest.mark.parametrize("kind,density", [(5, 0.4), (4, 0.5), (1, 2 / 3), (0, 1.0)])
+@pytest.mark.parametrize("kind,density", [(5, 0.4), (6, 4 / 9), (4, 0.5), (7, 4 / 7), (1, 2 / 3), (0, 1.0)])
 def test_full_size_density_extremes(torch_mod, dev, oracle, kind, density):
     """BASELINE.json config 4's synthetic extremes at full size (1 GiB): [1234,...] d = 0.4 (two rounds of the 32-bit
-    staging slice per tile, kEmitStaged2), [123,...] d = 0.5 (every block holds 32 indices: all lanes on one LDS bank,
-    so the tile is left to the block-wise form), [10,...] d = 0.67 and [[[[...]]]] d = 1.0 (emit_dense: block by block,
-    the block's mask as EXEC, straight to the output).
+    staging slice per tile, kEmitStaged2), [123,1234,...] d = 0.44 (the same with 1 820 of its 2 051 slots used),
+    [123,...] d = 0.5 (every block holds 32 indices: all lanes on one LDS bank, so the tile is left to the block-wise
+    form), [12,123,...] d = 0.57, [10,...] d = 0.67 and [[[[...]]]] d = 1.0 (emit_dense: block by block, the block's
+    mask as EXEC, straight to the output).
     Same replication property as the workloads above: every unit ends with all carries at zero, so
     the expected index array is unit_idx + k * unit_len, compared index by index on the device."""
     torch = torch_mod
