@@ -176,7 +176,7 @@ def end_to_end(unit, lib, n_bytes=256 << 20, runs=5):
                     "call, median of the runs; NOT the metric (inputs of `value` are resident in HBM)"}
 
 
-def same_box_ceilings(torch_mod, device, d_in, n_bytes, structurals, d_scratch, grid=None):
+def same_box_ceilings(torch_mod, device, d_in, n_bytes, structurals, d_scratch, grid=None, brief=False):
     """What the memory system of THIS box gives this launch's bytes when nothing is computed: the trivial kernels of
     scripts/ubench/hbm_ceilings.hip (built as scripts/bin/libhbm_ceilings.so by __graft_entry__.build()) on the
     product kernel's persistent grid, the product's tile walk and store shape, in the same process right behind the
@@ -184,7 +184,10 @@ def same_box_ceilings(torch_mod, device, d_in, n_bytes, structurals, d_scratch, 
     Reads the shard once per launch; writes ceil(4 S / tiles) bytes per tile, rounded UP to whole 128-byte lines.
     Returns GB/s per variant (settled: 300 untimed launches, then the faster of two windows of 300 timed ones) or None.
     `same_mix_best` is the fastest way found to move the launch's bytes without computing anything: the best of four
-    trivial read + write kernels and of (best pure read time + best pure write time)."""
+    trivial read + write kernels and of (best pure read time + best pure write time).
+    `best_trivial_kernel` is the fastest trivial kernel that EXISTS for these bytes (no serial-sum model).
+    brief=True (the sub-records of `other_configs`): non-temporal read + the two non-temporal mixes, 150 launches per
+    window -- a kernel that exists for the row, in a second of box time."""
     import ctypes
 
     path = os.path.join(ROOT, "scripts", "bin", "libhbm_ceilings.so")
@@ -201,28 +204,39 @@ def same_box_ceilings(torch_mod, device, d_in, n_bytes, structurals, d_scratch, 
     grid = grid or 4 * torch_mod.cuda.get_device_properties(device).multi_processor_count
     sink = torch_mod.zeros(64, dtype=torch_mod.uint8, device=device)
     stream = ctypes.c_void_p(torch_mod.cuda.current_stream(device).cuda_stream)
-    out = {"w_per_r": round(wquads * 16 / 4096, 4), "grid": grid, "launches": 300}
+    nl = 150 if brief else 300
+    out = {"w_per_r": round(wquads * 16 / 4096, 4), "grid": grid, "launches": nl}
     n_rd, n_wr = ntiles * 4096, ntiles * wquads * 16
 
     def ms(wq, policy):
         def go(reps):
             rc = L.msj_ceiling_launch(d_in.data_ptr(), d_scratch.data_ptr(), sink.data_ptr(), ntiles, wq, policy, grid, reps, stream)
             assert rc == 0, rc
-        go(300)
+        go(nl)
         best = None
-        for _ in range(2):  # a ceiling is the BEST the box does: the faster of two windows of 300 launches
+        for _ in range(2):  # a ceiling is the BEST the box does: the faster of two windows of `nl` launches
             e0, e1 = torch_mod.cuda.Event(enable_timing=True), torch_mod.cuda.Event(enable_timing=True)
             e0.record()
-            go(300)
+            go(nl)
             e1.record()
             torch_mod.cuda.synchronize()
-            t = e0.elapsed_time(e1) / 300
+            t = e0.elapsed_time(e1) / nl
             best = t if best is None else min(best, t)
         return best
 
     def gbps(nbytes, t_ms):
         return round(nbytes / (t_ms * 1e-3) / 1e9, 1)
 
+    if brief:
+        out["read_nt"] = gbps(n_rd, ms(0, 1))
+        if wquads:
+            t_mix = {"same_mix_nt_nt": ms(wquads, 1), "same_mix_deferred_nt_nt": ms(wquads, 9)}
+            for k, t in t_mix.items():
+                out[k] = gbps(n_rd + n_wr, t)
+            out["best_trivial_kernel"] = gbps(n_rd + n_wr, min(t_mix.values()))
+        else:
+            out["best_trivial_kernel"] = out["read_nt"]
+        return out
     t_read = {"read_plain": ms(0, 0), "read_nt": ms(0, 1)}
     for k, t in t_read.items():
         out[k] = gbps(n_rd, t)
@@ -255,9 +269,118 @@ def same_box_ceilings(torch_mod, device, d_in, n_bytes, structurals, d_scratch, 
         out["serial_sum_of_pure_streams"] = gbps(n_rd + n_wr, t_sum)
         out["same_mix_ms"] = round(min(min(t_mix.values()), t_sum), 4)
         out["same_mix_best"] = gbps(n_rd + n_wr, min(min(t_mix.values()), t_sum))
+        out["best_trivial_kernel"] = gbps(n_rd + n_wr, min(t_mix.values()))  # a kernel that exists (no model)
     else:
         out["same_mix_best"] = max(out["read_plain"], out["read_nt"])
+        out["best_trivial_kernel"] = out["same_mix_best"]
     return out
+
+
+# BASELINE.json configs 3 and 4 (and config 4's synthetic extremes) as sub-records of the default N = 1 line: the same
+# protocol as the headline (W warm-up steps, the K steps right behind them as `unsettled`, `settle_ms` of untimed
+# passes, K timed steps between synchronisations, HIP events on the launch stream for the kernel time), every index
+# verified on the device afterwards against the oracle's unit indices (checker only, outside every timed window).
+OTHER_CONFIGS = [
+    ("utf8", "BASELINE config 3: 1 GiB UTF-8-heavy JSON (multi-byte code points + escaped strings), UTF-8 validation on",
+     lambda: synth.workload("utf8", UNIT_BYTES)),
+    ("pretty4", "BASELINE config 4: 1 GiB pretty-printed JSON, indent 4",
+     lambda: synth.workload("pretty4", UNIT_BYTES)),
+    ("d0_blanks", "config 4 extreme d ~ 0: blanks + one scalar per 64 MiB unit",
+     lambda: synth.extreme(UNIT_BYTES - 52, 3)),
+    ("d0.5_[123,", "config 4 extreme d = 0.5: [123,123,...]",
+     lambda: synth.extreme(UNIT_BYTES - 52, 4)),
+    ("d1.0_[[[[", "config 4 extreme d = 1.0: [[[[...]]]]",
+     lambda: synth.extreme(UNIT_BYTES - 52, 0)),
+]
+
+
+def other_config_record(dev, device, name, what, gen, steps, warmup, settle_ms, flags, with_ceilings):
+    """One sub-record of `other_configs` (N = 1 only): a 1 GiB stream of the workload's unit, resident in HBM."""
+    from tests import replication
+
+    unit = gen()
+    unit_len = int(unit.size)
+    u_idx = unit_indices(unit)  # the oracle's indices of one unit: the expected result (checker only)
+    unit_n = int(u_idx.size)
+    d_unit = torch.from_numpy(unit).to(device)
+    reps = (1 << 30) // unit_len
+    d_buf = d_unit.repeat(reps)
+    total = reps * unit_len
+    d_idx = torch.empty(unit_n * reps + 1024, dtype=torch.int32, device=device)
+    d_res = dev.new_carry()
+    assert d_buf.data_ptr() % 16 == 0
+
+    def step():
+        dev.index(d_buf, d_idx, d_res, flags=flags, length=total)
+
+    def window(k):
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        t0 = time.perf_counter()
+        e0.record()
+        for _ in range(k):
+            step()
+        e1.record()
+        torch.cuda.synchronize()
+        return time.perf_counter() - t0, e0.elapsed_time(e1)
+
+    for _ in range(warmup):
+        step()
+    u_dt, u_ev = window(steps)
+    settle_steps = 0
+    t_end = time.perf_counter() + settle_ms * 1e-3
+    while settle_ms > 0 and time.perf_counter() < t_end:
+        for _ in range(25):
+            step()
+        settle_steps += 25
+        torch.cuda.synchronize()
+    dt, ev = window(steps)
+    res = dev.fetch(d_res)
+    count = int(res.count)
+    alg = total + 4 * count
+    k_ms = ev / steps
+    achieved = alg / (k_ms * 1e-3) / 1e9
+    # ---- every index, on the device (tests/replication.py), + the trailer + the closed-form hash
+    d_uidx = torch.from_numpy(u_idx.astype(np.int64)).to(device)
+    bad, h = replication.check_shard(torch, d_idx, min(count, unit_n * reps), d_uidx, unit_len, 0, 0, None)
+    tail = (d_idx[count:count + 3].to(torch.int64) & 0xFFFFFFFF).tolist() if count + 3 <= d_idx.numel() else None
+    ok = (int(res.code) == 0 and res.internal_error == 0 and count == unit_n * reps and bad == 0
+          and h == replication.stream_hash(u_idx, unit_len, reps) and tail == [total & 0xFFFFFFFF, total & 0xFFFFFFFF, 0]
+          and int(res.bytes) == total)
+    verified = "indices" if ok else (f"FAILED (code {int(res.code)}, count {count} want {unit_n * reps}, mismatches {bad}, "
+                                     f"trailer {tail})")
+    del d_uidx
+    rec = {
+        "workload": f"1 GiB/GPU synthetic {name} (unit {unit_len} B x {reps}); {what}",
+        "bytes_total": total, "structurals_total": count, "density": round(count / total, 5),
+        "utf8_validation": not (flags & 2),
+        "ms_per_step": round(dt / steps * 1e3, 4),
+        "value": round(total * steps / dt / 1e9, 2), "unit": "GB/s",
+        "untimed_passes_before_window": warmup + steps + settle_steps,
+        "verified": verified,
+        "utf8_error": int(res.utf8_error),
+        "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                     "frac": round(achieved / HBM_PEAK_GBPS, 4),
+                     "frac_unsettled": round(alg / (u_ev / steps * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
+                     "kernel": "stage1_kernel", "kernel_ms": round(k_ms, 4), "kernel_ms_unsettled": round(u_ev / steps, 4),
+                     "algorithmic_bytes_per_launch": alg, "traffic": None},
+    }
+    if with_ceilings:
+        try:
+            ntiles = total // 4096
+            wquads = min(1024, -(-(-(-4 * count // ntiles)) // 128) * 8)
+            need = ntiles * wquads * 16
+            d_scratch = d_idx if d_idx.numel() * 4 >= need else torch.empty(need, dtype=torch.uint8, device=device)
+            c = same_box_ceilings(torch, device, d_buf, ntiles * 4096, count, d_scratch, brief=True)
+            if c:
+                rec["roofline"]["ceilings"] = c
+                rec["roofline"]["frac_of_measured_read"] = round(achieved / c["read_nt"], 4)
+                rec["roofline"]["frac_of_best_trivial_kernel"] = round(achieved / c["best_trivial_kernel"], 4)
+        except Exception as exc:  # a measurement extra: never fails the bench
+            rec["roofline"]["ceilings"] = {"error": repr(exc)}
+    del d_buf, d_idx, d_unit
+    torch.cuda.empty_cache()
+    return rec, ok
 
 
 def ceiling_fields(achieved, ingest, box, recorded, workload):
@@ -273,15 +396,21 @@ def ceiling_fields(achieved, ingest, box, recorded, workload):
             src = f"profiles/traffic.json, recorded {recorded.get('date')} on another box of the pool (boxes differ by 3-5 %)"
     if not c:
         return {"ceilings": box if isinstance(box, dict) else None, "measured_read_peak": None, "frac_of_measured_read": None,
-                "ingest_frac_of_measured_read": None, "measured_same_mix_peak": None, "frac_of_same_mix": None}
+                "ingest_frac_of_measured_read": None, "model_envelope": None, "frac_of_model_envelope": None,
+                "best_trivial_kernel": None, "frac_of_best_trivial_kernel": None}
     read = max(c["read_plain"], c["read_nt"])
-    mix = c["same_mix_best"]  # the fastest of the trivial mixes and of the serial sum of the best pure streams
+    # `model_envelope` = max(the trivial mixes, the SERIAL SUM of the best pure read and the best pure write): the second
+    # term is a model (a half-duplex data bus), not a kernel; `best_trivial_kernel` is the fastest kernel that exists
+    mix = c["same_mix_best"]
+    best = c.get("best_trivial_kernel")
     return {"ceilings": {**c, "source": src},
             "measured_read_peak": read,
             "frac_of_measured_read": round(achieved / read, 4),
             "ingest_frac_of_measured_read": round(ingest / read, 4),
-            "measured_same_mix_peak": mix,
-            "frac_of_same_mix": round(achieved / mix, 4)}
+            "model_envelope": mix,
+            "frac_of_model_envelope": round(achieved / mix, 4),
+            "best_trivial_kernel": best,
+            "frac_of_best_trivial_kernel": round(achieved / best, 4) if best else None}
 
 
 def self_launch(args):
@@ -327,6 +456,8 @@ def main():
                     help="index slots per input byte (default: what the workload needs, from the unit's own count)")
     ap.add_argument("--no-ceilings", action="store_true",
                     help="skip the trivial HBM-ceiling kernels behind the verification (profiling passes: 6 000 launches less)")
+    ap.add_argument("--no-other-configs", action="store_true",
+                    help="skip the sub-records of BASELINE configs 3 and 4 (`other_configs`; N = 1, default workload only)")
     ap.add_argument("--no-emit", action="store_true",
                     help="diagnostic: summary pass only, no index writes (never a reported number)")
     args = ap.parse_args()
@@ -574,6 +705,21 @@ def main():
             del d_scratch
         except Exception as exc:  # a measurement extra: never fails the bench
             ceil_box = {"error": repr(exc)}
+    # ---- BASELINE configs 3 and 4 under the same clock (N = 1, default workload at 1 GiB only): sub-records, each with its
+    #      own warm-up, unsettled window, settle and K-step window; behind the headline's windows, before the CPU leg
+    others, others_failed = None, False
+    if (world == 1 and rank == 0 and not sharded and args.workload == "minified" and args.gib_per_gpu == 1.0
+            and not (args.no_other_configs or args.no_emit or args.no_verify)):
+        others = {}
+        for name, what, gen in OTHER_CONFIGS:
+            try:
+                rec, ok = other_config_record(dev, device, name, what, gen, args.steps, args.warmup, args.settle_ms, flags,
+                                              with_ceilings=not args.no_ceilings)
+                others[name] = rec
+                others_failed = others_failed or not ok
+            except Exception as exc:  # the headline is still printed; the exit code says that a sub-record broke
+                others[name] = {"error": repr(exc)}
+                others_failed = True
     if rank == 0 and world == 1 and not args.no_cpu_baseline and not args.rehearse_sharded:
         torch.cuda.synchronize()
         cpu = cpu_baseline(unit)  # timed CPU baseline on rank 0 at N = 1 only; the GPU is idle meanwhile
@@ -692,9 +838,14 @@ def main():
                           "far apart the ranks' kernels end; standalone_ms = each rank's shard through msj_stage1_shard_device "
                           "with its exact carry, no exchange, no host turn (K steps after the timed window)"}
         scaling_eff = {"value": round(total_len * args.steps / dt_max / 1e9 / alone_rate, 4),
+                       "gib_per_gpu": args.gib_per_gpu,
                        "basis": f"whole-job GB/s / sum over the {world} ranks of (shard bytes / standalone_ms): the same "
                                 f"{args.gib_per_gpu:g} GiB/GPU shards on the same GPUs in the same process without the stitch "
-                                f"(= {world} x the N = 1 configuration at this size per GPU, measured here rather than assumed)",
+                                f"(= {world} x the N = 1 configuration AT {args.gib_per_gpu:g} GiB PER GPU, measured here rather "
+                                f"than assumed).  NOT comparable with the default N = 1 line, which is BASELINE config 2 at "
+                                f"1 GiB per GPU: a launch of 1 GiB pays its ~11 us of start-up and tail 8 x as often per byte "
+                                f"as one of 8 GiB (`python bench.py --gpus 1 --gib-per-gpu {args.gib_per_gpu:g}` is the N = 1 "
+                                f"point of this curve)",
                        "standalone_aggregate": round(alone_rate, 2)}
 
     if rank == 0:
@@ -734,6 +885,9 @@ def main():
             "n_gpus": world,
             "steps": args.steps,
             "warmup": args.warmup,
+            # what really ran between the start of the process and the timed window: the W warm-up steps, the K steps of
+            # the `unsettled` window and the settle passes (config.dvfs_settle)
+            "untimed_passes_before_window": args.warmup + ((args.steps + settle_steps) if args.settle_ms > 0 else 0),
             "ms_per_step": round(ms_per_step, 4),
             **({"ms_per_step_median": step_dist["median"], "ms_per_step_min": step_dist["min"],
                 "ms_per_step_p95": step_dist["p95"]} if step_dist else {}),
@@ -789,6 +943,7 @@ def main():
             },
             "cpu_baseline": cpu,
             **({"end_to_end": e2e} if e2e else {}),
+            **({"other_configs": others} if others else {}),
         }
         if unsettled is not None:
             # the same K steps timed right after the W warm-up steps, before the clocks have settled
@@ -803,7 +958,14 @@ def main():
                 "note": "rank 0's clock; the first ~100 ms after idle run 10-15 % slower than the sustained rate",
             }
         print(json.dumps(out), flush=True)
-    verify_failed = verified.startswith("FAILED")
+    verify_failed = verified.startswith("FAILED") or others_failed
+    # a run over RCCL whose stitch did not go through the library's own ncclAllGather on a communicator of all N ranks is
+    # not the run the line claims to be: the line is printed (rank 0, above) and every rank leaves with exit code 4
+    exchange_failed = (sh is not None and backend == "nccl" and
+                       (sh.exchange_used != "rccl" or int(sh.rccl_ranks) != world))
+    if exchange_failed and rank == 0:
+        print(f"bench.py: the stitch ran over '{sh.exchange_used}' with {sh.rccl_ranks} RCCL ranks, not over RCCL with {world}: "
+              f"exit code 4", file=sys.stderr, flush=True)
     if sharded:
         barrier()
         sh.close()  # the RCCL communicator of the stitch goes before torch's process group does
@@ -812,6 +974,8 @@ def main():
         dist.destroy_process_group()
     if verify_failed:
         sys.exit(3)
+    if exchange_failed:
+        sys.exit(4)
 
 
 if __name__ == "__main__":
