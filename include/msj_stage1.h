@@ -411,8 +411,9 @@ int32_t msj_debug_set_segment_bytes(msj_ctx *ctx, uint64_t bytes);
  * reference compares with max_depth (DEPTH_ERROR).
  * These are derived quantities: the reference has no such arrays and no fixture for them, so
  * the CPU statement the tests compare with is a definition, not a pin.
- * d_buf / d_idx as produced by msj_stage1_device (offsets < len < 2^32, n < 2^31); d_idx and
- * d_depth 16-byte aligned, d_type 8-byte aligned.  Asynchronous on `stream`.
+ * d_buf / d_idx as produced by msj_stage1_device (offsets < len < 2^32, n < 2^31); d_idx,
+ * d_depth and (when given) d_match 16-byte aligned, d_type 8-byte aligned: anything else is
+ * MSJ_ERR_BAD_ARGUMENT (the arrays leave as 16-byte stores).  Asynchronous on `stream`.
  */
 typedef struct msj_tokens_result {
     uint64_t n;
@@ -455,7 +456,9 @@ int32_t msj_tokens_chain_device(msj_ctx *ctx, const uint8_t *d_buf, uint64_t len
 #define MSJ_SPAN_OPEN 16u    /* string not closed before the end of the buffer (d_end = len) */
 #define MSJ_SPAN_BAD 32u     /* number: the byte behind its digits is neither . e E nor structural / blank: the
                                 reference's parse_number returns NUMBER_ERROR here (number_parsing.mojo:56-57) */
-#define MSJ_SPAN_LONG 128u   /* string body over 1024 bytes: backslash flag not computed; number over 1024: not scanned */
+#define MSJ_SPAN_LONG 128u   /* number of more than 1024 characters: not scanned (d_end = 0).  Never set on a string: the
+                                closing quote and MSJ_SPAN_ESCAPED are exact at any body length (round 5: bodies over 1024
+                                bytes are scanned by a wave each behind the span kernel, over 1 MiB by the whole grid) */
 int32_t msj_token_spans_device(msj_ctx *ctx, const uint8_t *d_buf, uint64_t len, const uint32_t *d_idx, uint64_t n,
                                uint32_t *d_end, uint8_t *d_flags, void *stream);
 
@@ -489,8 +492,12 @@ int32_t msj_stage2_prep_chain_device(msj_ctx *ctx, const uint8_t *d_buf, uint64_
  * one call: one msj_stage2_prep_chain_device per segment, the depth handed from segment to segment on the device.
  *   segments: HOST copy of the shard's msj_segment table (n_segments entries; their counts size the launches)
  *   d_buf: the shard's first byte; d_idx and all output arrays: the shard's token arrays, segment s at
- *          [index_begin_s - index_begin_0, + count_s); every segment's slice must keep the alignment the single
- *          calls ask for (index counts are not multiples of 4: pass d_* arrays with slack and use `token_stride`)
+ *          [index_begin_s - index_begin_0, + count_s) of d_idx (dense, as stage 1 wrote them; a slice that does not
+ *          start on the 16-byte grid is copied to an aligned buffer of the library's before the kernels read it).  The
+ *          OUTPUT arrays are not dense: see offsets below; pass them with 8 elements of slack per segment.
+ *   The table is checked as a whole before anything is launched: segments must follow each other without gaps
+ *   (byte_base_s = byte_base_{s-1} + byte_len_{s-1}, index_begin likewise: MSJ_ERR_BAD_ARGUMENT), 0 < byte_len <=
+ *   MSJ_MAX_SEGMENT_BYTES and count < 2^31 (MSJ_CAPACITY).
  *   d_results: n_segments msj_tokens_result (device); the last one describes the shard
  *   d_prev: the result in front of the shard, or NULL
  * Outputs of segment s start at element offsets[s] = the sum of the counts in front of it, each rounded up to a multiple of 8

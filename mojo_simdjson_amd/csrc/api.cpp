@@ -687,7 +687,7 @@ int32_t msj_tokens_chain_device(msj_ctx *ctx, const uint8_t *d_buf, uint64_t len
     if (n > 0 && (!d_buf || !d_idx || !d_type || !d_depth)) return MSJ_ERR_BAD_ARGUMENT;
     if (len > MSJ_MAX_SEGMENT_BYTES || n >= (1ull << 31)) return MSJ_CAPACITY;
     if ((reinterpret_cast<uintptr_t>(d_idx) & 15u) || (reinterpret_cast<uintptr_t>(d_depth) & 15u) ||
-        (reinterpret_cast<uintptr_t>(d_type) & 7u))
+        (reinterpret_cast<uintptr_t>(d_type) & 7u) || (reinterpret_cast<uintptr_t>(d_match) & 15u))  // match[] leaves as 16-byte stores
         return MSJ_ERR_BAD_ARGUMENT;
     if (!hip_ok(hipSetDevice(ctx->device))) return MSJ_ERR_HIP;
     const uint64_t need = msj_stage2_prep_workspace_bytes(n, len, d_match != nullptr);  // incl. the fused kernel's chunk aggregates and table
@@ -739,7 +739,7 @@ int32_t msj_stage2_prep_chain_device(msj_ctx *ctx, const uint8_t *d_buf, uint64_
     if (n > 0 && (!d_buf || !d_idx || !d_type || !d_depth || !d_end || !d_flags)) return MSJ_ERR_BAD_ARGUMENT;
     if (len > MSJ_MAX_SEGMENT_BYTES || n >= (1ull << 31)) return MSJ_CAPACITY;
     if ((reinterpret_cast<uintptr_t>(d_idx) & 15u) || (reinterpret_cast<uintptr_t>(d_depth) & 15u) ||
-        (reinterpret_cast<uintptr_t>(d_type) & 7u))
+        (reinterpret_cast<uintptr_t>(d_type) & 7u) || (reinterpret_cast<uintptr_t>(d_match) & 15u))  // match[] leaves as 16-byte stores
         return MSJ_ERR_BAD_ARGUMENT;
     if (!hip_ok(hipSetDevice(ctx->device))) return MSJ_ERR_HIP;
     const uint64_t need = msj_stage2_prep_workspace_bytes(n, len, d_match != nullptr);
@@ -762,10 +762,18 @@ int32_t msj_stage2_prep_segments(msj_ctx *ctx, const uint8_t *d_buf, const msj_s
     if (!hip_ok(hipSetDevice(ctx->device))) return MSJ_ERR_HIP;
     hipStream_t st = static_cast<hipStream_t>(stream);
     const uint64_t begin0 = segments[0].index_begin, base0 = segments[0].byte_base;
+    // the whole table is checked before the first launch: a bad entry k must not leave segments 0 .. k-1 on the stream
+    for (uint32_t s = 0; s < n_segments; s++) {
+        const msj_segment &sg = segments[s];
+        if (sg.byte_len == 0 || sg.byte_len > MSJ_MAX_SEGMENT_BYTES || sg.count >= (1ull << 31)) return MSJ_CAPACITY;
+        if (s > 0) {  // segments of one shard follow each other without gaps, in bytes and in indices
+            const msj_segment &pv = segments[s - 1];
+            if (sg.byte_base != pv.byte_base + pv.byte_len || sg.index_begin != pv.index_begin + pv.count) return MSJ_ERR_BAD_ARGUMENT;
+        }
+    }
     uint64_t off = 0;
     for (uint32_t s = 0; s < n_segments; s++) {
         const msj_segment &sg = segments[s];
-        if (sg.index_begin < begin0 || sg.byte_base < base0) return MSJ_ERR_BAD_ARGUMENT;
         const uint64_t n = sg.count;
         const uint32_t *idx = d_idx + (sg.index_begin - begin0);
         if (n && (reinterpret_cast<uintptr_t>(idx) & 15u)) {

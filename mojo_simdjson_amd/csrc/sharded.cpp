@@ -71,7 +71,16 @@ int64_t run_before(const uint8_t *p, uint64_t pos) {
 // ---- default device operations: HIP
 int32_t hip_alloc(void *, uint64_t bytes, int pinned_host, void **out) {
     const hipError_t e = pinned_host ? hipHostMalloc(out, bytes, hipHostMallocDefault) : hipMalloc(out, bytes);
-    return e == hipSuccess ? MSJ_SUCCESS : MSJ_MEMALLOC;
+    if (e != hipSuccess) return MSJ_MEMALLOC;
+    // zeroed: a report whose `used` half no launch ever wrote (the carry goes by value) must not hold stale bytes
+    if (pinned_host) {
+        std::memset(*out, 0, bytes);
+    } else if (hipMemset(*out, 0, bytes) != hipSuccess) {
+        (void)hipFree(*out);
+        *out = nullptr;
+        return MSJ_ERR_HIP;
+    }
+    return MSJ_SUCCESS;
 }
 void hip_free(void *, void *p, int pinned_host) {
     if (!p) return;
@@ -691,6 +700,11 @@ int32_t msj_stage1_sharded_result(msj_sharded *sh, uint32_t ticket, int32_t *cod
                 sl.h_gathered[g].used.in_string = echo & 1u;
                 sl.h_gathered[g].used.next_is_escaped = (echo >> 1) & 1u;
                 sl.h_gathered[g].used.prev_scalar = (echo >> 2) & 1u;
+            } else if (sh->hip_default) {
+                // with the default operations nobody writes `used` on the device (the carry goes by value): a report
+                // without the echo -- a launch that never reached finish(), a library in the group that predates the
+                // echo -- has no carry to verify against.  An error, not a guess.
+                return MSJ_ERR_HIP;
             }
         }
         uint64_t mask = 0;

@@ -545,6 +545,55 @@ __device__ __forceinline__ Pending compute_tile(const KernelArgs &a, const uint3
     const uint32_t skip = tile == 0 ? (a.flags >> kFlagSkipShift) & 15u : 0u;  // uniform
     const bool partial = tile * kTileBytes + kTileBytes > len;  // uniform: the launch's last tile, cut short
 
+#ifdef MSJ_UNIFORM_TILES
+    // MEASURED NO-GAIN, not in the product (round 5, profiles/r05/ab_uniform_tiles.txt; build with -DMSJ_UNIFORM_TILES to
+    // repeat): with this path a tile of blanks / of one scalar character runs ~15 vector instructions instead of 311, and
+    // the d ~ 0 rows of the density sweep do not move (0.1790 / 0.1791 ms per GiB without it, 0.1714 / 0.1836 with it, same
+    // box, alternating) -- those rows are bound by the range loop's latency chain (one 8 KiB request per wave and
+    // iteration: load -> barrier -> hand-over -> load), not by instruction issue -- while the filter's 7 instructions
+    // cost every ordinary tile ~1 % (pretty-printed 0.2510 -> 0.2548 ms, UTF-8-heavy 0.2897 -> 0.2942).
+    // ---- a tile whose 4 096 bytes are ONE byte value that is a blank or a plain scalar character (padding between
+    //      records, the inside of a run of one character): nothing to transpose or classify.  Round 5 (VERDICT round 4,
+    //      "311 vector instructions are paid to learn that a tile of blanks holds nothing"): a three-dword filter that
+    //      ordinary text fails at once (7 vector instructions per tile), then the other thirteen dwords.  What
+    //      JsonScanner.next (json_scanner.mojo:64-70) computes for such a block is known in closed form:
+    //        blanks        no structural, no scalar carry out                       (whitespace: haswell.mojo:23-65)
+    //        scalar bytes  one structural -- the tile's first byte, unless the byte in front of the tile is a scalar
+    //                      (follows, json_scanner.mojo:76-79) and only outside a string -- and the scalar carry out set.
+    //      Neither holds a quote or a backslash, so parity, escape carry and both error flags are zero whatever the
+    //      carries in (an escaped first byte that is no quote and no backslash changes nothing).
+    if (!partial && !skip && tc.resolved && tc.u8_in == 0u) {  // uniform
+        const uint32_t splat = perm(x[0], x[0], 0u);  // byte 0 of the lane's block, four times
+        const uint32_t first = uniform32(splat);
+        uint32_t dif = lut3<MSJ_TT(TA | (TB ^ TC))>(x[0] ^ splat, x[7], splat);
+        dif = lut3<MSJ_TT(TA | (TB ^ TC))>(dif, x[15], splat);
+        if (__ballot((dif | (splat ^ first)) != 0u) == 0ull) {  // uniform: the filter passed in every lane
+            const uint32_t c = first & 0xFFu;
+            // op | ws | quote | backslash | control | >= 0x80 as a 128-entry bit table (haswell.mojo:22-74 + 22, 5C, < 20)
+            constexpr uint64_t kSpLo = 0xFFFFFFFFull | (1ull << 0x20) | (1ull << 0x22) | (1ull << 0x2C) | (1ull << 0x3A);
+            constexpr uint64_t kSpHi = (1ull << (0x5B - 64)) | (1ull << (0x5C - 64)) | (1ull << (0x5D - 64)) |
+                                       (1ull << (0x7B - 64)) | (1ull << (0x7D - 64));
+            const bool plain = c < 0x80u && !((((c & 0x40u) ? kSpHi : kSpLo) >> (c & 63u)) & 1ull);
+            if (c == 0x20u || plain) {  // uniform
+                uint32_t acc = 0;
+#pragma unroll
+                for (int k = 1; k < 15; k++)
+                    if (k != 7) acc = lut3<MSJ_TT(TA | (TB ^ TC))>(acc, x[k], splat);
+                if (__ballot(acc != 0u) == 0ull) {  // uniform: all 4 096 bytes are c
+                    Pending r;
+                    const uint32_t one = (plain && tc.ps_in == 0u) ? 1u : 0u;  // the tile's first byte starts a scalar
+                    r.T0 = (lane == 0u) ? (uint64_t)one : 0ull;
+                    r.T1 = 0ull;
+                    r.excl = (lane == 0u) ? 0u : one;  // packed (count if outside | count if inside << 16) in front of the lane
+                    r.tile_cnt = one;
+                    const uint32_t hi = (uint32_t)(kAgg >> 32) | ((plain ? 1u : 0u) << 25) | (timeout << 22);
+                    agg_word = u64(r.tile_cnt, hi);
+                    return r;
+                }
+            }
+        }
+    }
+#endif
     MSJ_STAMP(tile, 2);
     // ---- bit-planes and character classes (lane_math.h)
     uint64_t p[8];

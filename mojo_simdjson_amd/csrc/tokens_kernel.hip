@@ -879,7 +879,12 @@ static int launch_depth_passes(const uint32_t *d_idx, uint64_t n, uint8_t *d_typ
         // match[] is complete for every container that closes inside a block (apply_depth<true> wrote the whole array);
         // what is left -- a container that spans a block border, or lies outside the levels a block keeps -- walks the tree
         // (the lane groups of 32 workgroups stride over each of the lists)
-        hipLaunchKernelGGL(match_brackets, dim3(MSJ_MATCH_GRID, kSurvivorShards), dim3(256), 0, s, d_type, opens, survivors, t, d_match, survivor_capacity(nb));
+        // (block b appends to list b mod kSurvivorShards: a short call uses the first nb lists only, and a list then holds
+        // the survivors of nb / kSurvivorShards blocks -- the grid follows, instead of 8 192 workgroups for a handful of tokens)
+        const uint32_t lists = nb < kSurvivorShards ? nb : kSurvivorShards;
+        const uint32_t per_list = nb / kSurvivorShards / 8u + 1u;  // ~2 survivors per block, 16 brackets per workgroup and round
+        hipLaunchKernelGGL(match_brackets, dim3(per_list < MSJ_MATCH_GRID ? per_list : MSJ_MATCH_GRID, lists), dim3(256), 0, s, d_type, opens,
+                           survivors, t, d_match, survivor_capacity(nb));
     }
     return (int)hipGetLastError();
 }
@@ -1029,12 +1034,59 @@ static_assert(kSpanBlocks <= kSpanThreads, "one lane per staged block");
 constexpr uint32_t kFixCap = 16382;        // entries; more than that: span_fixup looks for the sentinel itself (MSJ_SPANS_FIX_CAP: tests)
 constexpr uint32_t kFixWords = kFixCap + 2;
 constexpr uint32_t kFixSentinel = 0xFFu;   // no token has all eight flag bits
-constexpr uint32_t kFixGroups = 32;
+constexpr uint32_t kFixGroups = 256;       // (x 4 waves: a wave per listed long string)
 __device__ __forceinline__ void fix_later(uint32_t *fix, uint32_t cap, uint32_t token, uint32_t &e, uint32_t &f) {
     const uint32_t slot = atomicAdd(&fix[0], 1u);
     if (slot < cap) fix[2 + slot] = token;
     e = 0;
     f = kFixSentinel;
+}
+
+// Strings whose body is longer than kSpanCap (round 5: the escape flag is exact at ANY length; MSJ_SPAN_LONG is left
+// to numbers).  The span kernels know such a string's closing quote -- the last non-blank byte in front of the next
+// structural -- but not whether its body holds a backslash: that is what parse_string rescans the most bytes for
+// (generic/stage2/string_parsing.mojo:334-386, include/haswell/stringparsing_defs.mojo:27-48).  They give it the flags
+// MSJ_SPAN_STRING | MSJ_SPAN_LONG as a MARKER and put it on a second work list behind the fix-up list (same buffer);
+// span_fixup scans the body of every listed string with one WAVE (1 KiB contiguous per load instruction), strings
+// over kBigBody bytes go on to long_strings_big, which scans each with the whole grid.  A list that overflows:
+// span_fixup finds the marker in flags[] itself.  Work per byte of long strings, whatever their length.
+constexpr uint32_t kLongString = MSJ_SPAN_STRING | MSJ_SPAN_LONG;
+constexpr uint32_t kLngHdr = 4;             // [0] entries, [2] strings over kBigBody, [3] workgroups of long_strings_big that are done
+constexpr uint32_t kBigBody = 1u << 20;     // bytes one wave scans at most
+constexpr uint32_t kBigCap = 4096;          // a segment (< 4 GiB) holds fewer strings of more than 1 MiB
+constexpr uint32_t kBigPiece = 1u << 16;    // bytes per wave and step of long_strings_big
+constexpr uint32_t kLngWords = kLngHdr + kFixCap + 2 * kBigCap;  // header, token indices, the big ones' tokens, their results
+__device__ __forceinline__ void long_later(uint32_t *fix, uint32_t cap, uint32_t token) {
+    uint32_t *lng = fix + kFixWords;
+    const uint32_t slot = atomicAdd(&lng[0], 1u);
+    if (slot < cap) lng[kLngHdr + slot] = token;
+}
+// 0x80 in every byte of x that is zero; exact (no carries between bytes)
+__device__ __forceinline__ uint32_t zero_bytes32(uint32_t x) { return ~(((x & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | x | 0x7F7F7F7Fu); }
+// any backslash in buf[b0, close)?  One wave; 1 KiB contiguous per load instruction, four of them per round trip;
+// the 16-byte pieces that straddle b0 or close are looked at byte by byte.  close <= len; buf 16-byte aligned.
+__device__ __forceinline__ bool wave_has_backslash(const uint8_t *__restrict__ buf, uint64_t b0, uint64_t close, uint32_t lane) {
+    uint32_t any = 0;
+    constexpr uint32_t kBs = 0x5C5C5C5Cu;
+    for (uint64_t base = b0 & ~15ull; base < close; base += 4096u) {  // uniform
+#pragma unroll
+        for (uint32_t k = 0; k < 4; k++) {
+            const uint64_t off = base + 1024u * k + 16u * lane;
+            if (off < close) {
+                if (off >= b0 && off + 16u <= close) {
+                    const uint4 v = *reinterpret_cast<const uint4 *>(buf + off);
+                    any |= zero_bytes32(v.x ^ kBs) | zero_bytes32(v.y ^ kBs) | zero_bytes32(v.z ^ kBs) | zero_bytes32(v.w ^ kBs);
+                } else {
+                    for (uint32_t j = 0; j < 16u; j++) {
+                        const uint64_t p = off + j;
+                        if (p >= b0 && p < close && buf[p] == 0x5Cu) any = 1u;
+                    }
+                }
+            }
+        }
+        if (__ballot(any != 0u) != 0ull) return true;  // uniform
+    }
+    return false;
 }
 
 // 32 bits of a bitmap starting at bit `pos` (bit 0 of the result = position pos)
@@ -1215,7 +1267,7 @@ __device__ __forceinline__ bool staged_token_fast(const uint8_t *stage, const ui
     const uint32_t e_num = lo + pe;
     e_out = is_str ? e_str : (is_num ? e_num : 0u);
     f_out = is_str ? f_str : (is_num ? f_num : 0u);
-    return !(is_str ? (more_ink || more_bs || far) : (is_num && (more_num || more_flt || no_end)));
+    return !(is_str ? (more_ink || more_bs || far || (closed && lng)) : (is_num && (more_num || more_flt || no_end)));
 }
 
 // kFused: the kernel also writes the type byte of every token and the (sum, min, max, opening brackets)
@@ -1261,11 +1313,17 @@ __global__ __launch_bounds__(kSpanThreads) void token_spans(const uint8_t *__res
     if (!staged) {
         MSJ_SPAN_ARRIVED();
         if (have0) {
-            if (kSpans) span_of(FromGlobal{buf, len}, start0, next0, len, e0, f0);
+            if (kSpans) {
+                span_of(FromGlobal{buf, len}, start0, next0, len, e0, f0);
+                if (f0 == kLongString) long_later(fix, fix_cap, tok0);
+            }
             if (kFused) c0 = buf[start0];
         }
         if (have1) {
-            if (kSpans) span_of(FromGlobal{buf, len}, start1, next1, len, e1, f1);
+            if (kSpans) {
+                span_of(FromGlobal{buf, len}, start1, next1, len, e1, f1);
+                if (f1 == kLongString) long_later(fix, fix_cap, tok0 + 1u);
+            }
             if (kFused) c1 = buf[start1];
         }
     } else {
@@ -1358,15 +1416,21 @@ __global__ __launch_bounds__(kSpanThreads) void token_spans(const uint8_t *__res
             const bool s1 = have1 && (c1 == '"' || c1 == '-' || c1 - '0' < 10u);
             const uint32_t cs = s0 ? c0 : c1, rs = s0 ? rs0 : rs1, rn = s0 ? rn0 : rn1;
             uint32_t e, f;
-            if (!staged_token_fast(stage, m_num, m_flt, m_bs, bs_cnt, m_ink, lo32, span, len32, cs, rs, rn, e, f) &&
-                staged_token(stage, m_num, m_flt, m_bs, m_ink, bs_blocks, lo, span, len, cs, lo + rs, lo + rn, e, f))
-                fix_later(fix, fix_cap, tok0 + (s0 ? 0u : 1u), e, f);
+            if (!staged_token_fast(stage, m_num, m_flt, m_bs, bs_cnt, m_ink, lo32, span, len32, cs, rs, rn, e, f)) {
+                if (staged_token(stage, m_num, m_flt, m_bs, m_ink, bs_blocks, lo, span, len, cs, lo + rs, lo + rn, e, f))
+                    fix_later(fix, fix_cap, tok0 + (s0 ? 0u : 1u), e, f);
+                else if (f == kLongString)
+                    long_later(fix, fix_cap, tok0 + (s0 ? 0u : 1u));
+            }
             e0 = s0 ? e : 0u, f0 = s0 ? f : 0u;
             e1 = s0 ? 0u : e, f1 = s0 ? 0u : f;
             if (s0 && s1) {  // two scalars in a row (not a valid document)
-                if (!staged_token_fast(stage, m_num, m_flt, m_bs, bs_cnt, m_ink, lo32, span, len32, c1, rs1, rn1, e1, f1) &&
-                    staged_token(stage, m_num, m_flt, m_bs, m_ink, bs_blocks, lo, span, len, c1, start1, next1, e1, f1))
-                    fix_later(fix, fix_cap, tok0 + 1u, e1, f1);
+                if (!staged_token_fast(stage, m_num, m_flt, m_bs, bs_cnt, m_ink, lo32, span, len32, c1, rs1, rn1, e1, f1)) {
+                    if (staged_token(stage, m_num, m_flt, m_bs, m_ink, bs_blocks, lo, span, len, c1, start1, next1, e1, f1))
+                        fix_later(fix, fix_cap, tok0 + 1u, e1, f1);
+                    else if (f1 == kLongString)
+                        long_later(fix, fix_cap, tok0 + 1u);
+                }
             }
         }
     }
@@ -1521,7 +1585,7 @@ __device__ __forceinline__ uint32_t pair_fast(const TileMaps &t, uint32_t lo, ui
     const uint32_t f_num = MSJ_SPAN_NUMBER | (flt ? MSJ_SPAN_FLOAT : 0u) | (bad ? MSJ_SPAN_BAD : 0u);
     e_out = is_str ? e_str : (is_num ? lo + pe : 0u);
     f_out = is_str ? f_str : (is_num ? f_num : 0u);
-    return is_str ? more_ink : (is_num & short_num);
+    return is_str ? (more_ink | (closed & lng)) : (is_num & short_num);  // (a long string: the slow path puts it on the long-string list)
 }
 
 // One token, any length, from the same maps (rare lanes; the chunks at the end of the input): staged_token with the
@@ -1861,30 +1925,51 @@ __global__ __launch_bounds__(kTgThreads) void token_tiles(const uint8_t *__restr
             const uint32_t cs = s0 ? c0 : c1, rs = s0 ? rs0 : rs1, rn = s0 ? rs1 : rn1;
             uint32_t e, f;
             const uint32_t again = pair_fast(maps, base, kTgStage, len32, cs, s0 | s1, rs, rn, e, f);
-            if (__ballot((again | (s0 & s1)) != 0u) != 0ull) {  // rare: a window came up short, or two scalars in a row
-                if (again && tile_token_slow(maps, base, kTgStage, len32, cs, rs, rn, e, f)) fix_later(fix, fix_cap, tok0 + (s0 ? 0u : 1u), e, f);
+            if (__ballot((again | (s0 & s1)) != 0u) != 0ull) {  // rare: a window came up short, a long string, or two scalars in a row
+                if (again) {
+                    if (tile_token_slow(maps, base, kTgStage, len32, cs, rs, rn, e, f))
+                        fix_later(fix, fix_cap, tok0 + (s0 ? 0u : 1u), e, f);
+                    else if (f == kLongString)
+                        long_later(fix, fix_cap, tok0 + (s0 ? 0u : 1u));
+                }
                 if (s0 & s1) {
-                    if (tile_token_slow(maps, base, kTgStage, len32, c1, rs1, rn1, e1, f1)) fix_later(fix, fix_cap, tok0 + 1u, e1, f1);
+                    if (tile_token_slow(maps, base, kTgStage, len32, c1, rs1, rn1, e1, f1))
+                        fix_later(fix, fix_cap, tok0 + 1u, e1, f1);
+                    else if (f1 == kLongString)
+                        long_later(fix, fix_cap, tok0 + 1u);
                 }
             }
             e0 = s0 ? e : 0u, f0 = s0 ? f : 0u;
             if (!(s0 & s1)) e1 = s0 ? 0u : e, f1 = s0 ? 0u : f;
         } else if (!staged) {
             if (have0) {
-                if (kSpans) span_of(FromGlobal{buf, len}, (uint64_t)start0, (uint64_t)next0, len, e0, f0);
+                if (kSpans) {
+                    span_of(FromGlobal{buf, len}, (uint64_t)start0, (uint64_t)next0, len, e0, f0);
+                    if (f0 == kLongString) long_later(fix, fix_cap, tok0);
+                }
                 if (kFused) c0 = buf[start0];
             }
             if (have1) {
-                if (kSpans) span_of(FromGlobal{buf, len}, (uint64_t)start1, (uint64_t)next1, len, e1, f1);
+                if (kSpans) {
+                    span_of(FromGlobal{buf, len}, (uint64_t)start1, (uint64_t)next1, len, e1, f1);
+                    if (f1 == kLongString) long_later(fix, fix_cap, tok0 + 1u);
+                }
                 if (kFused) c1 = buf[start1];
             }
         } else if (have0) {  // staged: the type bytes only (kSpans = false), or the chunk at the end of the index
             c0 = stage[start0 - base];
             c1 = have1 ? (uint32_t)stage[start1 - base] : 0u;
             if (kSpans) {
-                if (tile_token_slow(maps, base, kTgStage, len32, c0, start0 - base, next0 - base, e0, f0)) fix_later(fix, fix_cap, tok0, e0, f0);
-                if (have1 && tile_token_slow(maps, base, kTgStage, len32, c1, start1 - base, next1 - base, e1, f1))
-                    fix_later(fix, fix_cap, tok0 + 1u, e1, f1);
+                if (tile_token_slow(maps, base, kTgStage, len32, c0, start0 - base, next0 - base, e0, f0))
+                    fix_later(fix, fix_cap, tok0, e0, f0);
+                else if (f0 == kLongString)
+                    long_later(fix, fix_cap, tok0);
+                if (have1) {
+                    if (tile_token_slow(maps, base, kTgStage, len32, c1, start1 - base, next1 - base, e1, f1))
+                        fix_later(fix, fix_cap, tok0 + 1u, e1, f1);
+                    else if (f1 == kLongString)
+                        long_later(fix, fix_cap, tok0 + 1u);
+                }
             }
         }
         if (allhere && wide) {
@@ -1927,7 +2012,10 @@ __global__ __launch_bounds__(kTgThreads) void token_tiles(const uint8_t *__restr
     MSJ_TSTAMP(5);
 }
 
-// the tokens on the work list, from global memory; the last workgroup to finish clears the list for the next call
+// the tokens on the fix-up list, from global memory, then the strings on the long-string list (a wave each).  Neither
+// list is cleared here: long_strings_big, always launched behind this kernel, does that (stream order: every workgroup of
+// this kernel has read the counts by then -- the "last workgroup clears" protocol of round 2 cost one returning atomic
+// per workgroup on one word, ~85 per microsecond chip-wide).
 __global__ __launch_bounds__(256) void span_fixup(const uint8_t *__restrict__ buf, uint64_t len, const uint32_t *__restrict__ idx, uint64_t n,
                                                   uint32_t *__restrict__ end, uint8_t *__restrict__ flags, uint32_t *__restrict__ fix, uint32_t cap) {
     const uint32_t count = __hip_atomic_load(&fix[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1946,10 +2034,80 @@ __global__ __launch_bounds__(256) void span_fixup(const uint8_t *__restrict__ bu
                 if (flags[tok] == kFixSentinel) redo(tok);
         }
     }
-    __syncthreads();
-    if (threadIdx.x == 0 && atomicAdd(&fix[1], 1u) == gridDim.x - 1u) {  // every workgroup has read the count
-        fix[1] = 0;
+    // ---- strings over kSpanCap bytes: end[] holds their closing quote, the body is scanned here (one wave per string)
+    uint32_t *lng = fix + kFixWords;
+    const uint32_t lcount = __hip_atomic_load(&lng[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (lcount != 0) {
+        const uint32_t lane = threadIdx.x & 63u;
+        const uint32_t wv = (uint32_t)__builtin_amdgcn_readfirstlane((int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6));
+        const uint32_t nw = (gridDim.x * blockDim.x) >> 6;
+        const auto one = [&](uint64_t tok) {  // uniform per wave
+            const uint64_t b0 = (uint64_t)idx[tok] + 1u, close = end[tok];
+            if (close - b0 > kBigBody) {
+                if (lane == 0) {
+                    const uint32_t slot = atomicAdd(&lng[2], 1u);
+                    if (slot < kBigCap) lng[kLngHdr + kFixCap + slot] = (uint32_t)tok;
+                }
+            } else {
+                const bool any = wave_has_backslash(buf, b0, close, lane);
+                if (lane == 0) flags[tok] = (uint8_t)(MSJ_SPAN_STRING | (any ? MSJ_SPAN_ESCAPED : 0u));
+            }
+        };
+        if (lcount <= cap) {
+            for (uint32_t k = wv; k < lcount; k += nw) one(lng[kLngHdr + k]);
+        } else {  // the list overflowed: every token that carries the marker
+            for (uint64_t t0 = (uint64_t)wv * 64u; t0 < n; t0 += (uint64_t)nw * 64u) {  // uniform
+                const uint64_t t = t0 + lane;
+                uint64_t m = __ballot(t < n && flags[t] == kLongString);
+                while (m) {  // uniform
+                    const uint32_t b = (uint32_t)__builtin_ctzll(m);
+                    m &= m - 1ull;
+                    one(t0 + b);
+                }
+            }
+        }
+    }
+}
+
+// Strings of more than kBigBody bytes (an embedded blob): every workgroup takes pieces of every such string, a wave per
+// piece; the last workgroup to finish writes the flags.  Workgroup 0 also clears the two lists span_fixup worked through
+// (this kernel runs behind it on the stream).  Launched with every span call: ~2 us when there is nothing to do.
+constexpr uint32_t kBigGroups = 64;
+__global__ __launch_bounds__(256) void long_strings_big(const uint8_t *__restrict__ buf, const uint32_t *__restrict__ idx,
+                                                        const uint32_t *__restrict__ end, uint8_t *__restrict__ flags, uint32_t *__restrict__ fix) {
+    uint32_t *lng = fix + kFixWords, *big = lng + kLngHdr + kFixCap, *res = big + kBigCap;
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
         __hip_atomic_store(&fix[0], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&lng[0], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    uint32_t nbig = __hip_atomic_load(&lng[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (nbig == 0u) return;  // (nobody has touched lng[3])
+    if (nbig > kBigCap) nbig = kBigCap;  // cannot happen within one segment
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t wv = (uint32_t)__builtin_amdgcn_readfirstlane((int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6));
+    const uint32_t nw = (gridDim.x * blockDim.x) >> 6;
+    for (uint32_t k = 0; k < nbig; k++) {  // uniform
+        const uint64_t tok = big[k];
+        const uint64_t b0 = (uint64_t)idx[tok] + 1u, close = end[tok];
+        const uint64_t pieces = (close - b0 + kBigPiece - 1u) / kBigPiece;
+        bool any = false;
+        for (uint64_t p = wv; p < pieces && !any; p += nw) {  // uniform
+            const uint64_t lo = b0 + p * kBigPiece, hi = lo + kBigPiece < close ? lo + kBigPiece : close;
+            any = wave_has_backslash(buf, lo, hi, lane);
+        }
+        if (any && lane == 0) atomicOr(&res[k], 1u);
+    }
+    __threadfence();
+    __syncthreads();
+    if (threadIdx.x == 0 && atomicAdd(&lng[3], 1u) == gridDim.x - 1u) {  // every workgroup is through
+        __threadfence();
+        for (uint32_t k = 0; k < nbig; k++) {
+            const uint32_t any = __hip_atomic_load(&res[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            flags[big[k]] = (uint8_t)(MSJ_SPAN_STRING | (any ? MSJ_SPAN_ESCAPED : 0u));
+            res[k] = 0u;
+        }
+        lng[3] = 0u;
+        __hip_atomic_store(&lng[2], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 }
 
@@ -2001,7 +2159,7 @@ extern "C" int msj_debug_set_tile_stamps(void *d_stamps) {
 #endif
 
 // the work list of span_fixup: zeroed once by the owner (the kernels leave it zeroed)
-extern "C" uint64_t msj_span_fix_bytes(void) { return msj_tokens::kFixWords * sizeof(uint32_t); }
+extern "C" uint64_t msj_span_fix_bytes(void) { return (msj_tokens::kFixWords + msj_tokens::kLngWords) * sizeof(uint32_t); }  // + the long-string list
 
 // ---- workspace of the span / prep calls: the token pre-pass's own words, then (16-byte aligned) one int4 per chunk
 // of kChunk tokens (the fused kernels' depth aggregates), then the group table of token_tiles
@@ -2027,8 +2185,10 @@ static void launch_token_tiles(const uint8_t *d_buf, uint64_t len, const uint32_
     hipLaunchKernelGGL(group_table, dim3((ngroups + 1u + 255u) / 256u), dim3(256), 0, s, d_idx, (uint32_t)n, ngroups, len, tbl);
     hipLaunchKernelGGL((token_tiles<kFused, kSpans>), dim3(ngroups), dim3(kTgThreads), 0, s, d_buf, len, d_idx, n, d_end, d_flags,
                        o.lds_limit < kTgStage ? o.lds_limit : 0xFFFFFFFFu, d_type, sub, d_fix, fix_cap(o), tbl);
-    if (kSpans)
+    if (kSpans) {
         hipLaunchKernelGGL(span_fixup, dim3(kFixGroups), dim3(256), 0, s, d_buf, len, d_idx, n, d_end, d_flags, d_fix, fix_cap(o));
+        hipLaunchKernelGGL(long_strings_big, dim3(kBigGroups), dim3(256), 0, s, d_buf, d_idx, d_end, d_flags, d_fix);
+    }
 }
 
 int msj_launch_token_spans(const uint8_t *d_buf, uint64_t len, const uint32_t *d_idx, uint64_t n, uint32_t *d_end, uint8_t *d_flags,
@@ -2047,6 +2207,7 @@ int msj_launch_token_spans(const uint8_t *d_buf, uint64_t len, const uint32_t *d
     hipLaunchKernelGGL(token_spans<false>, dim3((uint32_t)((n + kSpanTokens - 1) / kSpanTokens)), dim3(kSpanThreads), 0, s, d_buf, len, d_idx, n,
                        d_end, d_flags, lds_limit, static_cast<uint8_t *>(nullptr), static_cast<int4 *>(nullptr), d_fix, fix_cap(o));
     hipLaunchKernelGGL(span_fixup, dim3(kFixGroups), dim3(256), 0, s, d_buf, len, d_idx, n, d_end, d_flags, d_fix, fix_cap(o));
+    hipLaunchKernelGGL(long_strings_big, dim3(kBigGroups), dim3(256), 0, s, d_buf, d_idx, d_end, d_flags, d_fix);
     return (int)hipGetLastError();
 }
 
@@ -2072,6 +2233,7 @@ int msj_launch_stage2_prep(const uint8_t *d_buf, uint64_t len, const uint32_t *d
         const uint32_t lds_limit = span_lds_limit(o);
         hipLaunchKernelGGL(token_spans<true>, dim3(nsub), dim3(kSpanThreads), 0, s, d_buf, len, d_idx, n, d_end, d_flags, lds_limit, d_type, sub, d_fix, fix_cap(o));
         hipLaunchKernelGGL(span_fixup, dim3(kFixGroups), dim3(256), 0, s, d_buf, len, d_idx, n, d_end, d_flags, d_fix, fix_cap(o));
+        hipLaunchKernelGGL(long_strings_big, dim3(kBigGroups), dim3(256), 0, s, d_buf, d_idx, d_end, d_flags, d_fix);
         hipLaunchKernelGGL(merge_chunk_counts, dim3((nb * 16u + 255u) / 256u), dim3(256), 0, s, sub, (uint32_t)chunk_count(n), d_ws, nb);
     }
     return launch_depth_passes(d_idx, n, d_type, d_depth, d_match, d_result, d_ws, s, o);

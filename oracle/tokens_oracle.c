@@ -76,7 +76,7 @@ int msj_oracle_match(const uint8_t *type, uint64_t n, uint32_t *match) {
  * parse_number's scan takes (include/generic/number_parsing.mojo:41-59, restated in the number branch
  * below and, without the cap, in msj_ref_parse_number_scan).  (The HIP kernel finds the closing
  * quote from the NEXT structural instead; the tests check that this is the same thing.)
- * Bodies over 1024 bytes: end still reported, backslash flag not (LONG); numbers over 1024: LONG, end 0. */
+ * Strings: exact at any length (round 5).  Numbers over 1024 characters: LONG, end 0. */
 /* structural_or_whitespace, internal/jsoncharutils_tables.mojo:5-16: 09 0A 0D 20 , : [ ] { } */
 static int msj_ref_structural_or_whitespace(uint8_t c) {
     return c == 0x09 || c == 0x0A || c == 0x0D || c == 0x20 || c == ',' || c == ':' || c == '[' || c == ']' || c == '{' || c == '}';
@@ -176,8 +176,7 @@ void msj_oracle_token_spans(const uint8_t *buf, uint64_t len, const uint32_t *id
             if (!closed) { e = (uint32_t)len; f |= 16; }
             else {
                 e = (uint32_t)j;
-                if (j - (start + 1) > cap) f |= 128;
-                else if (esc) f |= 2;
+                if (esc) f |= 2;  /* at ANY body length (round 5: the cap of 1024 bytes now binds numbers only) */
             }
         } else if (c == '-' || (c >= '0' && c <= '9')) {
             /* parse_number's scan restated (include/generic/number_parsing.mojo:41-59): has_minus_sign,

@@ -38,6 +38,7 @@ int32_t lane_stage1(const uint8_t *, uint64_t, uint32_t *, uint64_t, uint64_t *,
 hipError_t hipMalloc(void **, size_t) { std::abort(); }
 hipError_t hipHostMalloc(void **, size_t, unsigned int) { std::abort(); }
 hipError_t hipFree(void *) { std::abort(); }
+hipError_t hipMemset(void *, int, size_t) { std::abort(); }
 hipError_t hipHostFree(void *) { std::abort(); }
 hipError_t hipMemcpyAsync(void *, const void *, size_t, hipMemcpyKind, hipStream_t) { std::abort(); }
 hipError_t hipStreamSynchronize(hipStream_t) { std::abort(); }

@@ -195,6 +195,26 @@ def test_quiet_tiles(oracle):
         "utf-8 cut by the edges of quiet tiles": b'["x' + "漢".encode() * (3 * q // 3 + 11) + b'"]',
         "bad utf-8 in a quiet tile": b'["' + b"x" * (q + 50) + b"\xff" + b"x" * q + b'"]',
         "unclosed": b'["' + b"x" * (3 * q),
+        # round 5: tiles of ONE byte value (blank or plain scalar) skip the transpose and the classification altogether
+        "uniform: blanks from the first byte": b" " * (2 * q) + b"[1]",
+        "uniform: scalar tile behind a blank (its first byte is structural)": b"[" + b" " * (q - 1) + b"7" * q + b"   ,1]",
+        "uniform: scalar tile behind a scalar": b"[" + b" " * (q - 2) + b"8" + b"7" * q + b"   ,1]",
+        "uniform: scalar tile behind a closing quote": b'["' + b"a" * (q - 3) + b'"' + b"7" * q + b"]",
+        "uniform: scalar tile behind an operator": b"[" * q + b"7" * q + b"]" * q,
+        "uniform: scalar tiles, nothing else": b"7" * (3 * q),
+        "uniform: blanks, nothing else": b" " * (3 * q),
+        "uniform: a cut UTF-8 character in front (pending continuation)": b'["' + b"x" * (q - 3) + b"\xc3" + b"x" * q + b'"]',
+        "uniform: a cut UTF-8 character in front of blanks": b'["' + b"x" * (q - 4) + b'"' + b"\xe4" + b" " * q + b"]",
+        "uniform: tiles of quotes (not plain: the long way)": b'"' * (2 * q),
+        "uniform: tiles of commas": b"," * (2 * q),
+        "uniform: tiles of NUL": b"[" + b"\x00" * (2 * q - 1) + b"]",
+        "uniform: tiles of NUL in a string": b'["' + b"\x00" * (2 * q - 2) + b'"]',
+        "uniform: tiles of DEL": b"[" + b"\x7f" * (2 * q - 1) + b",1]",
+        "uniform: tiles of 0x80": b'["' + b"x" * (q - 2) + b"\x80" * q + b'"]',
+        "uniform: all but the tile's last byte": b"[" + b" " * (q - 1) + b"7" * (q - 1) + b"," + b"7" * q + b"]",
+        "uniform: all but byte 28 (between the filter's dwords)": b"[" + b" " * (q - 1) + b"7" * 28 + b"," + b"7" * (q - 29) + b"]",
+        "uniform: all but byte 4 of the last block": b"[" + b" " * (q - 1) + b"7" * (q - 60) + b"," + b"7" * 59 + b"]",
+        "uniform: escaped first byte": b'["' + b"x" * (q - 3) + b"\\" + b"7" * q + b'"]',
     }
     for name, d in cases.items():
         assert_matches_oracle(oracle, d, name)

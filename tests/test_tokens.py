@@ -49,7 +49,12 @@ def test_span_definition_by_hand():
     d2 = b'["' + b"a" * 2000 + b'",' + b"1" * 2000 + b',"zz'
     idx2 = np.array([0, 1, 2003, 2004, 4004, 4005], dtype=np.uint32)
     end, flags = helpers.oracle_token_spans(d2, idx2)
-    assert list(zip(end.tolist(), flags.tolist())) == [(0, 0), (2002, 129), (0, 0), (0, 132), (0, 0), (len(d2), 17)]
+    assert list(zip(end.tolist(), flags.tolist())) == [(0, 0), (2002, 1), (0, 0), (0, 132), (0, 0), (len(d2), 17)]
+    # the escape flag has no cap (round 5): a body of 70 000 bytes whose only backslash is its last-but-one byte
+    d3 = b'["' + b"a" * 69998 + b'\\n","' + b"b" * 70000 + b'"]'
+    idx3 = _stage1(oracle, d3)
+    end, flags = helpers.oracle_token_spans(d3, idx3)
+    assert list(zip(idx3.tolist(), end.tolist(), flags.tolist())) == [(0, 0, 0), (1, 70002, 3), (70003, 0, 0), (70004, 140005, 1), (140006, 0, 0)]
 
 
 
@@ -71,8 +76,8 @@ def _check_spans_against_reference_scans(data, idx, end, flags):
                 continue
             assert want == e, (i, start, want, e)
             assert start < e < nxt or (e < len(data) and nxt == len(data))
-            if not f & 128:
-                assert bool(f & 2) == esc, (i, start)
+            assert not f & 128  # MSJ_SPAN_LONG is for numbers only
+            assert bool(f & 2) == esc, (i, start)
             lit, _ = helpers.ref_parse_string_end(data, start + 1, 32)
             literal_differs += lit != want
         elif c == 0x2D or 0x30 <= c <= 0x39:
@@ -255,6 +260,24 @@ def test_token_spans(dev, lds_limit, request, span_mode):
     # a long string in the middle of many short tokens: its workgroup reads from global memory, the others stage
     _check_spans(dev, b"[" + b'"a\\b",12,' * 3000 + b'"' + b"x" * 40000 + b'",' + b'"cd",3.5,' * 3000 + b"0]", "mixed paths")
     _check_spans(dev, b'["a"  ,"b\\"" , "c\\\\"  ]  ', "blanks between the closing quote and the next structural")
+    # round 5: the escape flag of a string is exact at ANY length (bodies over 1 024 bytes: a wave per string behind the
+    # span kernel, over 1 MiB the whole grid).  The only backslash at the far end, at the near end, nowhere; bodies
+    # around the old cap, over several tiles / tile groups, and an escaped quote as the body's last bytes
+    for n in (1022, 1023, 1024, 1025, 1026, 4095, 4096, 4097, 12288, 16384, 70000):
+        for body in (b"a" * n, b"a" * (n - 2) + b"\\n", b"\\t" + b"a" * (n - 2), b"a" * (n - 2) + b'\\"', b"a" * (n // 2) + b"\\\\" + b"a" * (n - n // 2 - 2)):
+            assert len(body) == n
+            for pad in (0, 7, 4090):
+                _check_spans(dev, b" " * pad + b'["k",' + b"1," * 100 + b'"' + body + b'" , 5,"x"]', f"string of {n} bytes at {pad}: {body[:3]!r}..{body[-3:]!r}")
+    _check_spans(dev, b"[" + (b'"' + b"a" * 1500 + b'","' + b"b" * 1400 + b"\\n" + b"b" * 98 + b'",') * 300 + b"0]", "600 long strings")
+    big = b"x" * ((1 << 20) + 4097)
+    _check_spans(dev, b'{"blob":"' + big + b'","next":"' + big[:-9] + b"\\u00e9abc" + b'","n":1}', "bodies over 1 MiB: the whole grid per string")
+    _check_spans(dev, b'["' + big * 3 + b"\\\\" + b'"]', "3 MiB, the backslash in the last piece")
+    _check_spans(dev, b'["' + b"\\/" + big * 2 + b'"]', "2 MiB, the backslash in the first piece")
+    # the long-string list overflows (capacity lowered to 3 entries): the marker is found in flags[] itself
+    dev.lib.msj_debug_set_span_limits(dev.ctx, int(lds_limit) if lds_limit else 0xFFFFFFFF, 3)
+    _check_spans(dev, b"[" + (b'"' + b"a" * 1500 + b'","' + b"b" * 1400 + b"\\n" + b"b" * 98 + b'",') * 30 + b"0]", "the long-string list overflows")
+    dev.lib.msj_debug_set_span_limits(dev.ctx, int(lds_limit) if lds_limit else 0xFFFFFFFF, 0xFFFFFFFF)
+    _check_spans(dev, b"[" + (b'"' + b"a" * 1500 + b'","' + b"b" * 1400 + b"\\n" + b"b" * 98 + b'",') * 30 + b"0]", "the lists are clean again")
     # what sends a lane from the one-round evaluation to the general loop: more than 32 blanks / backslashes / digits
     # in a row, a body that crosses the 4 KiB one wave counts backslashes over (with and without an escape in it)
     _check_spans(dev, b'["x"' + b" " * 33 + b',"y"' + b" " * 32 + b',"z"' + b"\n" * 100 + b', 1' + b" " * 70 + b"]" + b" " * 50,
