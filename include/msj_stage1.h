@@ -502,7 +502,17 @@ int32_t msj_stage2_prep_chain_device(msj_ctx *ctx, const uint8_t *d_buf, uint64_
  *   d_prev: the result in front of the shard, or NULL
  * Outputs of segment s start at element offsets[s] = the sum of the counts in front of it, each rounded up to a multiple of 8
  * elements (so that every slice keeps the single calls' alignment); offsets_out (host, n_segments entries, may be NULL) receives them.
- * d_end is relative to the SEGMENT's bytes (like the indices), d_match to the segment's tokens.
+ * d_end is relative to the SEGMENT's bytes (like the indices).
+ * d_match (round 5) is valid over the WHOLE SHARD: for a bracket, the position IN THE SHARD'S OUTPUT ARRAYS (offsets[s] +
+ * the token's index inside its segment: the element at which that token's type / depth / end / flags / match are
+ * stored) of the other end of its container -- also when the container is opened in one segment and closed in a later
+ * one (the stack of start_container / end_container, generic/stage2/tape_builder.mojo:235-272, has no such border):
+ * every segment leaves the brackets it could not pair in a residual list of the context's (their depth is their place
+ * in it), and a stitch behind the last segment pairs them.  0xFFFFFFFF: not a bracket, or no partner inside the shard.
+ * Limits with d_match: at most 32 segments and fewer than 2^32 - 1 output elements (MSJ_CAPACITY otherwise); at a segment
+ * border, partners are stitched for nesting up to 65 536 containers deep -- beyond that the brackets keep 0xFFFFFFFF and
+ * bit 31 of d_results[n_segments - 1].reserved is set.  The single calls (msj_stage2_prep_chain_device,
+ * msj_tokens_chain_device) write into arrays of the caller's for each call and keep their partners local to the call.
  */
 int32_t msj_stage2_prep_segments(msj_ctx *ctx, const uint8_t *d_buf, const msj_segment *segments, uint32_t n_segments,
                                  const uint32_t *d_idx, uint8_t *d_type, int32_t *d_depth, uint32_t *d_match, uint32_t *d_end,

@@ -89,6 +89,8 @@ struct msj_ctx {
     uint64_t tok_doc_n = ~0ull;   // the token count whose document aggregates tok_ws holds (~0: none)
     uint32_t *seg_idx = nullptr;  // msj_stage2_prep_segments: 16-byte aligned copy of a segment's index slice that is not
     uint64_t seg_idx_words = 0;
+    uint32_t *resid = nullptr;    // msj_stage2_prep_segments with d_match: MSJ_RESID_WORDS per segment (the brackets a segment could not pair)
+    uint64_t resid_words = 0;
     msj_token_opts tok_opts;      // test hooks of the token calls (msj_debug_set_span_limits / _span_mode): per context
     void *doc_ws = nullptr;       // block counts of the document split
     uint64_t doc_ws_bytes = 0;
@@ -612,6 +614,7 @@ void msj_ctx_destroy(msj_ctx *ctx) {
     if (ctx->tp) (void)hipFree(ctx->tp);
     if (ctx->tok_ws) (void)hipFree(ctx->tok_ws);
     if (ctx->seg_idx) (void)hipFree(ctx->seg_idx);
+    if (ctx->resid) (void)hipFree(ctx->resid);
     if (ctx->span_fix) (void)hipFree(ctx->span_fix);
     if (ctx->doc_ws) (void)hipFree(ctx->doc_ws);
     if (ctx->carries) (void)hipFree(ctx->carries);
@@ -732,9 +735,20 @@ int32_t msj_stage2_prep_device(msj_ctx *ctx, const uint8_t *d_buf, uint64_t len,
     return msj_stage2_prep_chain_device(ctx, d_buf, len, d_idx, n, d_type, d_depth, d_match, d_end, d_flags, d_result, nullptr, stream);
 }
 
+static int32_t prep_chain_impl(msj_ctx *ctx, const uint8_t *d_buf, uint64_t len, const uint32_t *d_idx, uint64_t n, uint8_t *d_type,
+                               int32_t *d_depth, uint32_t *d_match, uint32_t *d_end, uint8_t *d_flags, msj_tokens_result *d_result,
+                               const msj_tokens_result *d_prev, void *stream, uint32_t match_bias, uint32_t *d_resid);
+
 int32_t msj_stage2_prep_chain_device(msj_ctx *ctx, const uint8_t *d_buf, uint64_t len, const uint32_t *d_idx, uint64_t n,
                                      uint8_t *d_type, int32_t *d_depth, uint32_t *d_match, uint32_t *d_end, uint8_t *d_flags,
                                      msj_tokens_result *d_result, const msj_tokens_result *d_prev, void *stream) {
+    return prep_chain_impl(ctx, d_buf, len, d_idx, n, d_type, d_depth, d_match, d_end, d_flags, d_result, d_prev, stream, 0u, nullptr);
+}
+
+// match_bias / d_resid: msj_stage2_prep_segments (partners as positions in the shard's arrays, the call's unpaired brackets kept)
+static int32_t prep_chain_impl(msj_ctx *ctx, const uint8_t *d_buf, uint64_t len, const uint32_t *d_idx, uint64_t n, uint8_t *d_type,
+                               int32_t *d_depth, uint32_t *d_match, uint32_t *d_end, uint8_t *d_flags, msj_tokens_result *d_result,
+                               const msj_tokens_result *d_prev, void *stream, uint32_t match_bias, uint32_t *d_resid) {
     if (!ctx || !d_result || d_prev == d_result) return MSJ_ERR_BAD_ARGUMENT;
     if (n > 0 && (!d_buf || !d_idx || !d_type || !d_depth || !d_end || !d_flags)) return MSJ_ERR_BAD_ARGUMENT;
     if (len > MSJ_MAX_SEGMENT_BYTES || n >= (1ull << 31)) return MSJ_CAPACITY;
@@ -748,6 +762,8 @@ int32_t msj_stage2_prep_chain_device(msj_ctx *ctx, const uint8_t *d_buf, uint64_
     if (!ensure_span_fix(ctx)) return MSJ_MEMALLOC;
     msj_token_opts o = ctx->tok_opts;
     o.d_prev = d_prev;
+    o.match_bias = match_bias;
+    o.d_resid = d_match ? d_resid : nullptr;
     if (msj_launch_stage2_prep(d_buf, len, d_idx, n, d_type, d_depth, d_match, d_end, d_flags, d_result, ctx->tok_ws, ctx->span_fix, stream, o) != 0)
         return MSJ_ERR_HIP;
     ctx->tok_doc_n = n;
@@ -770,6 +786,28 @@ int32_t msj_stage2_prep_segments(msj_ctx *ctx, const uint8_t *d_buf, const msj_s
             const msj_segment &pv = segments[s - 1];
             if (sg.byte_base != pv.byte_base + pv.byte_len || sg.index_begin != pv.index_begin + pv.count) return MSJ_ERR_BAD_ARGUMENT;
         }
+    }
+    // bracket partners over the whole shard: match[] holds positions in the shard's output arrays (uint32), every
+    // segment leaves its unpaired brackets in a residual list of the context's, a stitch pairs them at the end
+    msj_stitch_args st_args;
+    st_args.n_segments = n_segments;
+    if (d_match) {
+        if (n_segments > MSJ_STITCH_MAX_SEGMENTS) return MSJ_CAPACITY;
+        uint64_t total = 0;
+        for (uint32_t s = 0; s < n_segments; s++) total = (((total + segments[s].count + 3u) & ~3ull) + 7u) & ~7ull;
+        if (total >= 0xFFFFFFFFull) return MSJ_CAPACITY;  // (0xFFFFFFFF is "no partner")
+        const uint64_t need = (uint64_t)n_segments * MSJ_RESID_WORDS;
+        if (need > ctx->resid_words) {
+            if (ctx->resid) {
+                (void)hipDeviceSynchronize();
+                (void)hipFree(ctx->resid);
+            }
+            ctx->resid = nullptr;
+            ctx->resid_words = 0;
+            if (!hip_ok(hipMalloc(reinterpret_cast<void **>(&ctx->resid), need * sizeof(uint32_t)))) return MSJ_MEMALLOC;
+            ctx->resid_words = need;
+        }
+        if (!hip_ok(hipMemsetAsync(ctx->resid, 0, need * sizeof(uint32_t), st))) return MSJ_ERR_HIP;
     }
     uint64_t off = 0;
     for (uint32_t s = 0; s < n_segments; s++) {
@@ -794,14 +832,20 @@ int32_t msj_stage2_prep_segments(msj_ctx *ctx, const uint8_t *d_buf, const msj_s
             idx = ctx->seg_idx;
         }
         if (offsets_out) offsets_out[s] = off;
-        const int32_t rc = msj_stage2_prep_chain_device(ctx, d_buf + (sg.byte_base - base0), sg.byte_len, idx, n, d_type ? d_type + off : nullptr,
-                                                        d_depth ? d_depth + off : nullptr, d_match ? d_match + off : nullptr,
-                                                        d_end ? d_end + off : nullptr, d_flags ? d_flags + off : nullptr, &d_results[s],
-                                                        s == 0 ? d_prev : &d_results[s - 1], stream);
+        uint32_t *resid = d_match ? ctx->resid + (uint64_t)s * MSJ_RESID_WORDS : nullptr;
+        if (d_match) {
+            st_args.offsets[s] = (uint32_t)off;
+            st_args.resid[s] = resid;
+        }
+        const int32_t rc = prep_chain_impl(ctx, d_buf + (sg.byte_base - base0), sg.byte_len, idx, n, d_type ? d_type + off : nullptr,
+                                           d_depth ? d_depth + off : nullptr, d_match ? d_match + off : nullptr,
+                                           d_end ? d_end + off : nullptr, d_flags ? d_flags + off : nullptr, &d_results[s],
+                                           s == 0 ? d_prev : &d_results[s - 1], stream, (uint32_t)off, resid);
         if (rc != MSJ_SUCCESS) return rc;
         off += (n + 3u) & ~3ull;  // every segment's slices start 16-byte aligned (8 for the byte arrays: n rounded to 4 ... 8 below)
         off = (off + 7u) & ~7ull;
     }
+    if (d_match && msj_launch_stitch_partners(st_args, d_match, d_results, d_prev, stream) != 0) return MSJ_ERR_HIP;
     return MSJ_SUCCESS;
 }
 

@@ -194,7 +194,8 @@ __global__ __launch_bounds__(256) void scan_super(const int32_t *__restrict__ bl
 constexpr int kScanPer = 8;
 __global__ __launch_bounds__(1024) void scan_blocks(const int32_t *__restrict__ block_agg, uint32_t nblocks, int32_t *__restrict__ block_start,
                                                     uint32_t *__restrict__ open_start, msj_tokens_result *__restrict__ result, uint64_t n,
-                                                    const msj_tokens_result *__restrict__ prev, uint32_t *__restrict__ survivors) {
+                                                    const msj_tokens_result *__restrict__ prev, uint32_t *__restrict__ survivors,
+                                                    uint32_t *__restrict__ resid) {
     __shared__ Agg wave_agg[16];
     __shared__ uint32_t wave_opens[16];
     __shared__ Agg carry;
@@ -288,6 +289,7 @@ __global__ __launch_bounds__(1024) void scan_blocks(const int32_t *__restrict__ 
     }
     // apply_depth<true> appends the opening brackets it could not pair inside their block: one counter per list shard
     if (survivors && threadIdx.x < kSurvivorShards) survivors[threadIdx.x * kSurvivorStride] = 0u;
+    if (resid && threadIdx.x < 4) resid[threadIdx.x] = 0u;  // the counts of this call's residual brackets (match_brackets, collect_closers)
 }
 
 // (3) depth of every token -- and, kMatch, the partner of every bracket whose container closes inside the block:
@@ -311,7 +313,8 @@ __global__ __launch_bounds__(kThreads) void apply_depth(const uint8_t *__restric
                                                         int32_t *__restrict__ min512, const uint32_t *__restrict__ open_start,
                                                         uint32_t *__restrict__ opens, uint4 *__restrict__ doc_agg,
                                                         int32_t *__restrict__ block_mm, const msj_tokens_result *__restrict__ prev,
-                                                        uint32_t *__restrict__ match, uint32_t *__restrict__ survivors) {
+                                                        uint32_t *__restrict__ match, uint32_t *__restrict__ survivors, uint32_t match_bias,
+                                                        uint32_t want_closers) {
     __shared__ uint32_t bm[kMatch ? kMatchLevels : 1][kMatch ? kBlock / 32 : 1];  // opening brackets per level, one bit per token
     __shared__ unsigned long long bm_words[kMatch ? kMatchLevels : 1];              // ... and which of a level's 64 words are not empty
     __shared__ __attribute__((aligned(16))) uint32_t s_match[kMatch ? kBlock : 4];
@@ -370,7 +373,7 @@ __global__ __launch_bounds__(kThreads) void apply_depth(const uint8_t *__restric
         }
     }
     bool surv_any = false;
-    uint32_t surv_incl = 0, surv_slot = 0, surv_mine = 0, surv_mask = 0;
+    uint32_t surv_incl = 0, surv_slot = 0, surv_mine = 0, surv_mask = 0, cand_mask = 0;
     if (kMatch) {
         const int level0 = block_depth0 - kMatchBelow;
         const uint32_t t0 = 8u * threadIdx.x;  // this thread's first token inside the block
@@ -406,6 +409,9 @@ __global__ __launch_bounds__(kThreads) void apply_depth(const uint8_t *__restric
                 rem &= rem - 1u;
                 // a closing bracket sits at the depth of its container: one below the running depth in front of it
                 const uint32_t lv = (uint32_t)(before0 + (int)__builtin_popcount(om & below) - (int)__builtin_popcount(cm & below) - 1 - level0);
+                // a closing bracket BELOW the depth at the block's start: if nothing in the block pairs with it, its partner
+                // is in an earlier block -- or in front of this CALL (the residuals of msj_stage2_prep_segments)
+                if ((int)lv < kMatchBelow) cand_mask |= 1u << k;
                 if (lv < (uint32_t)kMatchLevels) {
                     const uint32_t t = t0 + k, w = t >> 5;
                     uint32_t m = bm[lv][w] & ((1u << (t & 31u)) - 1u);
@@ -419,7 +425,7 @@ __global__ __launch_bounds__(kThreads) void apply_depth(const uint8_t *__restric
                     }
                     if (m != 0u) {
                         const uint32_t i = 32u * wi + 31u - (uint32_t)__clz((int)m);
-                        const uint32_t blk0 = blockIdx.x * kBlock;  // token indices are < 2^31
+                        const uint32_t blk0 = blockIdx.x * kBlock + match_bias;  // token indices are < 2^31; + the call's place in the shard
                         s_match[t] = blk0 + i;
                         s_match[i] = blk0 + t;
                         atomicOr(&s_paired[w], 1u << (t & 31u));
@@ -432,6 +438,9 @@ __global__ __launch_bounds__(kThreads) void apply_depth(const uint8_t *__restric
         // (d) the opening brackets nobody claimed: to the list match_brackets works through (any order)
         // (the thread's eight tokens are one byte of a word of s_paired)
         surv_mask = om & ~(s_paired[t0 >> 5] >> (t0 & 31u));
+        // ... and (a shard call only) the closing brackets below the block's start depth that nothing in the block paired:
+        // bits 8..15, listed with bit 31 set; match_brackets skips them, collect_closers keeps those still unpaired
+        if (want_closers) surv_mask |= (cand_mask & ~(s_paired[t0 >> 5] >> (t0 & 31u)) & 0xFFu) << 8;
         const uint32_t mine = (uint32_t)__builtin_popcount(surv_mask);
         // the slot is DRAWN here (one returning atomic per wave that has any) and USED at the very end of the kernel: its
         // round trip overlaps the stores of match[] and depth[] and the aggregates below
@@ -561,6 +570,11 @@ __global__ __launch_bounds__(kThreads) void apply_depth(const uint8_t *__restric
 #pragma unroll
         for (int k = 0; k < kPer; k++)
             if ((surv_mask >> k) & 1u) list[slot++] = (uint32_t)(base + k);
+        if (surv_mask >> 8) {
+#pragma unroll
+            for (int k = 0; k < kPer; k++)
+                if ((surv_mask >> (8 + k)) & 1u) list[slot++] = (uint32_t)(base + k) | 0x80000000u;
+        }
     }
 }
 
@@ -683,7 +697,8 @@ __device__ __forceinline__ uint32_t first_le(const int v[8], uint32_t from, int 
 constexpr uint32_t kLinear = MSJ_MATCH_LINEAR, kGroup = 8, kSteps = 8;  // 64 tokens per group and round
 __global__ __launch_bounds__(256) void match_brackets(const uint8_t *__restrict__ type, const uint32_t *__restrict__ opens,
                                                       const uint32_t *__restrict__ n_opens, const MinTree t,
-                                                      uint32_t *__restrict__ match, uint64_t list_capacity) {
+                                                      uint32_t *__restrict__ match, uint64_t list_capacity, uint32_t match_bias,
+                                                      const msj_tokens_result *__restrict__ result, uint32_t *__restrict__ resid) {
     // one list per blockIdx.y (kSurvivorShards of them), the lane groups of its workgroups stride over it
     const uint32_t total = n_opens[blockIdx.y * kSurvivorStride];
     opens += (uint64_t)blockIdx.y * list_capacity;
@@ -693,8 +708,9 @@ __global__ __launch_bounds__(256) void match_brackets(const uint8_t *__restrict_
     const uint64_t wave0 = ((uint64_t)blockIdx.x * 4u + (threadIdx.x >> 6)) * per_wave, stride = (uint64_t)gridDim.x * 4u * per_wave;
     for (uint64_t w0 = wave0; w0 < total; w0 += stride) {  // uniform per wave
         const uint64_t w = w0 + grp;
-        const bool have = w < total;
-        const uint32_t i = have ? opens[w] : 0u;
+        const uint32_t entry = w < total ? opens[w] : 0x80000000u;
+        const bool have = (entry >> 31) == 0u;  // (bit 31: a closing bracket listed for collect_closers)
+        const uint32_t i = have ? entry : 0u;
         const int target = have ? t.lv[0][i] : kNone;
         uint32_t pos = i + 1u;
         bool found = false;
@@ -768,11 +784,76 @@ __global__ __launch_bounds__(256) void match_brackets(const uint8_t *__restrict_
         if (have && found && sub == 0u) {
             const uint32_t cj = type[pos];
             if (cj == '}' || cj == ']') {
-                match[i] = pos;
-                match[pos] = i;
+                match[i] = pos + match_bias;
+                match[pos] = i + match_bias;
             }
+        } else if (have && sub == 0u && resid) {
+            // never closed inside this call: the unclosed opening brackets nest, so the one at depth `target` is entry
+            // final_depth - 1 - target of the call's residual list (msj_stage2_prep_segments stitches the segments)
+            const uint32_t j = (uint32_t)(result->final_depth - 1 - target);
+            atomicAdd(&resid[0], 1u);
+            if (j < MSJ_RESID_CAP) resid[4u + j] = i;
         }
     }
+}
+
+// ---- residuals: bracket partners over a whole shard (msj_stage2_prep_segments; the stack of start_container /
+// end_container, generic/stage2/tape_builder.mojo:235-272, has no segment border).  A call pairs what closes inside it.
+// What is left are (a) opening brackets never closed in the call -- match_brackets finds them: the walk of a survivor
+// that reaches the call's end -- and (b) closing brackets whose partner is in front of the call: among the listed
+// candidates (apply_depth: below the block's start depth, unpaired in the block) those that match_brackets, which
+// writes both ends, has not touched either.  Both sets nest, so the bracket's DEPTH is its place in the list: no
+// sorting, no counting pass.  stitch_partners then pairs closing bracket k of segment s (depth c) with the unclosed
+// opening bracket at depth c of the latest segment in front that holds one.
+__global__ __launch_bounds__(256) void collect_closers(const uint32_t *__restrict__ opens, const uint32_t *__restrict__ n_opens,
+                                                       uint64_t list_capacity, const int32_t *__restrict__ depth,
+                                                       const uint32_t *__restrict__ match, const msj_tokens_result *__restrict__ prev,
+                                                       uint32_t *__restrict__ resid) {
+    const uint32_t total = n_opens[blockIdx.y * kSurvivorStride];
+    opens += (uint64_t)blockIdx.y * list_capacity;
+    const int d0 = prev ? prev->final_depth : 0;
+    for (uint64_t w = (uint64_t)blockIdx.x * 256u + threadIdx.x; w < total; w += (uint64_t)gridDim.x * 256u) {
+        const uint32_t entry = opens[w];
+        if (!(entry >> 31)) continue;
+        const uint32_t i = entry & 0x7FFFFFFFu;
+        if (match[i] != 0xFFFFFFFFu) continue;  // an opening bracket of an earlier block of this call claimed it
+        const uint32_t k = (uint32_t)(d0 - 1 - depth[i]);
+        atomicAdd(&resid[1], 1u);
+        if (k < MSJ_RESID_CAP) resid[4u + MSJ_RESID_CAP + k] = i;
+    }
+}
+
+__global__ __launch_bounds__(256) void stitch_partners(const msj_stitch_args a, uint32_t *__restrict__ match,
+                                                       msj_tokens_result *__restrict__ results, const msj_tokens_result *__restrict__ prev) {
+    const uint32_t s = blockIdx.x + 1u;  // segment 0 has nothing in front of it inside the shard
+    if (s >= a.n_segments) return;
+    const uint32_t *rs = a.resid[s];
+    const uint32_t n_close = rs[1];
+    bool clipped = n_close > MSJ_RESID_CAP;
+    const int d0 = results[s - 1].final_depth;  // the depth this segment starts at
+    for (uint32_t k = threadIdx.x; k < n_close && k < MSJ_RESID_CAP; k += 256u) {
+        const int c = d0 - 1 - (int)k;  // the closing bracket's depth = its container's
+        const uint32_t ci = rs[4u + MSJ_RESID_CAP + k];
+        for (int q = (int)s - 1; q >= 0; q--) {
+            const uint32_t *rq = a.resid[q];
+            const int df = results[q].final_depth, nu = (int)rq[0];
+            if (c < df && c >= df - nu) {  // segment q left an opening bracket at this depth open
+                const uint32_t j = (uint32_t)(df - 1 - c);
+                if (j < MSJ_RESID_CAP) {
+                    const uint32_t oi = rq[4u + j];
+                    match[a.offsets[s] + ci] = a.offsets[q] + oi;
+                    match[a.offsets[q] + oi] = a.offsets[s] + ci;
+                } else {
+                    clipped = true;
+                }
+                break;
+            }
+            // (else: segment q closed that level again or never reached it: look further in front; below every
+            //  segment's levels the partner lies in front of the shard and the bracket keeps 0xFFFFFFFF)
+        }
+    }
+    (void)prev;
+    if (clipped) atomicOr(&results[a.n_segments - 1u].reserved, 0x80000000u);  // nesting deeper than MSJ_RESID_CAP at a border
 }
 
 }  // namespace msj_tokens
@@ -833,8 +914,9 @@ static int launch_depth_passes(const uint32_t *d_idx, uint64_t n, uint8_t *d_typ
     int32_t *super_agg = d_ws + block_words(n), *super_start = super_agg + 4 * (uint64_t)nsuper;
     uint32_t *super_open = reinterpret_cast<uint32_t *>(super_start + nsuper);
     if (nb) hipLaunchKernelGGL(scan_super, dim3(nsuper), dim3(256), 0, s, agg, nb, start, open_start, super_agg);
+    uint32_t *resid = want_match ? o.d_resid : nullptr;
     hipLaunchKernelGGL(scan_blocks, dim3(1), dim3(1024), 0, s, super_agg, nb ? nsuper : 0u, super_start, super_open, d_result, n, o.d_prev,
-                       survivors);
+                       survivors, resid);
     // levels of the min tree: 1..3 come out of apply_depth, the rest from build_level
     MinTree t;
     t.lv[0] = d_depth;
@@ -858,10 +940,10 @@ static int launch_depth_passes(const uint32_t *d_idx, uint64_t n, uint8_t *d_typ
     int32_t *l3 = want_match ? (t.nlev > 3 ? lvl[3] : tree + tree_words(n) + 40) : nullptr;
     if (nb && want_match)
         hipLaunchKernelGGL(apply_depth<true>, dim3(nb), dim3(kThreads), 0, s, d_type, n, start, super_start, super_open, d_depth, l1, l2, l3,
-                           open_start, opens, doc_agg, agg, o.d_prev, d_match, survivors);
+                           open_start, opens, doc_agg, agg, o.d_prev, d_match, survivors, o.match_bias, resid ? 1u : 0u);
     else if (nb)
         hipLaunchKernelGGL(apply_depth<false>, dim3(nb), dim3(kThreads), 0, s, d_type, n, start, super_start, super_open, d_depth, l1, l2, l3,
-                           open_start, opens, doc_agg, agg, o.d_prev, d_match, survivors);
+                           open_start, opens, doc_agg, agg, o.d_prev, d_match, survivors, 0u, 0u);
     if (nb) hipLaunchKernelGGL(min_max_depth, dim3(nb < kMinMaxGroups * 256u ? (nb + 255u) / 256u : kMinMaxGroups), dim3(256), 0, s, agg, nb, d_result);
     if (want_match) {
         for (int k = 4; k < t.nlev && k < 6; k++)
@@ -884,7 +966,10 @@ static int launch_depth_passes(const uint32_t *d_idx, uint64_t n, uint8_t *d_typ
         const uint32_t lists = nb < kSurvivorShards ? nb : kSurvivorShards;
         const uint32_t per_list = nb / kSurvivorShards / 8u + 1u;  // ~2 survivors per block, 16 brackets per workgroup and round
         hipLaunchKernelGGL(match_brackets, dim3(per_list < MSJ_MATCH_GRID ? per_list : MSJ_MATCH_GRID, lists), dim3(256), 0, s, d_type, opens,
-                           survivors, t, d_match, survivor_capacity(nb));
+                           survivors, t, d_match, survivor_capacity(nb), o.match_bias, d_result, resid);
+        if (resid)  // the closing brackets whose partner lies in front of this call (behind match_brackets: it writes both ends)
+            hipLaunchKernelGGL(collect_closers, dim3(per_list < 8u ? per_list : 8u, lists), dim3(256), 0, s, opens, survivors, survivor_capacity(nb),
+                               d_depth, d_match, o.d_prev, resid);
     }
     return (int)hipGetLastError();
 }
@@ -2258,4 +2343,12 @@ int msj_launch_tokens(const uint8_t *d_buf, uint64_t len, const uint32_t *d_idx,
         hipLaunchKernelGGL(merge_chunk_counts, dim3((nb * 16u + 255u) / 256u), dim3(256), 0, s, sub, (uint32_t)chunk_count(n), d_ws, nb);
     }
     return launch_depth_passes(d_idx, n, d_type, d_depth, d_match, d_result, d_ws, s, o);
+}
+
+int msj_launch_stitch_partners(const msj_stitch_args &a, uint32_t *d_match, msj_tokens_result *d_results, const msj_tokens_result *d_prev,
+                               void *stream) {
+    if (a.n_segments < 2u) return 0;
+    hipLaunchKernelGGL(msj_tokens::stitch_partners, dim3(a.n_segments - 1u), dim3(256), 0, static_cast<hipStream_t>(stream), a, d_match, d_results,
+                       d_prev);
+    return (int)hipGetLastError();
 }

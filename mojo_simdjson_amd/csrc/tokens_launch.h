@@ -15,7 +15,26 @@ struct msj_token_opts {
     // a stream: the running depth walk_document keeps (json_iterator.mojo:84-90,173-180) goes on from its final_depth,
     // and this call's min / max / final are those of the stream so far
     const msj_tokens_result *d_prev = nullptr;
+    // msj_stage2_prep_segments (bracket partners over a whole shard): match[] values are positions in the SHARD's output
+    // arrays -- this call's token index + match_bias -- and the brackets this call could not pair (their container is cut
+    // by the call's border) are left in d_resid for the stitch behind the last segment (tokens_kernel.hip, "residuals")
+    uint32_t match_bias = 0;
+    uint32_t *d_resid = nullptr;
 };
+
+// residual brackets of one call (device, uint32 words): [0] unclosed opening brackets, [1] closing brackets without a
+// partner, [2..3] spare; then MSJ_RESID_CAP positions of the former -- entry j = the one at depth final_depth - 1 - j --
+// and MSJ_RESID_CAP of the latter -- entry k = the one at depth start_depth - 1 - k (token indices local to the call)
+#define MSJ_RESID_CAP 65536u
+#define MSJ_RESID_WORDS (4u + 2u * MSJ_RESID_CAP)
+#define MSJ_STITCH_MAX_SEGMENTS 32u
+struct msj_stitch_args {
+    uint32_t n_segments;
+    uint32_t offsets[MSJ_STITCH_MAX_SEGMENTS];       // element offset of every segment's slices in the shard's output arrays
+    const uint32_t *resid[MSJ_STITCH_MAX_SEGMENTS];  // its residual brackets
+};
+int msj_launch_stitch_partners(const msj_stitch_args &a, uint32_t *d_match, msj_tokens_result *d_results, const msj_tokens_result *d_prev,
+                               void *stream);
 
 extern "C" uint64_t msj_tokens_workspace_bytes(uint64_t n, int with_match);
 extern "C" uint64_t msj_stage2_prep_workspace_bytes(uint64_t n, uint64_t len, int with_match);

@@ -622,7 +622,14 @@ def test_prep_segments_of_one_shard(dev):
         assert any(s[2] % 4 for s in segs[1:]), "the test wants a slice off the 16-byte grid"
         offs, t, d, m, e, f, results = dev.stage2_prep_segments(d_buf, segs, d_idx, match=True)
         idx_all = d_idx.cpu().numpy().view(np.uint32)
-        depth0, mn_all, mx_all = 0, None, None
+        # partners over the WHOLE shard (round 5): the definition on the document's token stream, every index mapped to
+        # its position in the shard's output arrays (the document's root object spans all eight segments)
+        n_all = sum(sg[3] for sg in segs)
+        pos_of = np.concatenate([offs[s] + np.arange(sg[3], dtype=np.int64) for s, sg in enumerate(segs)])
+        wt_all, _, _ = helpers.oracle_tokens(data, np.concatenate([idx_all[sg[2]:sg[2] + sg[3]] + np.uint32(sg[0]) for sg in segs]))
+        wm_all = helpers.oracle_match(wt_all).astype(np.int64)
+        want_pos = np.where(wm_all == 0xFFFFFFFF, 0xFFFFFFFF, pos_of[np.minimum(wm_all, n_all - 1)])
+        depth0, mn_all, mx_all, stitched = 0, None, None, 0
         for s, (bb, bl, ib, cnt) in enumerate(segs):
             piece = data[bb:bb + bl]
             idx = idx_all[ib:ib + cnt]
@@ -632,7 +639,9 @@ def test_prep_segments_of_one_shard(dev):
             where = f"segment {s}"
             assert np.array_equal(t[o:o + cnt].cpu().numpy(), wt), where
             assert np.array_equal(d[o:o + cnt].cpu().numpy(), wd + depth0), where
-            assert np.array_equal(m[o:o + cnt].cpu().numpy().view(np.uint32), helpers.oracle_match(wt)), where
+            got_m = m[o:o + cnt].cpu().numpy().view(np.uint32).astype(np.int64)
+            assert np.array_equal(got_m, want_pos[ib - segs[0][2]:ib - segs[0][2] + cnt]), where
+            stitched += int(((helpers.oracle_match(wt).astype(np.int64) == 0xFFFFFFFF) & (got_m != 0xFFFFFFFF)).sum())
             assert np.array_equal(f[o:o + cnt].cpu().numpy(), wf) and np.array_equal(e[o:o + cnt].cpu().numpy().view(np.uint32), we), where
             mn_all = depth0 + mn if mn_all is None else min(mn_all, depth0 + mn)
             mx_all = depth0 + mx if mx_all is None else max(mx_all, depth0 + mx)
@@ -640,6 +649,20 @@ def test_prep_segments_of_one_shard(dev):
             r = results[s]
             assert (r.n, r.final_depth, r.min_depth, r.max_depth) == (cnt, depth0, mn_all, mx_all), where
         assert depth0 == 0  # the document is closed at the end of the shard
+        assert int((want_pos != 0xFFFFFFFF).sum()) == int((wm_all != 0xFFFFFFFF).sum()) and results[-1].reserved >> 31 == 0
+        assert stitched >= 2 * 7 and stitched % 2 == 0, stitched  # brackets whose partner lies in another segment
+        # ... and a shard that starts and ends in the middle of things: segments 2 .. 6 alone (closing brackets whose
+        # partners lie in front of the shard and opening ones never closed keep 0xFFFFFFFF; everything between pairs up)
+        sub = segs[2:7]
+        d_prev = torch.zeros(24, dtype=torch.uint8, device=dev.device)
+        offs2, t2, d2, m2, e2, f2, res2 = dev.stage2_prep_segments(d_buf[sub[0][0]:], sub, d_idx[sub[0][2]:], match=True, d_prev=None)
+        lo_tok, hi_tok = sub[0][2] - segs[0][2], sub[-1][2] + sub[-1][3] - segs[0][2]
+        wm_sub = helpers.oracle_match(wt_all[lo_tok:hi_tok]).astype(np.int64)
+        pos2 = np.concatenate([offs2[s] + np.arange(sg[3], dtype=np.int64) for s, sg in enumerate(sub)])
+        want2 = np.where(wm_sub == 0xFFFFFFFF, 0xFFFFFFFF, pos2[np.minimum(wm_sub, hi_tok - lo_tok - 1)])
+        got2 = np.concatenate([m2[offs2[s]:offs2[s] + sg[3]].cpu().numpy().view(np.uint32).astype(np.int64) for s, sg in enumerate(sub)])
+        assert np.array_equal(got2, want2)
+        assert int((want2 == 0xFFFFFFFF).sum()) > int((wm_all[lo_tok:hi_tok] == 0xFFFFFFFF).sum())  # some really are cut off
     finally:
         assert L.msj_debug_set_segment_bytes(dev.ctx, 0xFFFF0000) == 0
 
@@ -651,7 +674,8 @@ def test_prep_segments_over_4gib(dev):
     over the cut on the device), spans, partners of 0.9 G tokens, compared ON THE DEVICE with the definition by the
     replication property: a unit is a complete document, so token j of repetition k has the unit's type / depth / flags,
     the unit's end + k * unit_len (relative to its segment's first byte) and the unit's partner + k * unit_tokens
-    (relative to its segment's first token; a container cut by the segment border has no partner in either part)."""
+    (as a position in the shard's output arrays: round 5 -- a container opened in segment 0 and closed in segment 1 has
+    its partner like any other)."""
     import torch
     from mojo_simdjson_amd import synth
 
@@ -689,6 +713,7 @@ def test_prep_segments_over_4gib(dev):
     g_start = torch.from_numpy(idx_u.astype(np.int64)).to(dv)
     g_next = torch.cat([g_start[1:], torch.tensor([L], dtype=torch.int64, device=dv)])  # where the token's extent ends
     NONE = 0xFFFFFFFF
+    crossing = 0
     for k in range(reps):
         J0 = k * nu  # global token index of the repetition's first token
         for s, (bb, bl, ib, cnt) in enumerate(segs):
@@ -707,10 +732,16 @@ def test_prep_segments_over_4gib(dev):
             want_e = torch.where(g_e[r0:r1] != 0, g_e[r0:r1] + k * L - bb, torch.zeros_like(start_g))
             assert torch.equal(got_f[inside], g_f[r0:r1][inside]) and torch.equal(got_e[inside], want_e[inside]), where
             assert int((~inside).sum()) <= 1, where
-            # partners: global index of the unit's partner, local to the segment, none when it lies in the other one
+            # partners (round 5: valid over the whole shard): the position in the shard's output arrays of the unit's
+            # partner -- also for the containers the segment border cuts (the unit's root array among them)
             pg = g_m[r0:r1] + J0
             has = g_m[r0:r1] != NONE
-            same = has & (pg >= ib) & (pg < ib + cnt)
-            want_m = torch.where(same, pg - ib, torch.full_like(pg, NONE))
+            pos = torch.full_like(pg, NONE)
+            for s2, (_, _, ib2, cnt2) in enumerate(segs):
+                in2 = has & (pg >= ib2) & (pg < ib2 + cnt2)
+                pos = torch.where(in2, pg - ib2 + offs[s2], pos)
             got_m = m[o:o + hi - lo].to(torch.int64) & 0xFFFFFFFF
-            assert torch.equal(got_m, want_m), where
+            assert torch.equal(got_m, pos), where
+            crossing += int((has & ((pg < ib) | (pg >= ib + cnt))).sum())
+    assert crossing >= 4 and crossing % 2 == 0, crossing  # the cut lies inside a unit: its root object and array at least
+    assert results[1].reserved >> 31 == 0
