@@ -157,6 +157,8 @@ class _HostOps:
         self.bufs = {}
         self.launches = 0
         self.fail_at = None  # launch number (1-based) whose run_shard fails
+        self.poison_next = False  # the next launch WITHOUT MSJ_FLAG_TWO_PASS reports an expired wait (internal_error) and garbage
+        self.two_pass_launches = 0
         O = sharded.MsjShardedOps
         f = dict(O._fields_)
         self.alloc = f["alloc"](self._alloc)
@@ -186,6 +188,15 @@ class _HostOps:
             return -3
         data = ctypes.string_at(d_shard, length)
         cin = MsjCarry.from_address(d_in)
+        if flags & 0x100:  # MSJ_FLAG_TWO_PASS: what the library re-issues a poisoned launch through
+            self.two_pass_launches += 1
+        elif self.poison_next:
+            # a single-pass launch whose inter-workgroup wait expired: internal_error set, everything else untrustworthy
+            self.poison_next = False
+            out = MsjCarry.from_address(d_out)
+            ctypes.memset(d_out, 0, ctypes.sizeof(MsjCarry))
+            out.internal_error, out.count, out.bytes, out.in_string = 1, 12345, cin.bytes + length, 1
+            return 0
         idx, bad, esc, instr, pnq = serial_run(data, cin.next_is_escaped, cin.in_string, cin.prev_scalar)
         out = MsjCarry.from_address(d_out)
         ctypes.memset(d_out, 0, ctypes.sizeof(MsjCarry))
@@ -409,6 +420,8 @@ def _live_worker(rank, world, port, cases, q, deferred=False):
         for case in cases:
             data_hex, cuts = case[0], case[1]
             short = case[2] if len(case) > 2 else None  # (rank, capacity): that rank's index buffer is too small
+            if len(case) > 3 and case[3] == rank:       # this rank's first launch of the case is poisoned (an expired wait)
+                host.poison_next = True
             data = bytes.fromhex(data_hex)
             lo, hi = cuts[rank], cuts[rank + 1]
             # the "device" holds the 64-byte halo in front of the shard, like a placed shard does
@@ -446,7 +459,7 @@ def _live_worker(rank, world, port, cases, q, deferred=False):
                                              2 * len(data), int(rank > 0), None, None, 0, None, 0, ctypes.byref(ticket))
             assert rc == -3, rc
         host.fail_at = None
-        q.put((rank, results, int(L.msj_sharded_reruns(h)), int(L.msj_sharded_rounds(h))))
+        q.put((rank, results, int(L.msj_sharded_reruns(h)), int(L.msj_sharded_rounds(h)), host.two_pass_launches))
         L.msj_sharded_destroy(h)
     finally:
         dist.destroy_process_group()
@@ -574,3 +587,89 @@ def test_gloo_world2_live_protocol(deferred):
         total_reruns = res[1][1]
     assert res[0][1] == 0 and res[1][1] == total_reruns and total_reruns >= 2  # the refuted-guess cases did re-run
     assert res[0][2] == res[1][2] == len(cases) + total_reruns  # one all-gather per launch round, on every rank
+
+
+def test_gloo_world8_live_protocol():
+    """the live C protocol at WORLD 8 -- eight separate processes over gloo, each on the
+    asynchronous fake device (_DeferredOps: streams that run only when somebody waits, events, the exchange on its own
+    stream) with three submissions in flight, the way bench.py drives eight GPUs.  Streams of random text cut into eight
+    shards at arbitrary bytes; a rank in the MIDDLE of the chain whose in-string guess is refuted (it indexes again, the
+    ranks behind it only re-contribute); a rank whose launch is POISONED (an expired wait: internal_error) -- it goes
+    through MSJ_FLAG_TWO_PASS, and the ranks behind it, whose carries the replay could not judge, are verified in the
+    next round; both in one stream.  Every rank's indices, placement, carry-in and the stream's code against the serial
+    spec of the whole stream."""
+    world = 8
+    rng = random.Random(88)
+    alphabets = [b'\\\\\\""a1 ,:[]{}', b'{}[]:,"\\ abtrue1.5e\n', b'"xyz\\" \t:,', b'{"k":"v w","n":[1,2.5e3,true,null]} ']
+
+    def cuts_of(n, forced=()):
+        while True:
+            inner = sorted(set(list(forced) + [rng.randint(70, n - 70) for _ in range(world - 1 - len(forced))]))
+            c = [0] + inner + [n]
+            if len(c) == world + 1 and all(b - a >= 66 for a, b in zip(c[:-1], c[1:])):
+                return c
+
+    cases = []
+    for trial in range(20):
+        a = alphabets[trial % len(alphabets)]
+        data = bytes(rng.choice(a) for _ in range(rng.randint(900, 1600)))
+        cases.append((data, cuts_of(len(data)), None, None))
+    # rank 4's shard starts inside a string whose closing quote is followed by ':' (the neighbour rule guesses "outside")
+    filler = b'{"k":[1,2,3],"m":"v"},'
+    pre = b"[" + filler * 25
+    refuted = pre + b'"' + b"a" * 90 + b':",1,2,"ee",' + filler * 30 + b"0]"
+    cut4 = len(pre) + 40
+    c = cuts_of(len(refuted))
+    c = sorted(set([0, len(refuted), cut4] + [v for v in c[1:-1] if abs(v - cut4) >= 70][:world - 2]))
+    while len(c) < world + 1:  # (fill up deterministically if a random cut fell too close)
+        v = rng.randint(70, len(refuted) - 70)
+        if all(abs(v - u) >= 70 for u in c):
+            c = sorted(c + [v])
+    k4 = c.index(cut4)
+    refuted_case = len(cases)
+    cases.append((refuted, c, None, None))
+    # a poisoned launch on rank 5 of an ordinary stream ...
+    data = bytes(rng.choice(alphabets[3]) for _ in range(1400))
+    poisoned_case = len(cases)
+    cases.append((data, cuts_of(len(data)), None, 5))
+    # ... and both at once: the refuted rank in front of the poisoned one
+    both_case = len(cases)
+    cases.append((refuted, c, None, min(world - 1, k4 + 2)))
+    # CAPACITY on one rank of eight
+    dense = b"[" * 400 + b"1" + b"]" * 400
+    cap_case = len(cases)
+    cases.append((dense, [0, 100, 200, 300, 400, 500, 600, 700, len(dense)], (3, 50), None))
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    payload = [(cs[0].hex(), cs[1], cs[2], cs[3]) for cs in cases]
+    procs = [ctx.Process(target=_live_worker, args=(r, world, port, payload, q, True)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = dict((r[0], r[1:]) for r in (q.get(timeout=300) for _ in range(world)))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for k, (data, cuts, short, poison) in enumerate(cases):
+        idx, bad, esc, instr, pnq = serial_run(data)
+        want_code = 15 if instr else 14 if bad else 13 if not idx else 0
+        rows = [res[r][0][k] for r in range(world)]
+        assert all(row[1] == len(idx) for row in rows), k  # the stream's total on every rank
+        if k == cap_case:
+            assert all(row[0] == 1 for row in rows), [row[0] for row in rows]  # CAPACITY, whichever rank clipped
+            continue
+        assert all(row[0] == want_code for row in rows), (k, [row[0] for row in rows], want_code)
+        assert sum((row[2] for row in rows), []) == idx, f"case {k}"
+        for r, row in enumerate(rows):
+            assert row[6] == sum(1 for v in idx if v < cuts[r]), (k, r)          # index_begin of the stitched array
+            assert row[3] == (serial_state(data[:cuts[r]]) if r else (0, 0, 0)), (k, r)  # the carry the shard was indexed with
+        if want_code in (0, 13):
+            assert rows[-1][5] == [len(data), len(data), 0]
+    reruns = [res[r][1] for r in range(world)]
+    two_pass = [res[r][3] for r in range(world)]
+    rounds = [res[r][2] for r in range(world)]
+    p2 = min(world - 1, k4 + 2)
+    assert sum(two_pass) == 2 and two_pass[5] >= 1 and two_pass[p2] >= 1, (two_pass, p2)  # exactly the two poisoned launches went through the two-pass kernels
+    assert reruns[k4] >= 2, (k4, reruns)            # the refuted rank indexed again, in both streams that hold the case
+    assert reruns[0] == 0                            # rank 0 is never refuted
+    assert len(set(rounds)) == 1 and rounds[0] >= len(cases) + 3  # every rank took part in every all-gather round
