@@ -305,20 +305,41 @@ __global__ __launch_bounds__(1024) void scan_blocks(const int32_t *__restrict__ 
 // match_brackets resolves through the min tree as before.  1 GiB minified: of 8.6 M containers ... survive.
 constexpr int kMatchLevels = 16;
 constexpr int kMatchBelow = 4;
+// kFull: every token of the block exists (all blocks of a call but the last): no guards against n at all -- they were
+// 64-bit compares, eight per loop (round 5: 661 -> ~450 vector instructions per wave together with block-relative
+// 32-bit addressing, the DPP minima and the skipped document counts; profiles/r05/apply_depth_*.txt).
 template <bool kMatch>
-__global__ __launch_bounds__(kThreads) void apply_depth(const uint8_t *__restrict__ type, uint64_t n,
-                                                        const int32_t *__restrict__ block_start, const int32_t *__restrict__ super_start,
-                                                        const uint32_t *__restrict__ super_open, int32_t *__restrict__ depth,
-                                                        int32_t *__restrict__ min8, int32_t *__restrict__ min64,
-                                                        int32_t *__restrict__ min512, const uint32_t *__restrict__ open_start,
-                                                        uint32_t *__restrict__ opens, uint4 *__restrict__ doc_agg,
-                                                        int32_t *__restrict__ block_mm, const msj_tokens_result *__restrict__ prev,
-                                                        uint32_t *__restrict__ match, uint32_t *__restrict__ survivors, uint32_t match_bias,
-                                                        uint32_t want_closers) {
-    __shared__ uint32_t bm[kMatch ? kMatchLevels : 1][kMatch ? kBlock / 32 : 1];  // opening brackets per level, one bit per token
-    __shared__ unsigned long long bm_words[kMatch ? kMatchLevels : 1];              // ... and which of a level's 64 words are not empty
-    __shared__ __attribute__((aligned(16))) uint32_t s_match[kMatch ? kBlock : 4];
-    __shared__ uint32_t s_paired[kMatch ? kBlock / 32 : 1];                         // one bit per token: it has a partner in s_match
+struct DepthShared {
+    uint32_t bm[kMatch ? kMatchLevels : 1][kMatch ? kBlock / 32 : 1];  // opening brackets per level, one bit per token
+    unsigned long long bm_words[kMatch ? kMatchLevels : 1];              // ... and which of a level's 64 words are not empty
+    __attribute__((aligned(16))) uint32_t s_match[kMatch ? kBlock : 4];
+    uint32_t s_paired[kMatch ? kBlock / 32 : 1];                         // one bit per token: it has a partner in s_match
+    int wave_sum[kThreads / 64];
+    int wave_no[kThreads / 64];
+    int wave_rmn[kThreads / 64], wave_rmx[kThreads / 64];
+    uint32_t doc_cnt[kThreads / 64], doc_start[kThreads / 64], doc_close[kThreads / 64];
+    __attribute__((aligned(16))) int s_out[kThreads / 64][512];          // the depths' way out (1 KiB contiguous per store instruction)
+};
+template <bool kMatch, bool kFull>
+__device__ __forceinline__ void apply_depth_block(DepthShared<kMatch> &sh, const uint8_t *__restrict__ type, const uint32_t nrem /* tokens of this block */,
+                                                  const int block_depth0, int32_t *__restrict__ depth_blk, int32_t *__restrict__ min8,
+                                                  int32_t *__restrict__ min64, int32_t *__restrict__ min512, uint32_t *__restrict__ opens,
+                                                  uint4 *__restrict__ doc_agg, int32_t *__restrict__ block_mm,
+                                                  uint32_t *__restrict__ match_blk, uint32_t *__restrict__ survivors, const uint32_t match_bias,
+                                                  const uint32_t want_closers) {
+    // (the LDS lives in the kernel: two instantiations of this function must not own two copies of it)
+    auto &bm = sh.bm;
+    auto &bm_words = sh.bm_words;
+    auto &s_match = sh.s_match;
+    auto &s_paired = sh.s_paired;
+    auto &wave_sum = sh.wave_sum;
+    auto &wave_no = sh.wave_no;
+    auto &wave_rmn = sh.wave_rmn;
+    auto &wave_rmx = sh.wave_rmx;
+    auto &doc_cnt = sh.doc_cnt;
+    auto &doc_start = sh.doc_start;
+    auto &doc_close = sh.doc_close;
+    auto &s_out = sh.s_out;
     if (kMatch) {
         uint32_t *z = &bm[0][0];
 #pragma unroll
@@ -326,14 +347,13 @@ __global__ __launch_bounds__(kThreads) void apply_depth(const uint8_t *__restric
         if (threadIdx.x < kMatchLevels) bm_words[threadIdx.x] = 0ull;
         if (threadIdx.x < kBlock / 32) s_paired[threadIdx.x] = 0u;  // s_match itself is not initialised: s_paired says which words count
     }
-    __shared__ int wave_sum[kThreads / 64];
-    __shared__ int wave_no[kThreads / 64];
-    __shared__ int wave_rmn[kThreads / 64], wave_rmx[kThreads / 64];
-    __shared__ uint32_t doc_cnt[kThreads / 64], doc_start[kThreads / 64], doc_close[kThreads / 64];
-    const uint64_t base = (uint64_t)blockIdx.x * kBlock + (uint64_t)threadIdx.x * kPer;
+    const uint32_t t0 = 8u * threadIdx.x;  // this thread's first token inside the block (everything below is block-relative)
+    const uint32_t blk0 = blockIdx.x * kBlock;  // token indices are < 2^31
+    // which of the thread's eight tokens exist (kFull: all)
+    const uint32_t vm = kFull ? 0xFFu : (t0 >= nrem ? 0u : (nrem - t0 >= 8u ? 0xFFu : (1u << (nrem - t0)) - 1u));
     uint32_t c[kPer];
-    if (base + kPer <= n) {
-        const uint2 t = *reinterpret_cast<const uint2 *>(type + base);
+    if (kFull || vm == 0xFFu) {
+        const uint2 t = *reinterpret_cast<const uint2 *>(type + t0);
 #pragma unroll
         for (int k = 0; k < 4; k++) {
             c[k] = (t.x >> (8 * k)) & 0xFFu;
@@ -341,7 +361,7 @@ __global__ __launch_bounds__(kThreads) void apply_depth(const uint8_t *__restric
         }
     } else {
 #pragma unroll
-        for (int k = 0; k < kPer; k++) c[k] = (base + k < n) ? type[base + k] : (uint32_t)' ';
+        for (int k = 0; k < kPer; k++) c[k] = ((vm >> k) & 1u) ? type[t0 + k] : (uint32_t)' ';
     }
     int d[kPer], run = 0, no = 0;
 #pragma unroll
@@ -358,7 +378,6 @@ __global__ __launch_bounds__(kThreads) void apply_depth(const uint8_t *__restric
         wave_no[wave] = incl_no;
     }
     __syncthreads();
-    const int block_depth0 = (prev ? prev->final_depth : 0) + super_start[blockIdx.x / kSuper] + block_start[blockIdx.x];  // uniform
     int before = block_depth0 + incl - run;
     for (int w = 0; w < wave; w++) before += wave_sum[w];
     int out[kPer];
@@ -367,7 +386,7 @@ __global__ __launch_bounds__(kThreads) void apply_depth(const uint8_t *__restric
     for (int k = 0; k < kPer; k++) {
         out[k] = before - (d[k] < 0 ? 1 : 0);  // a closing bracket sits at the depth of its container
         before += d[k];
-        if (base + k < n) {
+        if (kFull || ((vm >> k) & 1u)) {
             rmn = min(rmn, before);
             rmx = max(rmx, before);
         }
@@ -376,7 +395,6 @@ __global__ __launch_bounds__(kThreads) void apply_depth(const uint8_t *__restric
     uint32_t surv_incl = 0, surv_slot = 0, surv_mine = 0, surv_mask = 0, cand_mask = 0;
     if (kMatch) {
         const int level0 = block_depth0 - kMatchBelow;
-        const uint32_t t0 = 8u * threadIdx.x;  // this thread's first token inside the block
         // (a) the opening brackets' bits (the zeroing above is behind the barrier that published wave_sum).  Brackets are
         // few (4 % of the tokens of the minified workload are opening ones): a thread walks the SET BITS of its eight
         // tokens' bracket masks, so a wave runs max-over-lanes(brackets per thread) rounds, not eight; the depth of
@@ -384,11 +402,10 @@ __global__ __launch_bounds__(kThreads) void apply_depth(const uint8_t *__restric
         uint32_t om = 0, cm = 0;
 #pragma unroll
         for (int k = 0; k < kPer; k++) {
-            if (base + k < n) {
-                om |= d[k] > 0 ? 1u << k : 0u;
-                cm |= d[k] < 0 ? 1u << k : 0u;
-            }
+            om |= d[k] > 0 ? 1u << k : 0u;
+            cm |= d[k] < 0 ? 1u << k : 0u;
         }
+        if (!kFull) om &= vm, cm &= vm;  // (a blank stands in for a token that does not exist: no bracket anyway)
         const int before0 = out[0] + (d[0] < 0 ? 1 : 0);  // the running depth in front of this thread's first token
         for (uint32_t rem = om; __ballot(rem != 0u) != 0ull;) {  // uniform
             if (rem != 0u) {
@@ -425,9 +442,9 @@ __global__ __launch_bounds__(kThreads) void apply_depth(const uint8_t *__restric
                     }
                     if (m != 0u) {
                         const uint32_t i = 32u * wi + 31u - (uint32_t)__clz((int)m);
-                        const uint32_t blk0 = blockIdx.x * kBlock + match_bias;  // token indices are < 2^31; + the call's place in the shard
-                        s_match[t] = blk0 + i;
-                        s_match[i] = blk0 + t;
+                        const uint32_t b0 = blk0 + match_bias;  // + the call's place in the shard (msj_stage2_prep_segments)
+                        s_match[t] = b0 + i;
+                        s_match[i] = b0 + t;
                         atomicOr(&s_paired[w], 1u << (t & 31u));
                         atomicOr(&s_paired[wi], 1u << (i & 31u));
                     }
@@ -437,10 +454,11 @@ __global__ __launch_bounds__(kThreads) void apply_depth(const uint8_t *__restric
         __syncthreads();
         // (d) the opening brackets nobody claimed: to the list match_brackets works through (any order)
         // (the thread's eight tokens are one byte of a word of s_paired)
-        surv_mask = om & ~(s_paired[t0 >> 5] >> (t0 & 31u));
+        const uint32_t paired8 = s_paired[t0 >> 5] >> (t0 & 31u);
+        surv_mask = om & ~paired8;
         // ... and (a shard call only) the closing brackets below the block's start depth that nothing in the block paired:
         // bits 8..15, listed with bit 31 set; match_brackets skips them, collect_closers keeps those still unpaired
-        if (want_closers) surv_mask |= (cand_mask & ~(s_paired[t0 >> 5] >> (t0 & 31u)) & 0xFFu) << 8;
+        if (want_closers) surv_mask |= (cand_mask & ~paired8 & 0xFFu) << 8;
         const uint32_t mine = (uint32_t)__builtin_popcount(surv_mask);
         // the slot is DRAWN here (one returning atomic per wave that has any) and USED at the very end of the kernel: its
         // round trip overlaps the stores of match[] and depth[] and the aggregates below
@@ -451,24 +469,23 @@ __global__ __launch_bounds__(kThreads) void apply_depth(const uint8_t *__restric
         }
         surv_mine = mine;
         // (e) the block's slice of match[]: 1 KiB contiguous per store instruction, like the depths below
-        const uint64_t wb = (uint64_t)blockIdx.x * kBlock + (uint64_t)wave * 512u;
-        if (wb + 512u <= n) {  // uniform per wave
+        const uint32_t wb = (uint32_t)wave * 512u;
+        if (kFull || wb + 512u <= nrem) {  // uniform per wave
             typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
             // tokens 4 lane .. 4 lane + 3 of the wave's first and second half: a nibble of s_paired each
-            const uint32_t q0 = wave * 512u + 4u * lane, q1 = q0 + 256u;
+            const uint32_t q0 = wb + 4u * lane, q1 = q0 + 256u;
             uint4 a = *reinterpret_cast<const uint4 *>(&s_match[q0]);
             uint4 b = *reinterpret_cast<const uint4 *>(&s_match[q1]);
             const uint32_t pa = s_paired[q0 >> 5] >> (q0 & 31u), pb = s_paired[q1 >> 5] >> (q1 & 31u);
             a.x = (pa & 1u) ? a.x : ~0u; a.y = (pa & 2u) ? a.y : ~0u; a.z = (pa & 4u) ? a.z : ~0u; a.w = (pa & 8u) ? a.w : ~0u;
             b.x = (pb & 1u) ? b.x : ~0u; b.y = (pb & 2u) ? b.y : ~0u; b.z = (pb & 4u) ? b.z : ~0u; b.w = (pb & 8u) ? b.w : ~0u;
             const u32x4 o0 = {a.x, a.y, a.z, a.w}, o1 = {b.x, b.y, b.z, b.w};
-            __builtin_nontemporal_store(o0, reinterpret_cast<u32x4 *>(match + wb + 4 * lane));
-            __builtin_nontemporal_store(o1, reinterpret_cast<u32x4 *>(match + wb + 256 + 4 * lane));
+            __builtin_nontemporal_store(o0, reinterpret_cast<u32x4 *>(match_blk + q0));
+            __builtin_nontemporal_store(o1, reinterpret_cast<u32x4 *>(match_blk + q1));
         } else {
-            const uint32_t pm = s_paired[t0 >> 5] >> (t0 & 31u);
 #pragma unroll
             for (int k = 0; k < kPer; k++)
-                if (base + k < n) match[base + k] = ((pm >> k) & 1u) ? s_match[t0 + k] : ~0u;
+                if ((vm >> k) & 1u) match_blk[t0 + k] = ((paired8 >> k) & 1u) ? s_match[t0 + k] : ~0u;
         }
     }
     // The depths leave through LDS, so that each store instruction of a wave writes 1 KiB contiguous instead of 16 bytes
@@ -478,10 +495,9 @@ __global__ __launch_bounds__(kThreads) void apply_depth(const uint8_t *__restric
     // (Round 4, measured with rocprofv3 on one box, alternating: letting the wave's quarter of s_match double as this
     // staging slice -- 13 KiB of LDS per workgroup instead of 21, eight resident workgroups per CU instead of seven --
     // changes nothing, 473 / 489 us either way; FEWER resident workgroups cost: six 533 us, four 616, three 752.)
-    __shared__ __attribute__((aligned(16))) int s_out[kThreads / 64][512];
     int *const stage = &s_out[wave][0];
-    const uint64_t wave_base = (uint64_t)blockIdx.x * kBlock + (uint64_t)wave * 512u;
-    if (wave_base + 512u <= n) {  // uniform per wave
+    const uint32_t wave_base = (uint32_t)wave * 512u;
+    if (kFull || wave_base + 512u <= nrem) {  // uniform per wave
         typedef int i32x4 __attribute__((ext_vector_type(4)));
         *reinterpret_cast<int4 *>(&stage[8 * lane]) = make_int4(out[0], out[1], out[2], out[3]);
         *reinterpret_cast<int4 *>(&stage[8 * lane + 4]) = make_int4(out[4], out[5], out[6], out[7]);
@@ -491,29 +507,33 @@ __global__ __launch_bounds__(kThreads) void apply_depth(const uint8_t *__restric
         const int4 a = *reinterpret_cast<const int4 *>(&stage[4 * lane]);
         const int4 b = *reinterpret_cast<const int4 *>(&stage[256 + 4 * lane]);
         const i32x4 o0 = {a.x, a.y, a.z, a.w}, o1 = {b.x, b.y, b.z, b.w};
-        __builtin_nontemporal_store(o0, reinterpret_cast<i32x4 *>(depth + wave_base + 4 * lane));
-        __builtin_nontemporal_store(o1, reinterpret_cast<i32x4 *>(depth + wave_base + 256 + 4 * lane));
+        __builtin_nontemporal_store(o0, reinterpret_cast<i32x4 *>(depth_blk + wave_base + 4u * lane));
+        __builtin_nontemporal_store(o1, reinterpret_cast<i32x4 *>(depth_blk + wave_base + 256u + 4u * lane));
     } else {  // the stream's last wave
 #pragma unroll
         for (int k = 0; k < kPer; k++)
-            if (base + k < n) depth[base + k] = out[k];
+            if ((vm >> k) & 1u) depth_blk[t0 + k] = out[k];
     }
     {   // what the document split (documents_kernel.hip, doc_count) would recompute from type[] and depth[]:
         // per block the number of tokens that start a document (depth 0, not a closing bracket), the last of
         // them + 1 and the last closing bracket at depth 0 + 1
         uint32_t cnt = 0, ls = 0, lc = 0;
+        // (round 5: a thread's eight tokens lie within 8 levels of its first one, and inside a large document no token of
+        // a whole wave is anywhere near depth 0 -- one compare that IS the ballot skips ~80 vector instructions per wave;
+        // streams of small documents take the counts as before)
+        if (__ballot((uint32_t)(out[0] + 8) <= 16u) != 0ull) {  // uniform per wave
 #pragma unroll
-        for (int k = 0; k < kPer; k++) {
-            if (base + k < n && out[k] == 0) {
-                if (d[k] < 0) {
-                    lc = (uint32_t)(base + k) + 1u;
-                } else {
-                    cnt++;
-                    ls = (uint32_t)(base + k) + 1u;
+            for (int k = 0; k < kPer; k++) {
+                if ((kFull || ((vm >> k) & 1u)) && out[k] == 0) {
+                    if (d[k] < 0) {
+                        lc = blk0 + t0 + (uint32_t)k + 1u;
+                    } else {
+                        cnt++;
+                        ls = blk0 + t0 + (uint32_t)k + 1u;
+                    }
                 }
             }
-        }
-        {   // wave totals by DPP (token indices + 1 fit an int: n < 2^31); lane 63 holds the sum, every lane the maxima
+            // wave totals by DPP (token indices + 1 fit an int: n < 2^31); lane 63 holds the sum, every lane the maxima
             cnt = wave_incl_sum(cnt);
             int neg_lc, m_ls;  // one chain of minima, one of maxima: max(lc) = -min(-lc)
             wave_min_max(-(int)lc, (int)ls, neg_lc, m_ls);
@@ -548,20 +568,35 @@ __global__ __launch_bounds__(kThreads) void apply_depth(const uint8_t *__restric
             block_mm[4 * (uint64_t)blockIdx.x + 2] = bmx;
         }
     }
-    if (min8) {  // the three lowest levels of the 8-ary min tree used for bracket matching
+    if (min8) {  // the three lowest levels of the 8-ary min tree used for bracket matching (block-relative pointers)
         int m = kNone;
 #pragma unroll
         for (int k = 0; k < kPer; k++)
-            if (base + k < n) m = min(m, out[k]);
-        if (base < n) min8[base >> 3] = m;                      // 8 tokens = this thread
-        m = min(m, __shfl_xor(m, 1));
-        m = min(m, __shfl_xor(m, 2));
-        m = min(m, __shfl_xor(m, 4));
-        if ((threadIdx.x & 7) == 0 && base < n) min64[base >> 6] = m;    // 64 tokens = 8 threads
-        m = min(m, __shfl_xor(m, 8));
-        m = min(m, __shfl_xor(m, 16));
-        m = min(m, __shfl_xor(m, 32));
-        if ((threadIdx.x & 63) == 0 && base < n) min512[base >> 9] = m;  // 512 tokens = this wave
+            if (kFull || ((vm >> k) & 1u)) m = min(m, out[k]);
+        if (kFull || vm) min8[threadIdx.x] = m;                      // 8 tokens = this thread
+        // the minima over 8 threads and over the wave by DPP (round 5; six ds_bpermute butterflies before): an inclusive
+        // scan to the right inside each row of 16 lanes -- after row_shr 1, 2, 4 lane 8g + 7 holds its group of eight --
+        // then row_shr:8 and the two row broadcasts bring the wave's minimum to lane 63.  A lane without a source keeps
+        // its value (a shift never crosses a row).  A group's / the wave's first token exists whenever any of it does.
+        asm volatile(
+            "s_nop 1\n\t"
+            "v_min_i32_dpp %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
+            "s_nop 1\n\t"
+            "v_min_i32_dpp %0, %0, %0 row_shr:2 row_mask:0xf bank_mask:0xf\n\t"
+            "s_nop 1\n\t"
+            "v_min_i32_dpp %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xf\n\t"
+            "s_nop 1"
+            : "+v"(m));
+        if ((threadIdx.x & 7) == 7 && (kFull || (t0 & ~63u) < nrem)) min64[threadIdx.x >> 3] = m;  // 64 tokens = 8 threads
+        asm volatile(
+            "v_min_i32_dpp %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xf\n\t"
+            "s_nop 1\n\t"
+            "v_min_i32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+            "s_nop 1\n\t"
+            "v_min_i32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"
+            "s_nop 1"
+            : "+v"(m));
+        if (lane == 63 && (kFull || wave_base < nrem)) min512[wave] = m;  // 512 tokens = this wave
     }
     if (kMatch && surv_any) {  // uniform per wave: the opening brackets left to match_brackets, at the slot drawn above
         const uint32_t shard = blockIdx.x % kSurvivorShards;
@@ -569,13 +604,39 @@ __global__ __launch_bounds__(kThreads) void apply_depth(const uint8_t *__restric
         uint32_t slot = (uint32_t)__builtin_amdgcn_readlane((int)surv_slot, 63) + surv_incl - surv_mine;
 #pragma unroll
         for (int k = 0; k < kPer; k++)
-            if ((surv_mask >> k) & 1u) list[slot++] = (uint32_t)(base + k);
+            if ((surv_mask >> k) & 1u) list[slot++] = blk0 + t0 + (uint32_t)k;
         if (surv_mask >> 8) {
 #pragma unroll
             for (int k = 0; k < kPer; k++)
-                if ((surv_mask >> (8 + k)) & 1u) list[slot++] = (uint32_t)(base + k) | 0x80000000u;
+                if ((surv_mask >> (8 + k)) & 1u) list[slot++] = (blk0 + t0 + (uint32_t)k) | 0x80000000u;
         }
     }
+}
+
+template <bool kMatch>
+__global__ __launch_bounds__(kThreads) void apply_depth(const uint8_t *__restrict__ type, uint64_t n,
+                                                        const int32_t *__restrict__ block_start, const int32_t *__restrict__ super_start,
+                                                        const uint32_t *__restrict__ super_open, int32_t *__restrict__ depth,
+                                                        int32_t *__restrict__ min8, int32_t *__restrict__ min64,
+                                                        int32_t *__restrict__ min512, const uint32_t *__restrict__ open_start,
+                                                        uint32_t *__restrict__ opens, uint4 *__restrict__ doc_agg,
+                                                        int32_t *__restrict__ block_mm, const msj_tokens_result *__restrict__ prev,
+                                                        uint32_t *__restrict__ match, uint32_t *__restrict__ survivors, uint32_t match_bias,
+                                                        uint32_t want_closers) {
+    (void)super_open;
+    (void)open_start;
+    // everything the block touches, as uniform (scalar) base pointers: the lanes add 32-bit offsets inside the block
+    const uint64_t b0 = (uint64_t)blockIdx.x * kBlock;
+    const uint32_t nrem = (uint32_t)(n - b0 < (uint64_t)kBlock ? n - b0 : (uint64_t)kBlock);
+    const int block_depth0 = (prev ? prev->final_depth : 0) + super_start[blockIdx.x / kSuper] + block_start[blockIdx.x];  // uniform
+    int32_t *m8 = min8 ? min8 + (b0 >> 3) : nullptr, *m64 = min8 ? min64 + (b0 >> 6) : nullptr, *m512 = min8 ? min512 + (b0 >> 9) : nullptr;
+    __shared__ DepthShared<kMatch> sh;
+    if (nrem == kBlock)
+        apply_depth_block<kMatch, true>(sh, type + b0, nrem, block_depth0, depth + b0, m8, m64, m512, opens, doc_agg, block_mm,
+                                        kMatch ? match + b0 : nullptr, survivors, match_bias, want_closers);
+    else
+        apply_depth_block<kMatch, false>(sh, type + b0, nrem, block_depth0, depth + b0, m8, m64, m512, opens, doc_agg, block_mm,
+                                         kMatch ? match + b0 : nullptr, survivors, match_bias, want_closers);
 }
 
 // (4) minimum / maximum of the running depth over the stream, from the per-block values apply_depth left in the block
