@@ -170,8 +170,26 @@ def end_to_end(unit, lib, n_bytes=256 << 20, runs=5):
         assert rc == 0, rc
     ts = sorted(ts[1:])  # the first call sets the pinned rings up
     med = ts[len(ts) // 2]
+    # where the host side ran (28.6 GB/s on the driver's box against 43 - 45 on the builder's, nothing in
+    # the record to say why): the GPU's NUMA node, the node of the caller's two buffers and of the library's pinned rings,
+    # how many copy workers are bound to the GPU's node, the PCIe link (msj_host_placement; -1 / "" = the kernel does not say)
+    placement = None
+    try:
+        lib.msj_host_placement.restype = ctypes.c_int32
+        lib.msj_host_placement.argtypes = [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_uint64]
+        lib.msj_debug_numa_node_of.restype = ctypes.c_int32
+        lib.msj_debug_numa_node_of.argtypes = [ctypes.c_void_p]
+        text = ctypes.create_string_buffer(1024)
+        if lib.msj_host_placement(None, text, 1024) == 0:
+            placement = json.loads(text.value.decode())
+            placement["caller_input_node"] = int(lib.msj_debug_numa_node_of(data.ctypes.data + data.size // 2))
+            placement["caller_index_node"] = int(lib.msj_debug_numa_node_of(idx.ctypes.data + idx.nbytes // 4))
+            placement["cpus_allowed"] = len(os.sched_getaffinity(0))
+    except Exception as exc:  # a measurement extra
+        placement = {"error": repr(exc)}
     return {"value": round(data.size / med / 1e9, 2), "unit": "GB/s", "best": round(data.size / ts[0] / 1e9, 2),
             "ms_median": round(med * 1e3, 3), "bytes": int(data.size), "structurals": int(n.value), "runs": runs,
+            "placement": placement,
             "what": "msj_stage1 (host pointers, pageable caller memory): H2D of the input + kernel + D2H of n + 3 indices per "
                     "call, median of the runs; NOT the metric (inputs of `value` are resident in HBM)"}
 

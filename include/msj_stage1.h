@@ -163,6 +163,16 @@ int32_t msj_stage1_ctx(msj_ctx *ctx, const uint8_t *buf, uint64_t len, uint32_t 
  * Returns MSJ_SUCCESS, MSJ_ERR_BAD_ARGUMENT (null / empty / ptr not the start of a registered range), MSJ_ERR_HIP.
  */
 int32_t msj_host_register(msj_ctx *ctx, void *ptr, uint64_t bytes);
+/*
+ * msj_host_placement -- where the host side of msj_stage1's pipeline lives, as one line of JSON in `out` (MSJ_CAPACITY if it
+ * does not fit): the GPU's PCI address and NUMA node, how many CPUs of that node the process may use, whether the
+ * pipeline exists yet (the first large call creates it), how many of its copy workers are bound to the GPU's node, the
+ * node its pinned rings were placed on, the PCIe link's speed and width (sysfs; -1 / "" = the kernel does not say).
+ * ctx NULL = the default context of msj_stage1.  A measurement aid: bench.py records it beside `end_to_end`.
+ */
+int32_t msj_host_placement(msj_ctx *ctx, char *out, uint64_t capacity);
+/* the NUMA node the page under a host address lies on (-1: unknown); measurement aid like the above */
+int32_t msj_debug_numa_node_of(const void *host_ptr);
 int32_t msj_host_unregister(msj_ctx *ctx, void *ptr);
 
 /*
@@ -461,6 +471,20 @@ int32_t msj_tokens_chain_device(msj_ctx *ctx, const uint8_t *d_buf, uint64_t len
                                 bytes are scanned by a wave each behind the span kernel, over 1 MiB by the whole grid) */
 int32_t msj_token_spans_device(msj_ctx *ctx, const uint8_t *d_buf, uint64_t len, const uint32_t *d_idx, uint64_t n,
                                uint32_t *d_end, uint8_t *d_flags, void *stream);
+
+/*
+ * PROTOTYPE (round 5; SURVEY.md section 8 row f1 from ONE pass over the bytes; measured and decided in DESIGN.md section 5b):
+ * msj_stage1_types_device -- msj_stage1_device that also writes d_types[k] = d_buf[d_idx[k]], the type byte stage 2's
+ *   JsonIterator.advance dereferences (generic/stage2/json_iterator.mojo:256-262), beside every index from the same
+ *   emission (one uint32 segment, single-pass kernel only: MSJ_CAPACITY otherwise; d_types 4-byte aligned, same
+ *   capacity as d_idx);
+ * msj_depth_from_types_device -- depth (and, d_match given, bracket partners) of every token from such type bytes:
+ *   msj_tokens_chain_device without the pass over the buffer.
+ */
+int32_t msj_stage1_types_device(msj_ctx *ctx, const uint8_t *d_buf, uint64_t len, uint32_t *d_idx, uint64_t idx_capacity,
+                                uint8_t *d_types, msj_carry *d_result, void *stream, uint32_t flags);
+int32_t msj_depth_from_types_device(msj_ctx *ctx, const uint8_t *d_type, uint64_t n, int32_t *d_depth, uint32_t *d_match,
+                                    msj_tokens_result *d_result, const msj_tokens_result *d_prev, void *stream);
 
 /* Test hook (per context, like msj_debug_set_segment_bytes): stretches of more than lds_limit_bytes take the span
  * kernels' global-memory path, the fix-up list holds fix_capacity entries; 0xFFFFFFFF = the built-in value of either. */

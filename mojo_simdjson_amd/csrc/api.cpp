@@ -20,6 +20,11 @@
 #include <thread>
 #include <vector>
 
+#include <pthread.h>
+#include <sched.h>
+#include <sys/syscall.h>
+#include <unistd.h>
+
 #include "../../include/msj_stage1.h"
 #include "stage1_kernel.h"
 #include "tokens_launch.h"
@@ -89,6 +94,7 @@ struct msj_ctx {
     uint64_t tok_doc_n = ~0ull;   // the token count whose document aggregates tok_ws holds (~0: none)
     uint32_t *seg_idx = nullptr;  // msj_stage2_prep_segments: 16-byte aligned copy of a segment's index slice that is not
     uint64_t seg_idx_words = 0;
+    uint8_t *types_out = nullptr; // msj_stage1_types_device (prototype): where the launch being enqueued writes the type bytes
     uint32_t *resid = nullptr;    // msj_stage2_prep_segments with d_match: MSJ_RESID_WORDS per segment (the brackets a segment could not pair)
     uint64_t resid_words = 0;
     msj_token_opts tok_opts;      // test hooks of the token calls (msj_debug_set_span_limits / _span_mode): per context
@@ -195,6 +201,8 @@ int32_t enqueue_shard(msj_ctx *ctx, const uint8_t *d_buf, uint64_t len, uint32_t
             a.carry_in = nullptr;
         }
         a.stamps = g_stamps;
+        a.types = ctx->types_out;
+        if (a.types) a.flags |= msj::kFlagEmitTypes;
         a.wait_ticks = ctx->wait_ticks;
         // without a segment table nothing tells the caller where a later segment's offsets start: they stay
         // relative to the call's buffer (wrapping like the reference's UInt32 would, json_structural_indexer.mojo:138)
@@ -253,15 +261,86 @@ int32_t enqueue_shard(msj_ctx *ctx, const uint8_t *d_buf, uint64_t len, uint32_t
 // with the carry chained in device memory (msj_stage1_shard_device); a second host thread follows the chunks'
 // counts and brings the finished part of the index array down through a second pinned ring while later chunks
 // are still on their way up -- both PCIe directions and the kernel run at the same time.
+// ---- where the host side of the pipeline lives (round 5: the PCIe-inclusive rate differed by 37 % between two boxes of
+// the pool with nothing in the record to say why).  The GPU hangs off ONE NUMA node's root complex: staging copies that
+// run on the other socket, or pinned rings whose pages lie there, cross the inter-socket link twice.  The copy workers
+// are therefore bound to the CPUs of the GPU's node (those of them the process may use: a cgroup / taskset limit is
+// respected; no such CPU -> no binding), the rings are allocated by a thread bound the same way (first touch), and
+// msj_host_placement reports all of it.  Linux sysfs / syscalls only, no libnuma; anything unreadable reads as -1.
+struct GpuHostLocality {
+    char pci[32] = "";
+    int node = -1;          // NUMA node of the GPU's PCIe root complex (-1: unknown / single node)
+    cpu_set_t cpus;         // CPUs of that node that this process may run on
+    int n_cpus = 0;
+    char link_speed[32] = "", link_width[16] = "";
+};
+static bool read_line(const char *path, char *out, size_t cap) {
+    FILE *f = std::fopen(path, "r");
+    if (!f) return false;
+    const bool ok = std::fgets(out, (int)cap, f) != nullptr;
+    std::fclose(f);
+    if (ok) out[std::strcspn(out, "\n")] = 0;
+    return ok;
+}
+static GpuHostLocality gpu_locality(int device) {
+    GpuHostLocality g;
+    CPU_ZERO(&g.cpus);
+    char bus[32] = "";
+    if (hipDeviceGetPCIBusId(bus, (int)sizeof bus, device) != hipSuccess) {
+        (void)hipGetLastError();
+        return g;
+    }
+    for (char *c = bus; *c; c++)
+        if (*c >= 'A' && *c <= 'F') *c = (char)(*c - 'A' + 'a');  // sysfs spells the address in lower case
+    std::snprintf(g.pci, sizeof g.pci, "%s", bus);
+    char path[128], line[4096];
+    std::snprintf(path, sizeof path, "/sys/bus/pci/devices/%s/numa_node", bus);
+    if (read_line(path, line, sizeof line)) g.node = std::atoi(line);
+    std::snprintf(path, sizeof path, "/sys/bus/pci/devices/%s/current_link_speed", bus);
+    (void)read_line(path, g.link_speed, sizeof g.link_speed);
+    std::snprintf(path, sizeof path, "/sys/bus/pci/devices/%s/current_link_width", bus);
+    (void)read_line(path, g.link_width, sizeof g.link_width);
+    std::snprintf(path, sizeof path, "/sys/bus/pci/devices/%s/local_cpulist", bus);
+    cpu_set_t allowed;
+    CPU_ZERO(&allowed);
+    if (read_line(path, line, sizeof line) && sched_getaffinity(0, sizeof allowed, &allowed) == 0) {
+        for (char *tok = std::strtok(line, ","); tok; tok = std::strtok(nullptr, ",")) {  // "0-31,64-95"
+            int lo = 0, hi = 0;
+            const int k = std::sscanf(tok, "%d-%d", &lo, &hi);
+            if (k == 1) hi = lo;
+            for (int c = lo; k >= 1 && c <= hi && c < CPU_SETSIZE; c++)
+                if (CPU_ISSET(c, &allowed)) {
+                    CPU_SET(c, &g.cpus);
+                    g.n_cpus++;
+                }
+        }
+    }
+    return g;
+}
+// NUMA node a mapped page lies on (get_mempolicy(MPOL_F_NODE | MPOL_F_ADDR)); -1 where the kernel will not say
+static int numa_node_of(const void *p) {
+#ifdef SYS_get_mempolicy
+    int node = -1;
+    if (p && syscall(SYS_get_mempolicy, &node, nullptr, 0UL, const_cast<void *>(p), 3UL /* MPOL_F_NODE | MPOL_F_ADDR */) == 0) return node;
+#endif
+    (void)p;
+    return -1;
+}
+
 struct CopyPool {
+    const cpu_set_t *bind = nullptr;  // the GPU's CPUs (HostPipe): every worker runs there
+    int bound = 0;                    // workers whose affinity call succeeded
     std::vector<std::thread> threads;
     std::deque<std::function<void()>> tasks;
     std::mutex m;
     std::condition_variable cv;
     bool stop = false;
-    explicit CopyPool(int n) {
+    explicit CopyPool(int n, const cpu_set_t *cpus = nullptr) : bind(cpus) {
+        std::atomic<int> ok{0};
         for (int i = 0; i < n; i++)
-            threads.emplace_back([this] {
+            threads.emplace_back([this, &ok] {
+                if (bind && pthread_setaffinity_np(pthread_self(), sizeof(cpu_set_t), bind) == 0) ok.fetch_add(1);
+                ok.fetch_add(1 << 16);  // this worker has started
                 for (;;) {
                     std::function<void()> f;
                     {
@@ -274,6 +353,8 @@ struct CopyPool {
                     f();
                 }
             });
+        while ((ok.load() >> 16) < n) std::this_thread::yield();  // (`ok` lives on this frame)
+        bound = ok.load() & 0xFFFF;
     }
     ~CopyPool() {
         {
@@ -361,13 +442,26 @@ struct HostPipe {
     hipEvent_t ev_in[kInSlots] = {nullptr, nullptr, nullptr};
     hipEvent_t ev_out[kOutSlots] = {nullptr, nullptr};
     std::vector<hipEvent_t> ev_chunk;
-    CopyPool pool{kCopyThreads};
+    GpuHostLocality where;            // the GPU's NUMA node and the CPUs of it this process may use
+    CopyPool pool;
     bool ok = false;
 
-    HostPipe() {
+    explicit HostPipe(int device) : where(gpu_locality(device)), pool(kCopyThreads, where.n_cpus > 0 ? &where.cpus : nullptr) {
         ok = true;
-        for (auto &p : pin_in) ok = ok && hip_ok(hipHostMalloc(reinterpret_cast<void **>(&p), kChunk, hipHostMallocDefault));
-        for (auto &p : pin_out) ok = ok && hip_ok(hipHostMalloc(reinterpret_cast<void **>(&p), kPiece, hipHostMallocDefault));
+        // the rings: allocated (and touched) by a thread that runs on the GPU's node, so that first-touch placement puts
+        // their pages there; the caller's thread keeps its own affinity
+        std::thread([&] {
+            (void)hipSetDevice(device);
+            if (where.n_cpus > 0) (void)pthread_setaffinity_np(pthread_self(), sizeof(cpu_set_t), &where.cpus);
+            for (auto &p : pin_in) {
+                ok = ok && hip_ok(hipHostMalloc(reinterpret_cast<void **>(&p), kChunk, hipHostMallocDefault));
+                if (ok) std::memset(p, 0, kChunk);
+            }
+            for (auto &p : pin_out) {
+                ok = ok && hip_ok(hipHostMalloc(reinterpret_cast<void **>(&p), kPiece, hipHostMallocDefault));
+                if (ok) std::memset(p, 0, kPiece);
+            }
+        }).join();
         ok = ok && hip_ok(hipStreamCreateWithFlags(&s_up, hipStreamNonBlocking)) &&
              hip_ok(hipStreamCreateWithFlags(&s_k, hipStreamNonBlocking)) &&
              hip_ok(hipStreamCreateWithFlags(&s_down, hipStreamNonBlocking));
@@ -420,7 +514,7 @@ int32_t host_pipeline(msj_ctx *ctx, const uint8_t *buf, uint64_t len, uint32_t *
                       msj_carry *res) {
     if (ctx->pipe_fail_setup) return kPipeUnavailable;  // test hook (msj_debug_fail_pipeline_setup)
     if (!ctx->pipe) {
-        ctx->pipe = new (std::nothrow) HostPipe();
+        ctx->pipe = new (std::nothrow) HostPipe(ctx->device);
         if (!ctx->pipe) return kPipeUnavailable;
     }
     HostPipe &P = *ctx->pipe;
@@ -638,6 +732,40 @@ int32_t msj_stage1_device(msj_ctx *ctx, const uint8_t *d_buf, uint64_t len, uint
     return enqueue_shard(ctx, d_buf, len, d_idx, idx_capacity, &ctx->carries[0], d_result, nullptr,
                          0, nullptr, false, true, false, len, static_cast<hipStream_t>(stream),
                          flags);
+}
+
+static bool ensure_tok_ws(msj_ctx *ctx, uint64_t need);
+extern "C" int msj_launch_depth_from_types(const uint8_t *d_type, uint64_t n, int32_t *d_depth, uint32_t *d_match, msj_tokens_result *d_result,
+                                           int32_t *d_ws, void *stream, const msj_token_opts &o);
+
+int32_t msj_stage1_types_device(msj_ctx *ctx, const uint8_t *d_buf, uint64_t len, uint32_t *d_idx, uint64_t idx_capacity,
+                                uint8_t *d_types, msj_carry *d_result, void *stream, uint32_t flags) {
+    if (!ctx || !d_result || !d_types || (reinterpret_cast<uintptr_t>(d_types) & 3u)) return MSJ_ERR_BAD_ARGUMENT;
+    if (len == 0) return MSJ_EMPTY;
+    if (len > ctx->seg_bytes || (flags & MSJ_FLAG_TWO_PASS)) return MSJ_CAPACITY;  // one single-pass launch (prototype)
+    ctx->types_out = d_types;
+    const int32_t rc = enqueue_shard(ctx, d_buf, len, d_idx, idx_capacity, &ctx->carries[0], d_result, nullptr, 0, nullptr, false, true, false,
+                                     len, static_cast<hipStream_t>(stream), flags);
+    ctx->types_out = nullptr;
+    ctx->last.valid = false;  // (no two-pass fallback for this form: a poisoned launch stays poisoned)
+    return rc;
+}
+
+int32_t msj_depth_from_types_device(msj_ctx *ctx, const uint8_t *d_type, uint64_t n, int32_t *d_depth, uint32_t *d_match,
+                                    msj_tokens_result *d_result, const msj_tokens_result *d_prev, void *stream) {
+    if (!ctx || !d_result || d_prev == d_result) return MSJ_ERR_BAD_ARGUMENT;
+    if (n > 0 && (!d_type || !d_depth)) return MSJ_ERR_BAD_ARGUMENT;
+    if (n >= (1ull << 31)) return MSJ_CAPACITY;
+    if ((reinterpret_cast<uintptr_t>(d_depth) & 15u) || (reinterpret_cast<uintptr_t>(d_type) & 7u) || (reinterpret_cast<uintptr_t>(d_match) & 15u))
+        return MSJ_ERR_BAD_ARGUMENT;
+    if (!hip_ok(hipSetDevice(ctx->device))) return MSJ_ERR_HIP;
+    if (!ensure_tok_ws(ctx, msj_stage2_prep_workspace_bytes(n, 0, d_match != nullptr))) return MSJ_MEMALLOC;
+    ctx->tok_doc_n = ~0ull;
+    msj_token_opts o = ctx->tok_opts;
+    o.d_prev = d_prev;
+    if (msj_launch_depth_from_types(d_type, n, d_depth, d_match, d_result, ctx->tok_ws, stream, o) != 0) return MSJ_ERR_HIP;
+    ctx->tok_doc_n = n;
+    return MSJ_SUCCESS;
 }
 
 int32_t msj_stage1_shard_device(msj_ctx *ctx, const uint8_t *d_buf, uint64_t len, uint32_t *d_idx,
@@ -941,6 +1069,34 @@ int32_t msj_carry_fetch(msj_ctx *ctx, const msj_carry *d_carry, msj_carry *host_
     }
     return MSJ_SUCCESS;
 }
+
+static msj_ctx *default_ctx_locked();
+int32_t msj_host_placement(msj_ctx *ctx, char *out, uint64_t capacity) {
+    if (!out || capacity == 0) return MSJ_ERR_BAD_ARGUMENT;
+    std::unique_lock<std::mutex> lock(g_default_mutex, std::defer_lock);
+    if (!ctx) {
+        lock.lock();
+        ctx = default_ctx_locked();
+        if (!ctx) return MSJ_ERR_NO_DEVICE;
+    }
+    const GpuHostLocality g = ctx->pipe ? ctx->pipe->where : gpu_locality(ctx->device);
+    const int ring_in = ctx->pipe ? numa_node_of(ctx->pipe->pin_in[0]) : -1, ring_out = ctx->pipe ? numa_node_of(ctx->pipe->pin_out[0]) : -1;
+    int nodes = 0;
+    for (;; nodes++) {
+        char path[64];
+        std::snprintf(path, sizeof path, "/sys/devices/system/node/node%d", nodes);
+        if (access(path, F_OK) != 0) break;
+    }
+    const int n = std::snprintf(out, (size_t)capacity,
+                                "{\"gpu_pci\": \"%s\", \"gpu_numa_node\": %d, \"numa_nodes\": %d, \"gpu_local_cpus_usable\": %d, "
+                                "\"pipeline_created\": %s, \"copy_threads\": %d, \"copy_threads_bound_to_gpu_node\": %d, "
+                                "\"ring_in_node\": %d, \"ring_out_node\": %d, \"pcie_link_speed\": \"%s\", \"pcie_link_width\": \"%s\"}",
+                                g.pci, g.node, nodes, g.n_cpus, ctx->pipe ? "true" : "false", ctx->pipe ? ctx->pipe->kCopyThreads : 0,
+                                ctx->pipe ? ctx->pipe->pool.bound : 0, ring_in, ring_out, g.link_speed, g.link_width);
+    return (n < 0 || (uint64_t)n >= capacity) ? MSJ_CAPACITY : MSJ_SUCCESS;
+}
+
+int32_t msj_debug_numa_node_of(const void *host_ptr) { return numa_node_of(host_ptr); }
 
 int32_t msj_debug_set_wait_ticks(msj_ctx *ctx, uint32_t ticks) {
     if (!ctx) return MSJ_ERR_BAD_ARGUMENT;

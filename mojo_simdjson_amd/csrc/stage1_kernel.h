@@ -41,6 +41,9 @@ constexpr uint32_t kFlagCarryByValue = 64u; // the state at the launch's first b
                                             // knows (msj_stage1_shard_device_cv) -- nothing has to be copied to the device first
 constexpr uint32_t kFlagEchoThrough = 128u; // a later segment of a chained shard: carry_out.reserved[0] = carry_in.reserved[0] (the
                                             // echo of the carry the SHARD started from travels down the chain)
+constexpr uint32_t kFlagEmitTypes = 256u;   // PROTOTYPE (msj_stage1_types_device): the type byte of every structural beside its index
+                                            // (what JsonIterator.advance dereferences, generic/stage2/json_iterator.mojo:256-262) from
+                                            // the same emission -- a second instantiation of the kernel, the product's is untouched
 constexpr uint32_t kFlagSkipShift = 24u;   // bits 24..27 == MSJ_FLAG_SKIP(n): the first n < 16 bytes of the launch read as blanks
 
 struct KernelArgs {
@@ -65,6 +68,7 @@ struct KernelArgs {
     uint32_t reserved0;
     uint64_t *stamps;         // diagnostic builds only (-DMSJ_STAMPS): 16 words per tile, else null
     uint64_t *tp;             // two-pass path only: 2 * ntiles words (tile aggregates, tile prefixes)
+    uint8_t *types;           // kFlagEmitTypes (prototype, round 5): types[k] = buf[idx[k]], written beside idx[k]
 };
 
 // ws: ticket shards (header), then per-tile carry words, range aggregates, range prefixes

@@ -861,8 +861,18 @@ __device__ __forceinline__ void st_index_quad(uint8_t *p, const uint4 v) {
 #endif
 }
 
+// kTypes (prototype): the type byte of four indices -- four byte gathers from the tile's bytes (L2 / MALL: the tile was
+// read two iterations ago), packed into the dword that lies beside the quad in types[]
+__device__ __forceinline__ uint32_t gather_types4(const uint8_t *bytes, const uint4 v) {
+    return (uint32_t)bytes[v.x] | ((uint32_t)bytes[v.y] << 8) | ((uint32_t)bytes[v.z] << 16) | ((uint32_t)bytes[v.w] << 24);
+}
+template <bool kTypes>
 __device__ __forceinline__ void copy_out(const KernelArgs &a, const EmitU &e, const uint32_t *stage,
                                          const uint32_t lane, const uint32_t lane_p) {
+    // types[] runs parallel to idx[]: element (e.base - e.shift) + v of either belongs to stage[v]; offsets are byte offsets
+    // of the document (+ index_bias), so `bytes + offset` is the byte itself
+    uint8_t *tout = kTypes ? a.types + (e.base - e.shift) : nullptr;
+    const uint8_t *bytes = kTypes ? a.buf - a.index_bias : nullptr;
     // uniform 64-bit base + 32-bit lane offsets; full 16-byte quads in the body, the (at
     // most two) partial quads at the ends element by element
     uint8_t *out = reinterpret_cast<uint8_t *>(a.idx + (e.base - e.shift));  // out[4v] <-> stage[v]; 16-byte aligned
@@ -890,7 +900,11 @@ __device__ __forceinline__ void copy_out(const KernelArgs &a, const EmitU &e, co
         if (lane_p < 16u) {  // the edges: [q_lo0, q_lo) and [q_hi, q_hi0), at most seven quads each
             const uint32_t q = lane_p < 8u ? q_lo0 + lane : q_hi + (lane - 8u);
             const bool ok = lane_p < 8u ? q < q_lo : q < q_hi0;
-            if (ok) *reinterpret_cast<uint4 *>(out + 16u * q) = *reinterpret_cast<const uint4 *>(src + 16u * q);
+            if (ok) {
+                const uint4 v = *reinterpret_cast<const uint4 *>(src + 16u * q);
+                *reinterpret_cast<uint4 *>(out + 16u * q) = v;
+                if (kTypes) *reinterpret_cast<uint32_t *>(tout + 4u * q) = gather_types4(bytes, v);
+            }
         }
     }
     // at most kStageWords / 256 = 4 rounds of 64 quads: one byte offset per lane, the rounds are
@@ -900,10 +914,15 @@ __device__ __forceinline__ void copy_out(const KernelArgs &a, const EmitU &e, co
     for (uint32_t k = 0; k < kStageWords / 256u; k++) {
         if (q_lo + 64u * k >= q_hi) break;  // uniform
         if (q_lo + 64u * (k + 1u) <= q_hi) {  // uniform: a full round, every lane stores
-            st_index_quad(out + off + 1024u * k, *reinterpret_cast<const uint4 *>(src + off + 1024u * k));
+            const uint4 v = *reinterpret_cast<const uint4 *>(src + off + 1024u * k);
+            st_index_quad(out + off + 1024u * k, v);
+            if (kTypes) *reinterpret_cast<uint32_t *>(tout + (off >> 2) + 256u * k) = gather_types4(bytes, v);
         } else {  // the last round: the first (q_hi - q_lo - 64k) lanes
-            if (lane_p < q_hi - q_lo - 64u * k)
-                st_index_quad(out + off + 1024u * k, *reinterpret_cast<const uint4 *>(src + off + 1024u * k));
+            if (lane_p < q_hi - q_lo - 64u * k) {
+                const uint4 v = *reinterpret_cast<const uint4 *>(src + off + 1024u * k);
+                st_index_quad(out + off + 1024u * k, v);
+                if (kTypes) *reinterpret_cast<uint32_t *>(tout + (off >> 2) + 256u * k) = gather_types4(bytes, v);
+            }
             break;
         }
     }
@@ -913,7 +932,11 @@ __device__ __forceinline__ void copy_out(const KernelArgs &a, const EmitU &e, co
         const bool head = lane_p < 4u;
         const uint32_t v = head ? lane : 4u * q_hi0 + (lane - 4u);
         const bool ok = head ? (v >= e.shift && v < 4u * q_lo0 && v < e.vend) : (v < e.vend && v >= 4u * q_lo0);
-        if (ok) *reinterpret_cast<uint32_t *>(out + 4u * v) = *reinterpret_cast<const uint32_t *>(src + 4u * v);
+        if (ok) {
+            const uint32_t x = *reinterpret_cast<const uint32_t *>(src + 4u * v);
+            *reinterpret_cast<uint32_t *>(out + 4u * v) = x;
+            if (kTypes) tout[v] = bytes[x];
+        }
     }
 }
 
@@ -934,7 +957,8 @@ __device__ __forceinline__ void lds_wave_sync() {
 // staging, no LDS.  (Plain stores: a block's store covers a part of one or two 128-byte lines and the next block's
 // store the rest; as non-temporal stores the parts reach memory one by one -- `[10,10,...`: 0.76 -> 1.09 ms per GiB.)
 __device__ __noinline__ void emit_dense(uint32_t *idx, const uint32_t tile_base, const uint64_t base, const uint32_t tlo,
-                                        const uint32_t thi, const uint32_t first_slot, const uint32_t lane) {
+                                        const uint32_t thi, const uint32_t first_slot, const uint32_t lane,
+                                        uint8_t *types = nullptr, const uint8_t *bytes = nullptr) {
     // out[k] = the tile's k-th index; wave-uniform (the arguments of a called function arrive in vector registers)
     const uint64_t out = uniform64(reinterpret_cast<uint64_t>(idx + base));
     const uint32_t tb = uniform32(tile_base);
@@ -955,6 +979,7 @@ __device__ __noinline__ void emit_dense(uint32_t *idx, const uint32_t tile_base,
             : [save] "=&s"(save)
             : [m] "s"(m), [off] "v"(off), [val] "v"(val), [out] "s"(out)
             : "memory");
+        if (types && ((m >> lane) & 1ull)) types[base + slot0 + rank] = bytes[val];  // (prototype: kFlagEmitTypes)
     }
 }
 
@@ -962,7 +987,7 @@ __device__ __noinline__ void emit_dense(uint32_t *idx, const uint32_t tile_base,
 __device__ __noinline__ void emit_general(uint32_t *idx, const uint64_t capacity, const uint32_t tile_base,
                                           const uint64_t base, const uint32_t shift, const uint32_t vend,
                                           uint32_t tlo, uint32_t thi, uint32_t vpos, uint32_t *stage,
-                                          const uint32_t lane) {
+                                          const uint32_t lane, uint8_t *types = nullptr, const uint8_t *bytes = nullptr) {
     const uint32_t v0 = tile_base + lane * 64u;
     for (uint32_t r0 = 0; r0 < vend; r0 += kStageWords) {
         const uint32_t r1 = r0 + kStageWords;
@@ -989,12 +1014,16 @@ __device__ __noinline__ void emit_general(uint32_t *idx, const uint64_t capacity
             const uint64_t g = gbase + 4u * q;
             if (vq >= shift && vq + 4u <= lim && g + 4u <= capacity) {
                 *reinterpret_cast<uint4 *>(&idx[g]) = val;
+                if (types) *reinterpret_cast<uint32_t *>(&types[g]) = gather_types4(bytes, val);
             } else {
                 const uint32_t vv[4] = {val.x, val.y, val.z, val.w};
 #pragma unroll
                 for (uint32_t j = 0; j < 4; j++) {
                     const uint32_t v = vq + j;
-                    if (v >= shift && v < lim && g + j < capacity) idx[g + j] = vv[j];
+                    if (v >= shift && v < lim && g + j < capacity) {
+                        idx[g + j] = vv[j];
+                        if (types) types[g + j] = bytes[vv[j]];
+                    }
                 }
             }
         }
@@ -1064,23 +1093,30 @@ __device__ __forceinline__ void emit_stage(const Shared &sh, EmitU &e, const uin
         stage_indices_round(e, v, stage, lane64, 0u);
     }
 }
+template <bool kTypes = false>
 __device__ __forceinline__ void emit_store(const KernelArgs &a, const Shared &sh, const EmitU &e, const uint32_t wave,
                                            const uint32_t slot, uint32_t *stage, const uint32_t lane, const uint32_t lane_p) {
     if (e.mode == kEmitStaged) {  // uniform
-        copy_out(a, e, stage, lane, lane_p);
+        copy_out<kTypes>(a, e, stage, lane, lane_p);
     } else if (e.mode == kEmitStaged2) {
-        copy_out(a, emit_round(e, 0u), stage, lane, lane_p);
+        copy_out<kTypes>(a, emit_round(e, 0u), stage, lane, lane_p);
         lds_wave_sync();  // the slice is reused by the second round
         const EmitV v = emit_lane(sh, wave, slot, lane, e);
         stage_indices_round(e, v, stage, lane64_of(lane), 1u);
         lds_wave_sync();
-        copy_out(a, emit_round(e, 1u), stage, lane, lane_p);
+        copy_out<kTypes>(a, emit_round(e, 1u), stage, lane, lane_p);
     } else if (e.mode == kEmitDense) {
         const EmitV v = emit_lane(sh, wave, slot, lane, e);
-        emit_dense(a.idx, e.tile_base, e.base, v.tlo, v.thi, v.vpos - e.shift, lane);
+        if (kTypes)
+            emit_dense(a.idx, e.tile_base, e.base, v.tlo, v.thi, v.vpos - e.shift, lane, a.types, a.buf - a.index_bias);
+        else
+            emit_dense(a.idx, e.tile_base, e.base, v.tlo, v.thi, v.vpos - e.shift, lane);
     } else if (e.mode == kEmitGeneral) {
         const EmitV v = emit_lane(sh, wave, slot, lane, e);
-        emit_general(a.idx, a.capacity, e.tile_base, e.base, e.shift, e.vend, v.tlo, v.thi, v.vpos, stage, lane);
+        if (kTypes)
+            emit_general(a.idx, a.capacity, e.tile_base, e.base, e.shift, e.vend, v.tlo, v.thi, v.vpos, stage, lane, a.types, a.buf - a.index_bias);
+        else
+            emit_general(a.idx, a.capacity, e.tile_base, e.base, e.shift, e.vend, v.tlo, v.thi, v.vpos, stage, lane);
     }
 }
 
@@ -1117,6 +1153,7 @@ __device__ __forceinline__ void emit_store(const KernelArgs &a, const Shared &sh
 // tile numbers, addresses, counts, the emission's mode -- is kept in scalar registers, lane-derived
 // offsets are loop invariants, and the rare cases (errors in a range, a tile cut by the end of
 // the input, escapes that cross a block) branch off uniformly.
+template <bool kTypes>
 __device__ __forceinline__ void worker_wave(const KernelArgs &a, Shared &sh, const uint32_t lane,
                                             const uint32_t wave) {
     // Ticket shard and first range: drawn at the kernel's entry (stage1_kernel), one atomic for both.
@@ -1334,7 +1371,7 @@ __device__ __forceinline__ void worker_wave(const KernelArgs &a, Shared &sh, con
         emit_stage(sh, e0, wave, slot0, stage, lane, lane64);
         lds_wave_sync();
         MSJ_STAMP(srow, 13);  // tile A staged
-        emit_store(al, sh, e0, wave, slot0, stage, lane, lane_p);
+        emit_store<kTypes>(al, sh, e0, wave, slot0, stage, lane, lane_p);
         lds_wave_sync();  // the staging slice is reused by the next tile
         MSJ_STAMP(srow, 14);  // tile A stored
         EmitU e1 = emit_prepare(al, sh, wave, slot0 + 1u, rp, count0, timeout);
@@ -1346,7 +1383,7 @@ __device__ __forceinline__ void worker_wave(const KernelArgs &a, Shared &sh, con
 #pragma unroll
         for (uint32_t j = 0; j < kBatch; j++) touch_block(blk[j]);
         MSJ_STAMP(srow, 11);  // the next range's bytes have arrived
-        emit_store(al, sh, e1, wave, slot0 + 1u, stage, lane, lane_p);
+        emit_store<kTypes>(al, sh, e1, wave, slot0 + 1u, stage, lane, lane_p);
         lds_wave_sync();
         __builtin_amdgcn_s_setprio(MSJ_PRIO_COMPUTE);
         // ---- 4. park this iteration's tiles
@@ -1380,7 +1417,7 @@ __device__ __forceinline__ void worker_wave(const KernelArgs &a, Shared &sh, con
                 EmitU e = emit_prepare(a, sh, wave, slot, w, count0, timeout);
                 emit_stage(sh, e, wave, slot, stage, lane, lane64);
                 lds_wave_sync();
-                emit_store(a, sh, e, wave, slot, stage, lane, lane);
+                emit_store<kTypes>(a, sh, e, wave, slot, stage, lane, lane);
                 lds_wave_sync();  // the staging slice is reused by the next tile
             }
         }
@@ -1820,7 +1857,8 @@ __global__ __launch_bounds__(kThreads) void twopass_emit_kernel(const KernelArgs
     emit_store(a, sh, e, wave, 0, stage, lane, lane);
 }
 
-__global__ __launch_bounds__(kThreads, 4) void stage1_kernel(const KernelArgs a) {
+template <bool kTypes>
+__device__ __forceinline__ void stage1_body(const KernelArgs &a) {
     __shared__ Shared sh;
     const uint32_t tid = threadIdx.x;
     // ONE atomic per workgroup at start-up gives it its job.  A workgroup belongs to a ticket shard
@@ -1849,8 +1887,11 @@ __global__ __launch_bounds__(kThreads, 4) void stage1_kernel(const KernelArgs a)
         return;
     }
     // the wave index is wave-uniform: say so, or every tile-derived value and branch is vector code
-    worker_wave(a, sh, tid & 63u, uniform32(tid >> 6));
+    worker_wave<kTypes>(a, sh, tid & 63u, uniform32(tid >> 6));
 }
+__global__ __launch_bounds__(kThreads, 4) void stage1_kernel(const KernelArgs a) { stage1_body<false>(a); }
+// PROTOTYPE (round 5, kFlagEmitTypes): the same kernel, the type bytes written beside the indices
+__global__ __launch_bounds__(kThreads, 4) void stage1_types_kernel(const KernelArgs a) { stage1_body<true>(a); }
 
 }  // namespace msj
 
@@ -1859,8 +1900,10 @@ extern "C" int msj_launch_stage1(const msj::KernelArgs *args, void *stream, uint
     // persistent workgroups of kWaves worker waves, plus the resolver workgroup
     const uint32_t need = (a.ntiles + msj::kWaves - 1u) / msj::kWaves + 1u;
     const uint32_t g = (grid == 0 || grid > need) ? need : grid;
-    hipLaunchKernelGGL(msj::stage1_kernel, dim3(g < 2u ? 2u : g), dim3(msj::kThreads), 0,
-                       static_cast<hipStream_t>(stream), a);
+    if (a.flags & msj::kFlagEmitTypes)
+        hipLaunchKernelGGL(msj::stage1_types_kernel, dim3(g < 2u ? 2u : g), dim3(msj::kThreads), 0, static_cast<hipStream_t>(stream), a);
+    else
+        hipLaunchKernelGGL(msj::stage1_kernel, dim3(g < 2u ? 2u : g), dim3(msj::kThreads), 0, static_cast<hipStream_t>(stream), a);
     return (int)hipGetLastError();
 }
 

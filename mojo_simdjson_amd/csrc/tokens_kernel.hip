@@ -627,7 +627,11 @@ __global__ __launch_bounds__(kThreads) void apply_depth(const uint8_t *__restric
     (void)open_start;
     // everything the block touches, as uniform (scalar) base pointers: the lanes add 32-bit offsets inside the block
     const uint64_t b0 = (uint64_t)blockIdx.x * kBlock;
-    const uint32_t nrem = (uint32_t)(n - b0 < (uint64_t)kBlock ? n - b0 : (uint64_t)kBlock);
+    // tokens of this block: n < 2^31 (the entry points check), so 32-bit arithmetic and ONE s_min_u32.  (Written as a
+    // 64-bit compare + select, hipcc 7.2 lowered the select to an s_cselect on an SCC that another select's condition had
+    // set -- the not-full path then ran with nrem = 2 048 on the stream's last block and folded the stale type bytes
+    // behind the stream's end into the minimum / maximum depth: found by test_stage2_prep_1gib_replicated.)
+    const uint32_t nrem = min((uint32_t)n - blockIdx.x * kBlock, kBlock);
     const int block_depth0 = (prev ? prev->final_depth : 0) + super_start[blockIdx.x / kSuper] + block_start[blockIdx.x];  // uniform
     int32_t *m8 = min8 ? min8 + (b0 >> 3) : nullptr, *m64 = min8 ? min64 + (b0 >> 6) : nullptr, *m512 = min8 ? min512 + (b0 >> 9) : nullptr;
     __shared__ DepthShared<kMatch> sh;
@@ -2383,6 +2387,59 @@ int msj_launch_stage2_prep(const uint8_t *d_buf, uint64_t len, const uint32_t *d
         hipLaunchKernelGGL(merge_chunk_counts, dim3((nb * 16u + 255u) / 256u), dim3(256), 0, s, sub, (uint32_t)chunk_count(n), d_ws, nb);
     }
     return launch_depth_passes(d_idx, n, d_type, d_depth, d_match, d_result, d_ws, s, o);
+}
+
+// ---- PROTOTYPE (round 5): depth (and partners) from type bytes that stage 1 wrote itself
+// (msj_stage1_types_device) -- the bracket counts per block from one pass over type[] (1 byte per token), then the scans
+// and apply_depth as above.  One thread per 16 tokens, one wave per 1 024, two waves per block of 2 048.
+namespace msj_tokens {
+__global__ __launch_bounds__(256) void count_brackets(const uint8_t *__restrict__ type, uint32_t n, int32_t *__restrict__ block_agg) {
+    const uint32_t t = blockIdx.x * 256u + threadIdx.x, first = t * 16u;
+    uint32_t ups = 0, downs = 0;
+    if (first + 16u <= n) {
+        const uint4 q = *reinterpret_cast<const uint4 *>(type + first);
+        const uint32_t w[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const uint32_t x = w[k] & 0xDFDFDFDFu;  // '[' '{' -> 5B, ']' '}' -> 5D
+            ups += (uint32_t)__builtin_popcount(zero_bytes32(x ^ 0x5B5B5B5Bu));
+            downs += (uint32_t)__builtin_popcount(zero_bytes32(x ^ 0x5D5D5D5Du));
+        }
+    } else {
+        for (uint32_t i = first; i < n; i++) {
+            const uint32_t c = type[i] & 0xDFu;
+            ups += c == 0x5Bu;
+            downs += c == 0x5Du;
+        }
+    }
+    // 128 threads = one block of 2 048 tokens: two waves, summed through LDS
+    ups = wave_incl_sum(ups);
+    downs = wave_incl_sum(downs);
+    __shared__ uint32_t s_up[4], s_dn[4];
+    const uint32_t wave = threadIdx.x >> 6;
+    if ((threadIdx.x & 63u) == 63u) {
+        s_up[wave] = ups;
+        s_dn[wave] = downs;
+    }
+    __syncthreads();
+    if ((threadIdx.x & 127u) == 0u) {
+        const uint32_t b = t >> 7;
+        if ((uint64_t)b * kBlock < n) {
+            const uint32_t u = s_up[wave] + s_up[wave + 1], d = s_dn[wave] + s_dn[wave + 1];
+            *reinterpret_cast<int4 *>(block_agg + 4 * (uint64_t)b) = make_int4((int)u - (int)d, kNone, -kNone, (int)u);
+        }
+    }
+}
+}  // namespace msj_tokens
+
+extern "C" int msj_launch_depth_from_types(const uint8_t *d_type, uint64_t n, int32_t *d_depth, uint32_t *d_match, msj_tokens_result *d_result,
+                                           int32_t *d_ws, void *stream, const msj_token_opts &o) {
+    using namespace msj_tokens;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const uint64_t nb64 = (n + kBlock - 1) / kBlock;
+    if (nb64 > 0x7FFFFFFFull) return (int)hipErrorInvalidValue;
+    if (n) hipLaunchKernelGGL(count_brackets, dim3((uint32_t)((nb64 * 128u + 255u) / 256u)), dim3(256), 0, s, d_type, (uint32_t)n, d_ws);
+    return launch_depth_passes(nullptr, n, const_cast<uint8_t *>(d_type), d_depth, d_match, d_result, d_ws, s, o);
 }
 
 int msj_launch_tokens(const uint8_t *d_buf, uint64_t len, const uint32_t *d_idx, uint64_t n, uint8_t *d_type, int32_t *d_depth,

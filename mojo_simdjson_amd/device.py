@@ -71,6 +71,30 @@ class Stage1Device:
             raise RuntimeError(f"msj_stage1_device failed: {rc}")
         return rc
 
+    def index_types(self, d_buf, d_idx, d_types, d_result, flags=0, length=None):
+        """PROTOTYPE (``msj_stage1_types_device``): ``index`` that also writes d_types[k] = d_buf[d_idx[k]] beside every index."""
+        n = int(d_buf.numel() if length is None else length)
+        rc = self.lib.msj_stage1_types_device(self.ctx, _ptr(d_buf), n, _ptr(d_idx), d_idx.numel(), _ptr(d_types), _ptr(d_result),
+                                              self._stream(), flags)
+        if rc != 0:
+            raise RuntimeError(f"msj_stage1_types_device failed: {rc}")
+        return rc
+
+    def depth_from_types(self, d_type, n, d_depth=None, d_match=None, match=False, d_result=None, d_prev=None):
+        """PROTOTYPE (``msj_depth_from_types_device``): depth (and partners) of every token from type bytes stage 1 wrote.
+        Asynchronous; returns (d_depth, d_match or None, d_result)."""
+        n = int(n)
+        if d_depth is None:
+            d_depth = torch.empty(max(n, 4), dtype=torch.int32, device=self.device)
+        if match and d_match is None:
+            d_match = torch.empty(max(n, 4), dtype=torch.int32, device=self.device)
+        d_res = d_result if d_result is not None else torch.zeros(24, dtype=torch.uint8, device=self.device)
+        rc = self.lib.msj_depth_from_types_device(self.ctx, _ptr(d_type), n, _ptr(d_depth), _ptr(d_match) if d_match is not None else None,
+                                                  _ptr(d_res), _ptr(d_prev) if d_prev is not None else None, self._stream())
+        if rc != 0:
+            raise RuntimeError(f"msj_depth_from_types_device failed: {rc}")
+        return d_depth, d_match, d_res
+
     def shard(self, d_buf, length, d_idx, carry_in, carry_out, segments=None, has_prefix=False,
               is_final=False, no_emit=False, trailer_len=0, flags=0):
         nseg = ctypes.c_uint32(0)

@@ -745,3 +745,72 @@ def test_prep_segments_over_4gib(dev):
             crossing += int((has & ((pg < ib) | (pg >= ib + cnt))).sum())
     assert crossing >= 4 and crossing % 2 == 0, crossing  # the cut lies inside a unit: its root object and array at least
     assert results[1].reserved >> 31 == 0
+
+
+@pytest.mark.gpu
+def test_types_from_stage1_prototype(dev):
+    """PROTOTYPE: msj_stage1_types_device writes d_types[k] = buf[idx[k]] beside every index
+    from the same emission, msj_depth_from_types_device turns them into depths (and partners): both equal what the
+    separate calls and the definitions give -- fixtures, workloads (every emission path: staged, two rounds, block-wise,
+    clipped), soups, a 1 GiB stream."""
+    import torch
+    from mojo_simdjson_amd import synth
+
+    oracle = helpers.load_oracle()
+    docs = []
+    for f in helpers.golden_valid_files():
+        docs.append((f, helpers.read_fixture(f)[0]))
+    for name in ("minified", "utf8", "pretty4"):
+        docs.append((name, synth.workload(name, 4 << 20).tobytes()))
+    for kind in (0, 1, 4, 5, 6, 7):
+        docs.append((f"extreme {kind}", synth.extreme((1 << 20) - 52, kind).tobytes()))
+    rng = np.random.default_rng(17)
+    alphabet = np.frombuffer(b'{}[]{}[],: "a1\\tn', dtype=np.uint8)
+    for n in (1, 2, 7, 63, 64, 65, 4095, 4096, 4097, 70001):
+        docs.append((f"soup {n}", alphabet[rng.integers(0, len(alphabet), n)].tobytes()))
+    for where, data in docs:
+        if isinstance(data, str):
+            data = data.encode()
+        d_buf = torch.from_numpy(np.frombuffer(data, dtype=np.uint8).copy()).to(dev.device)
+        d_idx = torch.zeros(len(data) + 3 + 4, dtype=torch.int32, device=dev.device)
+        d_types = torch.zeros(len(data) + 3 + 4, dtype=torch.uint8, device=dev.device)
+        d_res = dev.new_carry()
+        dev.index_types(d_buf, d_idx, d_types, d_res)
+        r = dev.fetch(d_res)
+        n = int(r.count)
+        idx = d_idx[:n].cpu().numpy().view(np.uint32)
+        code, wn, widx = helpers.run_oracle(oracle.msj_oracle_stage1, data)
+        if code in (0, 13):
+            assert n == wn and np.array_equal(idx, widx[:n]), where
+        arr = np.frombuffer(data, dtype=np.uint8)
+        assert np.array_equal(d_types[:n].cpu().numpy(), arr[idx]), where
+        if n:
+            d_depth, d_match, d_tr = dev.depth_from_types(d_types, n, match=True)
+            wt, wd, (final, mn, mx) = helpers.oracle_tokens(data, idx)
+            assert np.array_equal(d_depth[:n].cpu().numpy(), wd), where
+            assert np.array_equal(d_match[:n].cpu().numpy().view(np.uint32), helpers.oracle_match(wt)), where
+    # an index buffer that is too small: the clipped emission writes the types it writes indices for
+    data = b"[" * 5000 + b"]" * 5000
+    d_buf = torch.from_numpy(np.frombuffer(data, dtype=np.uint8).copy()).to(dev.device)
+    d_idx = torch.zeros(6000, dtype=torch.int32, device=dev.device)
+    d_types = torch.zeros(6000, dtype=torch.uint8, device=dev.device)
+    d_res = dev.new_carry()
+    dev.index_types(d_buf, d_idx, d_types, d_res)
+    assert dev.fetch(d_res).code == 1
+    assert d_types[:5000].cpu().numpy().tobytes() == b"[" * 5000 and d_types[5000:6000].cpu().numpy().tobytes() == b"]" * 1000
+    # full size: 1 GiB minified, replicated unit
+    u = synth.workload("minified", 64 << 20)
+    b = u.tobytes()
+    idx_u = _stage1(oracle, b)
+    wt, wd, _ = helpers.oracle_tokens(b, idx_u)
+    reps = 16
+    d_buf = torch.from_numpy(u).to(dev.device).repeat(reps)
+    nu = len(idx_u)
+    d_idx = torch.empty(nu * reps + 16, dtype=torch.int32, device=dev.device)
+    d_types = torch.empty(nu * reps + 16, dtype=torch.uint8, device=dev.device)
+    d_res = dev.new_carry()
+    dev.index_types(d_buf, d_idx, d_types, d_res)
+    assert int(dev.fetch(d_res).count) == nu * reps
+    assert torch.equal(d_types[:nu * reps].view(reps, -1), torch.from_numpy(wt).to(dev.device).expand(reps, -1))
+    d_depth, _, _ = dev.depth_from_types(d_types, nu * reps)
+    assert torch.equal(d_depth[:nu * reps].view(reps, -1), torch.from_numpy(wd).to(dev.device).expand(reps, -1))
