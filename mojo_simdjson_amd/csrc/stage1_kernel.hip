@@ -862,7 +862,12 @@ __device__ __forceinline__ void st_index_quad(uint8_t *p, const uint4 v) {
 }
 
 // kTypes (prototype): the type byte of four indices -- four byte gathers from the tile's bytes (L2 / MALL: the tile was
-// read two iterations ago), packed into the dword that lies beside the quad in types[]
+// read two iterations ago), packed into the dword that lies beside the quad in types[].  Measured (scripts/fused_types.py,
+// profiles/r05/fused_types_*.txt): the gathers cost stage 1 0.235 ms per GiB minified (0.314 -> 0.549) -- 16 load
+// instructions per tile, each 64 scattered bytes = up to 32 cache lines: eight times the requests of the tile's own read --
+// and requesting all of a tile's rounds before the first is looked at made it 0.573, not faster: it is the texture
+// path's request rate, not the round trips.  The next step would be the tile's 4 KiB re-read coalesced into the staging
+// slice behind the copy-out and ds_read_u8 gathers from there.
 __device__ __forceinline__ uint32_t gather_types4(const uint8_t *bytes, const uint4 v) {
     return (uint32_t)bytes[v.x] | ((uint32_t)bytes[v.y] << 8) | ((uint32_t)bytes[v.z] << 16) | ((uint32_t)bytes[v.w] << 24);
 }
