@@ -473,6 +473,25 @@ int32_t msj_token_spans_device(msj_ctx *ctx, const uint8_t *d_buf, uint64_t len,
                                uint32_t *d_end, uint8_t *d_flags, void *stream);
 
 /*
+ * Bracket partners as a COMPACT LIST (round 5): d_pairs[k] = {token index of the k-th opening bracket of the call, token
+ * index of the bracket that closes its container, 0xFFFFFFFF if it is never closed inside the call}, k in the order of
+ * the opening brackets; d_result->reserved is their number, the array needs room for as many (n at most).  Eight bytes per
+ * CONTAINER instead of the four bytes per TOKEN of d_match -- brackets are 8 % of the minified workload's tokens -- for
+ * the consumer that walks the tokens in order and takes one record at every opening bracket, the way the reference's
+ * stage 2 pushes in start_container and pops in end_container (generic/stage2/tape_builder.mojo:235-272).  Same arguments
+ * and results otherwise as msj_tokens_chain_device / msj_stage2_prep_chain_device without d_match; d_pairs 8-byte aligned.
+ */
+typedef struct msj_bracket_pair {
+    uint32_t open, close;
+} msj_bracket_pair;
+int32_t msj_tokens_pairs_device(msj_ctx *ctx, const uint8_t *d_buf, uint64_t len, const uint32_t *d_idx, uint64_t n, uint8_t *d_type,
+                                int32_t *d_depth, msj_bracket_pair *d_pairs, msj_tokens_result *d_result,
+                                const msj_tokens_result *d_prev, void *stream);
+int32_t msj_stage2_prep_pairs_device(msj_ctx *ctx, const uint8_t *d_buf, uint64_t len, const uint32_t *d_idx, uint64_t n,
+                                     uint8_t *d_type, int32_t *d_depth, msj_bracket_pair *d_pairs, uint32_t *d_end, uint8_t *d_flags,
+                                     msj_tokens_result *d_result, const msj_tokens_result *d_prev, void *stream);
+
+/*
  * PROTOTYPE (round 5; SURVEY.md section 8 row f1 from ONE pass over the bytes; measured and decided in DESIGN.md section 5b):
  * msj_stage1_types_device -- msj_stage1_device that also writes d_types[k] = d_buf[d_idx[k]], the type byte stage 2's
  *   JsonIterator.advance dereferences (generic/stage2/json_iterator.mojo:256-262), beside every index from the same

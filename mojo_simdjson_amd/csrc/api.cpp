@@ -811,9 +811,23 @@ int32_t msj_tokens_device(msj_ctx *ctx, const uint8_t *d_buf, uint64_t len, cons
     return msj_tokens_chain_device(ctx, d_buf, len, d_idx, n, d_type, d_depth, d_match, d_result, nullptr, stream);
 }
 
+static int32_t tokens_chain_impl(msj_ctx *ctx, const uint8_t *d_buf, uint64_t len, const uint32_t *d_idx, uint64_t n, uint8_t *d_type,
+                                 int32_t *d_depth, uint32_t *d_match, msj_tokens_result *d_result, const msj_tokens_result *d_prev,
+                                 void *stream, msj_bracket_pair *d_pairs);
 int32_t msj_tokens_chain_device(msj_ctx *ctx, const uint8_t *d_buf, uint64_t len, const uint32_t *d_idx, uint64_t n,
                                 uint8_t *d_type, int32_t *d_depth, uint32_t *d_match, msj_tokens_result *d_result,
                                 const msj_tokens_result *d_prev, void *stream) {
+    return tokens_chain_impl(ctx, d_buf, len, d_idx, n, d_type, d_depth, d_match, d_result, d_prev, stream, nullptr);
+}
+int32_t msj_tokens_pairs_device(msj_ctx *ctx, const uint8_t *d_buf, uint64_t len, const uint32_t *d_idx, uint64_t n, uint8_t *d_type,
+                                int32_t *d_depth, msj_bracket_pair *d_pairs, msj_tokens_result *d_result,
+                                const msj_tokens_result *d_prev, void *stream) {
+    if (!d_pairs || (reinterpret_cast<uintptr_t>(d_pairs) & 7u)) return MSJ_ERR_BAD_ARGUMENT;
+    return tokens_chain_impl(ctx, d_buf, len, d_idx, n, d_type, d_depth, nullptr, d_result, d_prev, stream, d_pairs);
+}
+static int32_t tokens_chain_impl(msj_ctx *ctx, const uint8_t *d_buf, uint64_t len, const uint32_t *d_idx, uint64_t n, uint8_t *d_type,
+                                 int32_t *d_depth, uint32_t *d_match, msj_tokens_result *d_result, const msj_tokens_result *d_prev,
+                                 void *stream, msj_bracket_pair *d_pairs) {
     if (!ctx || !d_result || d_prev == d_result) return MSJ_ERR_BAD_ARGUMENT;
     if (n > 0 && (!d_buf || !d_idx || !d_type || !d_depth)) return MSJ_ERR_BAD_ARGUMENT;
     if (len > MSJ_MAX_SEGMENT_BYTES || n >= (1ull << 31)) return MSJ_CAPACITY;
@@ -821,11 +835,12 @@ int32_t msj_tokens_chain_device(msj_ctx *ctx, const uint8_t *d_buf, uint64_t len
         (reinterpret_cast<uintptr_t>(d_type) & 7u) || (reinterpret_cast<uintptr_t>(d_match) & 15u))  // match[] leaves as 16-byte stores
         return MSJ_ERR_BAD_ARGUMENT;
     if (!hip_ok(hipSetDevice(ctx->device))) return MSJ_ERR_HIP;
-    const uint64_t need = msj_stage2_prep_workspace_bytes(n, len, d_match != nullptr);  // incl. the fused kernel's chunk aggregates and table
+    const uint64_t need = msj_stage2_prep_workspace_bytes(n, len, d_match != nullptr || d_pairs != nullptr);  // incl. the fused kernel's chunk aggregates and table
     if (!ensure_tok_ws(ctx, need)) return MSJ_MEMALLOC;
     ctx->tok_doc_n = ~0ull;
     msj_token_opts o = ctx->tok_opts;
     o.d_prev = d_prev;
+    o.d_pairs = d_pairs;
     if (msj_launch_tokens(d_buf, len, d_idx, n, d_type, d_depth, d_match, d_result, ctx->tok_ws, stream, o) != 0) return MSJ_ERR_HIP;
     ctx->tok_doc_n = n;
     return MSJ_SUCCESS;
@@ -865,7 +880,15 @@ int32_t msj_stage2_prep_device(msj_ctx *ctx, const uint8_t *d_buf, uint64_t len,
 
 static int32_t prep_chain_impl(msj_ctx *ctx, const uint8_t *d_buf, uint64_t len, const uint32_t *d_idx, uint64_t n, uint8_t *d_type,
                                int32_t *d_depth, uint32_t *d_match, uint32_t *d_end, uint8_t *d_flags, msj_tokens_result *d_result,
-                               const msj_tokens_result *d_prev, void *stream, uint32_t match_bias, uint32_t *d_resid);
+                               const msj_tokens_result *d_prev, void *stream, uint32_t match_bias, uint32_t *d_resid,
+                               msj_bracket_pair *d_pairs = nullptr);
+
+int32_t msj_stage2_prep_pairs_device(msj_ctx *ctx, const uint8_t *d_buf, uint64_t len, const uint32_t *d_idx, uint64_t n,
+                                     uint8_t *d_type, int32_t *d_depth, msj_bracket_pair *d_pairs, uint32_t *d_end, uint8_t *d_flags,
+                                     msj_tokens_result *d_result, const msj_tokens_result *d_prev, void *stream) {
+    if (!d_pairs || (reinterpret_cast<uintptr_t>(d_pairs) & 7u)) return MSJ_ERR_BAD_ARGUMENT;
+    return prep_chain_impl(ctx, d_buf, len, d_idx, n, d_type, d_depth, nullptr, d_end, d_flags, d_result, d_prev, stream, 0u, nullptr, d_pairs);
+}
 
 int32_t msj_stage2_prep_chain_device(msj_ctx *ctx, const uint8_t *d_buf, uint64_t len, const uint32_t *d_idx, uint64_t n,
                                      uint8_t *d_type, int32_t *d_depth, uint32_t *d_match, uint32_t *d_end, uint8_t *d_flags,
@@ -876,7 +899,8 @@ int32_t msj_stage2_prep_chain_device(msj_ctx *ctx, const uint8_t *d_buf, uint64_
 // match_bias / d_resid: msj_stage2_prep_segments (partners as positions in the shard's arrays, the call's unpaired brackets kept)
 static int32_t prep_chain_impl(msj_ctx *ctx, const uint8_t *d_buf, uint64_t len, const uint32_t *d_idx, uint64_t n, uint8_t *d_type,
                                int32_t *d_depth, uint32_t *d_match, uint32_t *d_end, uint8_t *d_flags, msj_tokens_result *d_result,
-                               const msj_tokens_result *d_prev, void *stream, uint32_t match_bias, uint32_t *d_resid) {
+                               const msj_tokens_result *d_prev, void *stream, uint32_t match_bias, uint32_t *d_resid,
+                               msj_bracket_pair *d_pairs) {
     if (!ctx || !d_result || d_prev == d_result) return MSJ_ERR_BAD_ARGUMENT;
     if (n > 0 && (!d_buf || !d_idx || !d_type || !d_depth || !d_end || !d_flags)) return MSJ_ERR_BAD_ARGUMENT;
     if (len > MSJ_MAX_SEGMENT_BYTES || n >= (1ull << 31)) return MSJ_CAPACITY;
@@ -884,7 +908,7 @@ static int32_t prep_chain_impl(msj_ctx *ctx, const uint8_t *d_buf, uint64_t len,
         (reinterpret_cast<uintptr_t>(d_type) & 7u) || (reinterpret_cast<uintptr_t>(d_match) & 15u))  // match[] leaves as 16-byte stores
         return MSJ_ERR_BAD_ARGUMENT;
     if (!hip_ok(hipSetDevice(ctx->device))) return MSJ_ERR_HIP;
-    const uint64_t need = msj_stage2_prep_workspace_bytes(n, len, d_match != nullptr);
+    const uint64_t need = msj_stage2_prep_workspace_bytes(n, len, d_match != nullptr || d_pairs != nullptr);
     if (!ensure_tok_ws(ctx, need)) return MSJ_MEMALLOC;
     ctx->tok_doc_n = ~0ull;
     if (!ensure_span_fix(ctx)) return MSJ_MEMALLOC;
@@ -892,6 +916,7 @@ static int32_t prep_chain_impl(msj_ctx *ctx, const uint8_t *d_buf, uint64_t len,
     o.d_prev = d_prev;
     o.match_bias = match_bias;
     o.d_resid = d_match ? d_resid : nullptr;
+    o.d_pairs = d_pairs;
     if (msj_launch_stage2_prep(d_buf, len, d_idx, n, d_type, d_depth, d_match, d_end, d_flags, d_result, ctx->tok_ws, ctx->span_fix, stream, o) != 0)
         return MSJ_ERR_HIP;
     ctx->tok_doc_n = n;

@@ -308,25 +308,34 @@ constexpr int kMatchBelow = 4;
 // kFull: every token of the block exists (all blocks of a call but the last): no guards against n at all -- they were
 // 64-bit compares, eight per loop (round 5: 661 -> ~450 vector instructions per wave together with block-relative
 // 32-bit addressing, the DPP minima and the skipped document counts; profiles/r05/apply_depth_*.txt).
-template <bool kMatch>
+// kMode: 0 = depths only; 1 = + match[] (a partner index per token: 4 bytes per token out); 2 = + pairs[] (round 5: one
+// {open, close} record per CONTAINER, in the order of the opening brackets -- 8 bytes per container instead of 4 per token:
+// 0.64 instead of 4 bytes per token of the minified workload; what a consumer that walks the tokens in order takes one
+// entry of at every opening bracket, the way start_container pushes and end_container pops,
+// generic/stage2/tape_builder.mojo:235-272)
+template <int kMode>
 struct DepthShared {
+    static constexpr bool kMatch = kMode != 0;
     uint32_t bm[kMatch ? kMatchLevels : 1][kMatch ? kBlock / 32 : 1];  // opening brackets per level, one bit per token
     unsigned long long bm_words[kMatch ? kMatchLevels : 1];              // ... and which of a level's 64 words are not empty
-    __attribute__((aligned(16))) uint32_t s_match[kMatch ? kBlock : 4];
-    uint32_t s_paired[kMatch ? kBlock / 32 : 1];                         // one bit per token: it has a partner in s_match
+    __attribute__((aligned(16))) uint32_t s_match[kMode == 1 ? kBlock : 4];
+    uint32_t s_paired[kMatch ? kBlock / 32 : 1];                         // one bit per token: it has a partner
+    uint16_t s_pre[kMode == 2 ? kThreads : 2];                           // pairs: opening brackets of the block in front of each thread's tokens
+    uint8_t s_om[kMode == 2 ? kThreads : 4];                             // ... and which of the thread's eight tokens are opening brackets
     int wave_sum[kThreads / 64];
     int wave_no[kThreads / 64];
     int wave_rmn[kThreads / 64], wave_rmx[kThreads / 64];
     uint32_t doc_cnt[kThreads / 64], doc_start[kThreads / 64], doc_close[kThreads / 64];
     __attribute__((aligned(16))) int s_out[kThreads / 64][512];          // the depths' way out (1 KiB contiguous per store instruction)
 };
-template <bool kMatch, bool kFull>
-__device__ __forceinline__ void apply_depth_block(DepthShared<kMatch> &sh, const uint8_t *__restrict__ type, const uint32_t nrem /* tokens of this block */,
+template <int kMode, bool kFull>
+__device__ __forceinline__ void apply_depth_block(DepthShared<kMode> &sh, const uint8_t *__restrict__ type, const uint32_t nrem /* tokens of this block */,
                                                   const int block_depth0, int32_t *__restrict__ depth_blk, int32_t *__restrict__ min8,
                                                   int32_t *__restrict__ min64, int32_t *__restrict__ min512, uint32_t *__restrict__ opens,
                                                   uint4 *__restrict__ doc_agg, int32_t *__restrict__ block_mm,
                                                   uint32_t *__restrict__ match_blk, uint32_t *__restrict__ survivors, const uint32_t match_bias,
-                                                  const uint32_t want_closers) {
+                                                  const uint32_t want_closers, uint2 *__restrict__ pairs_blk, const uint32_t open_base) {
+    constexpr bool kMatch = kMode != 0;
     // (the LDS lives in the kernel: two instantiations of this function must not own two copies of it)
     auto &bm = sh.bm;
     auto &bm_words = sh.bm_words;
@@ -392,7 +401,7 @@ __device__ __forceinline__ void apply_depth_block(DepthShared<kMatch> &sh, const
         }
     }
     bool surv_any = false;
-    uint32_t surv_incl = 0, surv_slot = 0, surv_mine = 0, surv_mask = 0, cand_mask = 0;
+    uint32_t surv_incl = 0, surv_slot = 0, surv_mine = 0, surv_mask = 0, cand_mask = 0, surv_rank0 = 0, surv_om = 0;
     if (kMatch) {
         const int level0 = block_depth0 - kMatchBelow;
         // (a) the opening brackets' bits (the zeroing above is behind the barrier that published wave_sum).  Brackets are
@@ -407,6 +416,13 @@ __device__ __forceinline__ void apply_depth_block(DepthShared<kMatch> &sh, const
         }
         if (!kFull) om &= vm, cm &= vm;  // (a blank stands in for a token that does not exist: no bracket anyway)
         const int before0 = out[0] + (d[0] < 0 ? 1 : 0);  // the running depth in front of this thread's first token
+        uint32_t excl_no = 0;  // pairs: opening brackets of the block in front of this thread's tokens = their rank
+        if (kMode == 2) {
+            excl_no = (uint32_t)(incl_no - no);
+            for (int w = 0; w < wave; w++) excl_no += (uint32_t)wave_no[w];
+            sh.s_pre[threadIdx.x] = (uint16_t)excl_no;
+            sh.s_om[threadIdx.x] = (uint8_t)om;  // (visible behind the barrier between (a) and (c))
+        }
         for (uint32_t rem = om; __ballot(rem != 0u) != 0ull;) {  // uniform
             if (rem != 0u) {
                 const uint32_t k = (uint32_t)__builtin_ctz(rem), below = (1u << k) - 1u;
@@ -442,9 +458,16 @@ __device__ __forceinline__ void apply_depth_block(DepthShared<kMatch> &sh, const
                     }
                     if (m != 0u) {
                         const uint32_t i = 32u * wi + 31u - (uint32_t)__clz((int)m);
-                        const uint32_t b0 = blk0 + match_bias;  // + the call's place in the shard (msj_stage2_prep_segments)
-                        s_match[t] = b0 + i;
-                        s_match[i] = b0 + t;
+                        if (kMode == 1) {
+                            const uint32_t b0 = blk0 + match_bias;  // + the call's place in the shard (msj_stage2_prep_segments)
+                            s_match[t] = b0 + i;
+                            s_match[i] = b0 + t;
+                        } else {
+                            // the container's record: at the opening bracket's rank among the call's opening brackets
+                            const uint32_t ti = i >> 3;
+                            const uint32_t r = (uint32_t)sh.s_pre[ti] + (uint32_t)__builtin_popcount((uint32_t)sh.s_om[ti] & ((1u << (i & 7u)) - 1u));
+                            pairs_blk[r] = make_uint2(blk0 + i, blk0 + t);
+                        }
                         atomicOr(&s_paired[w], 1u << (t & 31u));
                         atomicOr(&s_paired[wi], 1u << (i & 31u));
                     }
@@ -456,6 +479,8 @@ __device__ __forceinline__ void apply_depth_block(DepthShared<kMatch> &sh, const
         // (the thread's eight tokens are one byte of a word of s_paired)
         const uint32_t paired8 = s_paired[t0 >> 5] >> (t0 & 31u);
         surv_mask = om & ~paired8;
+        surv_rank0 = excl_no;
+        surv_om = om;
         // ... and (a shard call only) the closing brackets below the block's start depth that nothing in the block paired:
         // bits 8..15, listed with bit 31 set; match_brackets skips them, collect_closers keeps those still unpaired
         if (want_closers) surv_mask |= (cand_mask & ~paired8 & 0xFFu) << 8;
@@ -470,7 +495,9 @@ __device__ __forceinline__ void apply_depth_block(DepthShared<kMatch> &sh, const
         surv_mine = mine;
         // (e) the block's slice of match[]: 1 KiB contiguous per store instruction, like the depths below
         const uint32_t wb = (uint32_t)wave * 512u;
-        if (kFull || wb + 512u <= nrem) {  // uniform per wave
+        if (kMode != 1) {
+            // pairs: nothing per token
+        } else if (kFull || wb + 512u <= nrem) {  // uniform per wave
             typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
             // tokens 4 lane .. 4 lane + 3 of the wave's first and second half: a nibble of s_paired each
             const uint32_t q0 = wb + 4u * lane, q1 = q0 + 256u;
@@ -602,10 +629,20 @@ __device__ __forceinline__ void apply_depth_block(DepthShared<kMatch> &sh, const
         const uint32_t shard = blockIdx.x % kSurvivorShards;
         uint32_t *list = opens + (uint64_t)shard * survivor_capacity(gridDim.x);
         uint32_t slot = (uint32_t)__builtin_amdgcn_readlane((int)surv_slot, 63) + surv_incl - surv_mine;
+        if (kMode == 2) {  // two words per entry: the token and its rank among the call's opening brackets (the record's place)
+            list += (uint64_t)shard * survivor_capacity(gridDim.x);  // (the lists are twice as long)
+#pragma unroll
+            for (int k = 0; k < kPer; k++)
+                if ((surv_mask >> k) & 1u) {
+                    list[2u * slot] = blk0 + t0 + (uint32_t)k;
+                    list[2u * slot + 1u] = open_base + surv_rank0 + (uint32_t)__builtin_popcount(surv_om & ((1u << k) - 1u));
+                    slot++;
+                }
+        } else
 #pragma unroll
         for (int k = 0; k < kPer; k++)
             if ((surv_mask >> k) & 1u) list[slot++] = blk0 + t0 + (uint32_t)k;
-        if (surv_mask >> 8) {
+        if (kMode != 2 && (surv_mask >> 8)) {
 #pragma unroll
             for (int k = 0; k < kPer; k++)
                 if ((surv_mask >> (8 + k)) & 1u) list[slot++] = (blk0 + t0 + (uint32_t)k) | 0x80000000u;
@@ -613,7 +650,7 @@ __device__ __forceinline__ void apply_depth_block(DepthShared<kMatch> &sh, const
     }
 }
 
-template <bool kMatch>
+template <int kMode>
 __global__ __launch_bounds__(kThreads) void apply_depth(const uint8_t *__restrict__ type, uint64_t n,
                                                         const int32_t *__restrict__ block_start, const int32_t *__restrict__ super_start,
                                                         const uint32_t *__restrict__ super_open, int32_t *__restrict__ depth,
@@ -622,9 +659,10 @@ __global__ __launch_bounds__(kThreads) void apply_depth(const uint8_t *__restric
                                                         uint32_t *__restrict__ opens, uint4 *__restrict__ doc_agg,
                                                         int32_t *__restrict__ block_mm, const msj_tokens_result *__restrict__ prev,
                                                         uint32_t *__restrict__ match, uint32_t *__restrict__ survivors, uint32_t match_bias,
-                                                        uint32_t want_closers) {
-    (void)super_open;
-    (void)open_start;
+                                                        uint32_t want_closers, uint2 *__restrict__ pairs) {
+    constexpr bool kMatch = kMode != 0;
+    // pairs: the number of opening brackets of the call in front of this block = where its containers' records start
+    const uint32_t open_base = kMode == 2 ? super_open[blockIdx.x / kSuper] + open_start[blockIdx.x] : 0u;
     // everything the block touches, as uniform (scalar) base pointers: the lanes add 32-bit offsets inside the block
     const uint64_t b0 = (uint64_t)blockIdx.x * kBlock;
     // tokens of this block: n < 2^31 (the entry points check), so 32-bit arithmetic and ONE s_min_u32.  (Written as a
@@ -634,13 +672,16 @@ __global__ __launch_bounds__(kThreads) void apply_depth(const uint8_t *__restric
     const uint32_t nrem = min((uint32_t)n - blockIdx.x * kBlock, kBlock);
     const int block_depth0 = (prev ? prev->final_depth : 0) + super_start[blockIdx.x / kSuper] + block_start[blockIdx.x];  // uniform
     int32_t *m8 = min8 ? min8 + (b0 >> 3) : nullptr, *m64 = min8 ? min64 + (b0 >> 6) : nullptr, *m512 = min8 ? min512 + (b0 >> 9) : nullptr;
-    __shared__ DepthShared<kMatch> sh;
+    __shared__ DepthShared<kMode> sh;
     if (nrem == kBlock)
-        apply_depth_block<kMatch, true>(sh, type + b0, nrem, block_depth0, depth + b0, m8, m64, m512, opens, doc_agg, block_mm,
-                                        kMatch ? match + b0 : nullptr, survivors, match_bias, want_closers);
+        apply_depth_block<kMode, true>(sh, type + b0, nrem, block_depth0, depth + b0, m8, m64, m512, opens, doc_agg, block_mm,
+                                       kMode == 1 ? match + b0 : nullptr, survivors, match_bias, want_closers,
+                                       kMode == 2 ? pairs + open_base : nullptr, open_base);
     else
-        apply_depth_block<kMatch, false>(sh, type + b0, nrem, block_depth0, depth + b0, m8, m64, m512, opens, doc_agg, block_mm,
-                                         kMatch ? match + b0 : nullptr, survivors, match_bias, want_closers);
+        apply_depth_block<kMode, false>(sh, type + b0, nrem, block_depth0, depth + b0, m8, m64, m512, opens, doc_agg, block_mm,
+                                        kMode == 1 ? match + b0 : nullptr, survivors, match_bias, want_closers,
+                                        kMode == 2 ? pairs + open_base : nullptr, open_base);
+    (void)kMatch;
 }
 
 // (4) minimum / maximum of the running depth over the stream, from the per-block values apply_depth left in the block
@@ -763,17 +804,19 @@ constexpr uint32_t kLinear = MSJ_MATCH_LINEAR, kGroup = 8, kSteps = 8;  // 64 to
 __global__ __launch_bounds__(256) void match_brackets(const uint8_t *__restrict__ type, const uint32_t *__restrict__ opens,
                                                       const uint32_t *__restrict__ n_opens, const MinTree t,
                                                       uint32_t *__restrict__ match, uint64_t list_capacity, uint32_t match_bias,
-                                                      const msj_tokens_result *__restrict__ result, uint32_t *__restrict__ resid) {
+                                                      const msj_tokens_result *__restrict__ result, uint32_t *__restrict__ resid,
+                                                      uint2 *__restrict__ pairs) {
     // one list per blockIdx.y (kSurvivorShards of them), the lane groups of its workgroups stride over it
     const uint32_t total = n_opens[blockIdx.y * kSurvivorStride];
-    opens += (uint64_t)blockIdx.y * list_capacity;
+    opens += (uint64_t)blockIdx.y * list_capacity * (pairs ? 2u : 1u);
     const uint32_t lane = threadIdx.x & 63u, sub = lane & (kGroup - 1u), grp = lane / kGroup;
     const uint32_t n = t.cnt[0];
     constexpr uint32_t per_wave = 64u / kGroup;
     const uint64_t wave0 = ((uint64_t)blockIdx.x * 4u + (threadIdx.x >> 6)) * per_wave, stride = (uint64_t)gridDim.x * 4u * per_wave;
     for (uint64_t w0 = wave0; w0 < total; w0 += stride) {  // uniform per wave
         const uint64_t w = w0 + grp;
-        const uint32_t entry = w < total ? opens[w] : 0x80000000u;
+        const uint32_t entry = w < total ? opens[pairs ? 2u * w : w] : 0x80000000u;  // (pairs: two words per entry, the lists twice as long)
+        const uint32_t rank = (pairs && w < total) ? opens[2u * w + 1u] : 0u;
         const bool have = (entry >> 31) == 0u;  // (bit 31: a closing bracket listed for collect_closers)
         const uint32_t i = have ? entry : 0u;
         const int target = have ? t.lv[0][i] : kNone;
@@ -848,10 +891,14 @@ __global__ __launch_bounds__(256) void match_brackets(const uint8_t *__restrict_
         }
         if (have && found && sub == 0u) {
             const uint32_t cj = type[pos];
-            if (cj == '}' || cj == ']') {
+            if (pairs) {
+                pairs[rank] = make_uint2(i, (cj == '}' || cj == ']') ? pos : 0xFFFFFFFFu);
+            } else if (cj == '}' || cj == ']') {
                 match[i] = pos + match_bias;
                 match[pos] = i + match_bias;
             }
+        } else if (have && sub == 0u && pairs) {
+            pairs[rank] = make_uint2(i, 0xFFFFFFFFu);  // never closed inside this call
         } else if (have && sub == 0u && resid) {
             // never closed inside this call: the unclosed opening brackets nest, so the one at depth `target` is entry
             // final_depth - 1 - target of the call's residual list (msj_stage2_prep_segments stitches the segments)
@@ -955,7 +1002,8 @@ extern "C" uint64_t msj_tokens_workspace_bytes(uint64_t n, int with_match) {
     // (matching: the min tree, 64 scratch words, the list of opening brackets left to the tree -- one uint32 per token
     // at most -- and its counter)
     const uint64_t nb = (n + msj_tokens::kBlock - 1) / msj_tokens::kBlock;
-    return (head_words(n) + (with_match ? tree_words(n) + 64 + msj_tokens::kSurvivorShards * msj_tokens::survivor_capacity(nb) +
+    // (the lists twice: the pairs form keeps two words per entry)
+    return (head_words(n) + (with_match ? tree_words(n) + 64 + 2 * msj_tokens::kSurvivorShards * msj_tokens::survivor_capacity(nb) +
                                               (uint64_t)msj_tokens::kSurvivorShards * msj_tokens::kSurvivorStride
                                         : 0)) * sizeof(int32_t);
 }
@@ -971,15 +1019,16 @@ static int launch_depth_passes(const uint32_t *d_idx, uint64_t n, uint8_t *d_typ
     uint32_t *open_start = reinterpret_cast<uint32_t *>(d_ws + 9 * nbs);
     uint4 *doc_agg = reinterpret_cast<uint4 *>(d_ws + 4 * nbs);
     int32_t *tree = d_ws + head_words(n);  // 32-byte aligned inside the workspace
-    const bool want_match = d_match != nullptr && n > 0;
+    uint2 *d_pairs = reinterpret_cast<uint2 *>(o.d_pairs);
+    const bool want_match = (d_match != nullptr || d_pairs != nullptr) && n > 0;
     uint32_t *opens = want_match ? reinterpret_cast<uint32_t *>(tree + tree_words(n) + 64) : nullptr;
-    // ... kSurvivorShards lists, then their counters (zeroed by scan_blocks)
-    uint32_t *survivors = want_match ? opens + kSurvivorShards * survivor_capacity(nb) : nullptr;
+    // ... kSurvivorShards lists (room for two words per entry: the pairs form), then their counters (zeroed by scan_blocks)
+    uint32_t *survivors = want_match ? opens + 2 * kSurvivorShards * survivor_capacity(nb) : nullptr;
     const uint32_t nsuper = (uint32_t)super_count(n);
     int32_t *super_agg = d_ws + block_words(n), *super_start = super_agg + 4 * (uint64_t)nsuper;
     uint32_t *super_open = reinterpret_cast<uint32_t *>(super_start + nsuper);
     if (nb) hipLaunchKernelGGL(scan_super, dim3(nsuper), dim3(256), 0, s, agg, nb, start, open_start, super_agg);
-    uint32_t *resid = want_match ? o.d_resid : nullptr;
+    uint32_t *resid = (want_match && !d_pairs) ? o.d_resid : nullptr;
     hipLaunchKernelGGL(scan_blocks, dim3(1), dim3(1024), 0, s, super_agg, nb ? nsuper : 0u, super_start, super_open, d_result, n, o.d_prev,
                        survivors, resid);
     // levels of the min tree: 1..3 come out of apply_depth, the rest from build_level
@@ -1003,12 +1052,15 @@ static int launch_depth_passes(const uint32_t *d_idx, uint64_t n, uint8_t *d_typ
     int32_t *l1 = want_match ? (t.nlev > 1 ? lvl[1] : tree) : nullptr;
     int32_t *l2 = want_match ? (t.nlev > 2 ? lvl[2] : tree + tree_words(n) + 8) : nullptr;
     int32_t *l3 = want_match ? (t.nlev > 3 ? lvl[3] : tree + tree_words(n) + 40) : nullptr;
-    if (nb && want_match)
-        hipLaunchKernelGGL(apply_depth<true>, dim3(nb), dim3(kThreads), 0, s, d_type, n, start, super_start, super_open, d_depth, l1, l2, l3,
-                           open_start, opens, doc_agg, agg, o.d_prev, d_match, survivors, o.match_bias, resid ? 1u : 0u);
+    if (nb && want_match && d_pairs)
+        hipLaunchKernelGGL(apply_depth<2>, dim3(nb), dim3(kThreads), 0, s, d_type, n, start, super_start, super_open, d_depth, l1, l2, l3,
+                           open_start, opens, doc_agg, agg, o.d_prev, d_match, survivors, 0u, 0u, d_pairs);
+    else if (nb && want_match)
+        hipLaunchKernelGGL(apply_depth<1>, dim3(nb), dim3(kThreads), 0, s, d_type, n, start, super_start, super_open, d_depth, l1, l2, l3,
+                           open_start, opens, doc_agg, agg, o.d_prev, d_match, survivors, o.match_bias, resid ? 1u : 0u, static_cast<uint2 *>(nullptr));
     else if (nb)
-        hipLaunchKernelGGL(apply_depth<false>, dim3(nb), dim3(kThreads), 0, s, d_type, n, start, super_start, super_open, d_depth, l1, l2, l3,
-                           open_start, opens, doc_agg, agg, o.d_prev, d_match, survivors, 0u, 0u);
+        hipLaunchKernelGGL(apply_depth<0>, dim3(nb), dim3(kThreads), 0, s, d_type, n, start, super_start, super_open, d_depth, l1, l2, l3,
+                           open_start, opens, doc_agg, agg, o.d_prev, d_match, survivors, 0u, 0u, static_cast<uint2 *>(nullptr));
     if (nb) hipLaunchKernelGGL(min_max_depth, dim3(nb < kMinMaxGroups * 256u ? (nb + 255u) / 256u : kMinMaxGroups), dim3(256), 0, s, agg, nb, d_result);
     if (want_match) {
         for (int k = 4; k < t.nlev && k < 6; k++)
@@ -1031,7 +1083,7 @@ static int launch_depth_passes(const uint32_t *d_idx, uint64_t n, uint8_t *d_typ
         const uint32_t lists = nb < kSurvivorShards ? nb : kSurvivorShards;
         const uint32_t per_list = nb / kSurvivorShards / 8u + 1u;  // ~2 survivors per block, 16 brackets per workgroup and round
         hipLaunchKernelGGL(match_brackets, dim3(per_list < MSJ_MATCH_GRID ? per_list : MSJ_MATCH_GRID, lists), dim3(256), 0, s, d_type, opens,
-                           survivors, t, d_match, survivor_capacity(nb), o.match_bias, d_result, resid);
+                           survivors, t, d_match, survivor_capacity(nb), o.match_bias, d_result, resid, d_pairs);
         if (resid)  // the closing brackets whose partner lies in front of this call (behind match_brackets: it writes both ends)
             hipLaunchKernelGGL(collect_closers, dim3(per_list < 8u ? per_list : 8u, lists), dim3(256), 0, s, opens, survivors, survivor_capacity(nb),
                                d_depth, d_match, o.d_prev, resid);
@@ -2373,7 +2425,7 @@ int msj_launch_stage2_prep(const uint8_t *d_buf, uint64_t len, const uint32_t *d
     if (nb64 > 0x7FFFFFFFull) return (int)hipErrorInvalidValue;
     const uint32_t nb = (uint32_t)nb64;
     // the fused kernel's aggregates live behind the token pre-pass's own workspace (16-byte aligned)
-    const int wm = d_match != nullptr;
+    const int wm = d_match != nullptr || o.d_pairs != nullptr;
     int4 *sub = sub_of(d_ws, n, wm);
     if (n && by_tiles(o, n, len)) {
         launch_token_tiles<true, true>(d_buf, len, d_idx, n, d_end, d_flags, d_type, sub, table_of(d_ws, n, wm), d_fix, s, o);
@@ -2449,7 +2501,7 @@ int msj_launch_tokens(const uint8_t *d_buf, uint64_t len, const uint32_t *d_idx,
     const uint64_t nb64 = (n + kBlock - 1) / kBlock;
     if (nb64 > 0x7FFFFFFFull) return (int)hipErrorInvalidValue;
     const uint32_t nb = (uint32_t)nb64;
-    const int wm = d_match != nullptr;
+    const int wm = d_match != nullptr || o.d_pairs != nullptr;
     int4 *sub = sub_of(d_ws, n, wm);
     if (n && by_tiles(o, n, len)) {
         launch_token_tiles<true, false>(d_buf, len, d_idx, n, nullptr, nullptr, d_type, sub, table_of(d_ws, n, wm), nullptr, s, o);

@@ -20,6 +20,9 @@ struct msj_token_opts {
     // by the call's border) are left in d_resid for the stitch behind the last segment (tokens_kernel.hip, "residuals")
     uint32_t match_bias = 0;
     uint32_t *d_resid = nullptr;
+    // msj_*_pairs_device: the containers as {open, close} records in the order of their opening brackets (msj_bracket_pair),
+    // instead of a partner index per token
+    msj_bracket_pair *d_pairs = nullptr;
 };
 
 // residual brackets of one call (device, uint32 words): [0] unclosed opening brackets, [1] closing brackets without a

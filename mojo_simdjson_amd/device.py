@@ -80,6 +80,31 @@ class Stage1Device:
             raise RuntimeError(f"msj_stage1_types_device failed: {rc}")
         return rc
 
+    def stage2_prep_pairs(self, d_buf, length, d_idx, n, spans=True, d_prev=None, d_result=None):
+        """``msj_stage2_prep_pairs_device`` (spans=True) / ``msj_tokens_pairs_device``: bracket partners as a compact list --
+        d_pairs[k] = (token of the k-th opening bracket, token that closes it or 0xFFFFFFFF) -- instead of an index per
+        token.  Returns (d_type, d_depth, d_pairs int32[n_cap, 2], d_end or None, d_flags or None, d_result); asynchronous:
+        the number of records is msj_tokens_result.reserved."""
+        n = int(n)
+        dv = self.device
+        d_type = torch.empty(max(n, 8), dtype=torch.uint8, device=dv)
+        d_depth = torch.empty(max(n, 4), dtype=torch.int32, device=dv)
+        d_pairs = torch.empty((max(n, 1), 2), dtype=torch.int32, device=dv)
+        d_res = d_result if d_result is not None else torch.zeros(24, dtype=torch.uint8, device=dv)
+        prev = _ptr(d_prev) if d_prev is not None else None
+        if spans:
+            d_end = torch.empty(max(n, 2), dtype=torch.int32, device=dv)
+            d_flags = torch.empty(max(n, 2), dtype=torch.uint8, device=dv)
+            rc = self.lib.msj_stage2_prep_pairs_device(self.ctx, _ptr(d_buf), int(length), _ptr(d_idx), n, _ptr(d_type), _ptr(d_depth),
+                                                       _ptr(d_pairs), _ptr(d_end), _ptr(d_flags), _ptr(d_res), prev, self._stream())
+        else:
+            d_end = d_flags = None
+            rc = self.lib.msj_tokens_pairs_device(self.ctx, _ptr(d_buf), int(length), _ptr(d_idx), n, _ptr(d_type), _ptr(d_depth),
+                                                  _ptr(d_pairs), _ptr(d_res), prev, self._stream())
+        if rc != 0:
+            raise RuntimeError(f"msj_*_pairs_device failed: {rc}")
+        return d_type[:n], d_depth[:n], d_pairs, d_end, d_flags, d_res
+
     def depth_from_types(self, d_type, n, d_depth=None, d_match=None, match=False, d_result=None, d_prev=None):
         """PROTOTYPE (``msj_depth_from_types_device``): depth (and partners) of every token from type bytes stage 1 wrote.
         Asynchronous; returns (d_depth, d_match or None, d_result)."""

@@ -16,6 +16,7 @@ from mojo_simdjson_amd.device import Stage1Device, _ptr  # noqa: E402
 ap = argparse.ArgumentParser()
 ap.add_argument("workload", nargs="?", default="minified")
 ap.add_argument("--match", action="store_true")
+ap.add_argument("--pairs", action="store_true", help="the partners as a compact list (msj_stage2_prep_pairs_device)")
 ap.add_argument("--iters", type=int, default=200)
 ap.add_argument("--warm", type=int, default=200)
 ap.add_argument("--mib", type=int, default=1024)
@@ -41,12 +42,18 @@ dv = dev.device
 d_type = torch.empty(n, dtype=torch.uint8, device=dv)
 d_depth = torch.empty(n, dtype=torch.int32, device=dv)
 d_match = torch.empty(n, dtype=torch.int32, device=dv) if a.match else None
+d_pairs = torch.empty((n, 2), dtype=torch.int32, device=dv) if a.pairs else None
 d_end = torch.empty(n, dtype=torch.int32, device=dv)
 d_flags = torch.empty(n, dtype=torch.uint8, device=dv)
 d_res = torch.zeros(24, dtype=torch.uint8, device=dv)
 
 
 def call():
+    if a.pairs:
+        rc = dev.lib.msj_stage2_prep_pairs_device(dev.ctx, _ptr(d_buf), nbytes, _ptr(d_idx), n, _ptr(d_type), _ptr(d_depth), _ptr(d_pairs),
+                                                  _ptr(d_end), _ptr(d_flags), _ptr(d_res), None, dev._stream())
+        assert rc == 0, rc
+        return
     rc = dev.lib.msj_stage2_prep_device(dev.ctx, _ptr(d_buf), nbytes, _ptr(d_idx), n, _ptr(d_type), _ptr(d_depth),
                                         _ptr(d_match) if a.match else None, _ptr(d_end), _ptr(d_flags), _ptr(d_res), dev._stream())
     assert rc == 0, rc
@@ -62,6 +69,6 @@ for _ in range(a.iters):
 e1.record()
 torch.cuda.synchronize()
 ms = e0.elapsed_time(e1) / a.iters
-print(f"{a.workload}{' +match' if a.match else ''} mode {a.mode}: {n} structurals, {nbytes} bytes: {ms:.4f} ms per call "
+print(f"{a.workload}{' +match' if a.match else ''}{' +pairs' if a.pairs else ''} mode {a.mode}: {n} structurals, {nbytes} bytes: {ms:.4f} ms per call "
       f"({ms * (1 << 30) / nbytes:.4f} ms per GiB, {n / ms / 1e6:.1f} G structurals/s), {a.iters} calls after {a.warm} warm-up")
 dev.close()

@@ -814,3 +814,77 @@ def test_types_from_stage1_prototype(dev):
     assert torch.equal(d_types[:nu * reps].view(reps, -1), torch.from_numpy(wt).to(dev.device).expand(reps, -1))
     d_depth, _, _ = dev.depth_from_types(d_types, nu * reps)
     assert torch.equal(d_depth[:nu * reps].view(reps, -1), torch.from_numpy(wd).to(dev.device).expand(reps, -1))
+
+
+def _check_pairs(dev, data, where, spans):
+    import torch
+    from mojo_simdjson_amd import _lib
+
+    d_buf = torch.from_numpy(np.frombuffer(data, dtype=np.uint8).copy()).to(dev.device)
+    d_idx = torch.empty(len(data) + 3 + 4, dtype=torch.int32, device=dev.device)
+    d_res = dev.new_carry()
+    dev.index(d_buf, d_idx, d_res)
+    n = int(dev.fetch(d_res).count)
+    t, d, pairs, e, f, d_tr = dev.stage2_prep_pairs(d_buf, len(data), d_idx, n, spans=spans)
+    r = _lib.MsjTokensResult.from_buffer_copy(d_tr.cpu().numpy().tobytes())
+    idx = d_idx[:n].cpu().numpy().view(np.uint32)
+    wt, wd, (final, mn, mx) = helpers.oracle_tokens(data, idx)
+    wm = helpers.oracle_match(wt)
+    opens = np.nonzero((wt == ord("{")) | (wt == ord("[")))[0]
+    want = np.stack([opens.astype(np.uint32), wm[opens]], axis=1) if len(opens) else np.zeros((0, 2), dtype=np.uint32)
+    assert r.reserved == len(opens), (where, r.reserved, len(opens))
+    got = pairs[:len(opens)].cpu().numpy().view(np.uint32)
+    if not np.array_equal(got, want):
+        bad = int(np.argmax((got != want).any(axis=1)))
+        raise AssertionError(f"{where}: pair {bad} = {got[bad].tolist()} != {want[bad].tolist()}")
+    assert np.array_equal(t.cpu().numpy(), wt) and np.array_equal(d.cpu().numpy(), wd), where
+    assert (r.n, r.final_depth, r.min_depth, r.max_depth) == (n, final, mn, mx) if n else True, where
+    if spans and n:
+        we, wf = helpers.oracle_token_spans(data, idx)
+        assert np.array_equal(f[:n].cpu().numpy(), wf) and np.array_equal(e[:n].cpu().numpy().view(np.uint32), we), where
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("spans", [True, False], ids=["prep", "tokens"])
+def test_bracket_pairs_compact_list(dev, span_mode, spans):
+    """Round 5: the partners as one {open, close} record per container, in the order of the opening brackets
+    (msj_stage2_prep_pairs_device / msj_tokens_pairs_device) = the definition's match[] read at the opening brackets:
+    fixtures, workloads, soups (stray and unclosed brackets), deep nests, containers across block borders and outside
+    the sixteen levels a block keeps, a 1 GiB stream."""
+    import torch
+    from mojo_simdjson_amd import synth
+
+    for f in helpers.golden_valid_files():
+        js, _ = helpers.read_fixture(f)
+        _check_pairs(dev, js.encode() if isinstance(js, str) else js, f, spans)
+    for name in ("minified", "utf8", "pretty4"):
+        _check_pairs(dev, synth.workload(name, 8 << 20).tobytes(), name, spans)
+    rng = np.random.default_rng(23)
+    alphabet = np.frombuffer(b'{}[]{}[],: "a1', dtype=np.uint8)
+    for n in (1, 2, 7, 8, 9, 2047, 2048, 2049, 4096 * 3 + 5, 100000, 1 << 20):
+        soup = alphabet[rng.integers(0, len(alphabet), n)].tobytes().replace(b'"', b"x")
+        _check_pairs(dev, soup, f"bracket soup {n}", spans)
+    _check_pairs(dev, b"[" * 300000 + b"]" * 299999, "deep", spans)
+    _check_pairs(dev, b"]" * 5000 + b"[" * 7, "underflow", spans)
+    _check_pairs(dev, b"[" + b"[1]," * 3000 + b"[" * 20 + b"1" + b"]" * 20 + b",[[2]]" * 3000 + b"]", "mixed nests over many blocks", spans)
+    _check_pairs(dev, b" ", "no structurals", spans)
+    # full size
+    u = synth.workload("minified", 64 << 20)
+    oracle = helpers.load_oracle()
+    b = u.tobytes()
+    idx_u = _stage1(oracle, b)
+    wt, wd, _ = helpers.oracle_tokens(b, idx_u)
+    wm = helpers.oracle_match(wt).astype(np.int64)
+    opens = np.nonzero((wt == ord("{")) | (wt == ord("[")))[0]
+    reps, nu, no = 16, len(idx_u), len(opens)
+    d_buf = torch.from_numpy(u).to(dev.device).repeat(reps)
+    d_idx = torch.empty(nu * reps + 16, dtype=torch.int32, device=dev.device)
+    d_res = dev.new_carry()
+    dev.index(d_buf, d_idx, d_res)
+    assert int(dev.fetch(d_res).count) == nu * reps
+    t, d, pairs, e, f, d_tr = dev.stage2_prep_pairs(d_buf, d_buf.numel(), d_idx, nu * reps, spans=spans)
+    got = pairs[:no * reps].to(torch.int64) & 0xFFFFFFFF
+    want = torch.from_numpy(np.stack([opens.astype(np.int64), wm[opens]], axis=1)).to(dev.device)
+    k = (torch.arange(reps, device=dev.device, dtype=torch.int64) * nu)[:, None, None]
+    assert torch.equal(got.view(reps, no, 2), want[None, :, :] + k)
+    assert torch.equal(d.view(reps, -1), torch.from_numpy(wd).to(dev.device).expand(reps, -1))
