@@ -3,7 +3,7 @@
 # workloads with the traffic entries for the new source hash, the ceilings table, density / size sweeps with same-box
 # ceilings, the default and the 8 GiB bench lines, the stitch overlap on one GPU.   scripts/campaign.sh <tag> [part]
 cd "$(dirname "$0")/.."
-T=${1:-r04}; PART=${2:-all}; O=gpurun_out/$T; mkdir -p $O
+T=${1:-r05}; PART=${2:-all}; O=gpurun_out/$T; mkdir -p $O
 if [ $PART = all ] || [ $PART = 1 ]; then
 timeout -k 10 800 python -m pytest tests -x -q -m gpu > $O/gpu_tests.txt 2>&1; tail -2 $O/gpu_tests.txt | cut -c1-200
 timeout -k 10 150 python tests/stress.py 60 201 > $O/stress_201.txt 2>&1; tail -1 $O/stress_201.txt
@@ -19,7 +19,7 @@ for w in minified utf8 pretty4; do
   cp gpurun_out/prof/${T}_$w/summary.txt $O/summary_${T}_${w}_1gib.txt 2>/dev/null
   cp gpurun_out/prof/${T}_$w/bench_line.json $O/bench_${T}_${w}_1gib.json 2>/dev/null
   cp gpurun_out/prof/${T}_$w/kernel_stats.csv $O/kernel_stats_${T}_${w}_1gib.csv 2>/dev/null
-  python3 scripts/traffic_update.py /tmp/prof/${T}_$w $w profiles/r04/summary_${T}_${w}_1gib.txt > $O/traffic_$w.txt 2>&1; cut -c1-200 $O/traffic_$w.txt
+  python3 scripts/traffic_update.py /tmp/prof/${T}_$w $w profiles/${T}/summary_${T}_${w}_1gib.txt > $O/traffic_$w.txt 2>&1; cut -c1-200 $O/traffic_$w.txt
 done
 rm -rf gpurun_out/prof
 timeout -k 10 120 scripts/bin/hbm_ceilings 1 > $O/hbm_ceilings_1gib.txt 2>&1; python3 scripts/ceilings_update.py $O/hbm_ceilings_1gib.txt > $O/ceilings_update.txt 2>&1; tail -3 $O/ceilings_update.txt

@@ -1,4 +1,4 @@
-out=gpurun_out/r04n; mkdir -p $out
+out=gpurun_out/${1:-r05n}; mkdir -p $out
 timeout -k 10 600 python -m pytest tests/test_tokens.py tests/test_documents.py -x -q -m gpu > $out/gpu_tests_tokens.txt 2>&1 || { tail -40 $out/gpu_tests_tokens.txt; exit 1; }
 tail -2 $out/gpu_tests_tokens.txt
 timeout -k 10 150 python tests/stress_tokens.py 60 304 > $out/stress_tokens_304.txt 2>&1; tail -1 $out/stress_tokens_304.txt
@@ -7,5 +7,5 @@ for w in minified utf8 pretty4; do
   python scripts/prep_prof.py $w 2>&1 | grep -v amdgpu | tail -1 | tee -a $out/rates.txt
   python scripts/prep_prof.py $w --match 2>&1 | grep -v amdgpu | tail -1 | tee -a $out/rates.txt
 done
-MATCH=1 bash scripts/prep_ab.sh libs minified variants/cur.so 2>&1 | grep -v amdgpu | tee $out/ab_match.txt
+MATCH=1 bash scripts/prep_ab.sh libs minified ${2:-scripts/ab/r5_tokens_before.so} 2>&1 | grep -v amdgpu | tee $out/ab_match.txt
 bash scripts/prep_split.sh minified "" 2>&1 | grep -E "^==|msj_tokens" | tee $out/split.txt
