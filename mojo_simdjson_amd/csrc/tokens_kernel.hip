@@ -423,6 +423,90 @@ __device__ __forceinline__ void apply_depth_block(DepthShared<kMode> &sh, const 
             sh.s_pre[threadIdx.x] = (uint16_t)excl_no;
             sh.s_om[threadIdx.x] = (uint8_t)om;  // (visible behind the barrier between (a) and (c))
         }
+#ifndef MSJ_MATCH_PER_THREAD
+        // Round 5: the wave's brackets are COMPACTED first.  A thread holds 0 .. 8 of them (4 % of the minified workload's
+        // tokens open a container, 4 % close one: ~40 per wave of 512 tokens), and a loop in which every thread walks its
+        // own runs max-over-lanes rounds of the whole body -- 2 to 3 of the 22-instruction insertion and of the
+        // 45-instruction look-up -- with a third of the lanes busy.  So a thread only works out WHERE its brackets are and at
+        // which level (one short round per bracket), writes a 16-bit entry per bracket -- token inside the wave | level + 1
+        // << 9, 0 = below the block's levels, 17 = above -- into the wave's list of opening or of closing brackets (the
+        // depths' staging slice, free until the depths leave), and lane j then handles the wave's j-th bracket: one round of
+        // each body for up to 64 brackets.  profiles/r05/apply_depth_*.txt.
+        uint16_t *const olist = reinterpret_cast<uint16_t *>(&s_out[wave][0]);  // up to 512 entries each
+        uint16_t *const clist = olist + 512;
+        const uint32_t ncl = (uint32_t)__builtin_popcount(cm);
+        const uint32_t incl_nc = wave_incl_sum(ncl);
+        uint32_t oslot = (uint32_t)(incl_no - no), cslot = incl_nc - ncl;
+        const uint32_t n_open_w = (uint32_t)__builtin_amdgcn_readlane(incl_no, 63), n_close_w = (uint32_t)__builtin_amdgcn_readlane((int)incl_nc, 63);
+        for (uint32_t rem = om | cm; __ballot(rem != 0u) != 0ull;) {  // uniform
+            if (rem != 0u) {
+                const uint32_t k = (uint32_t)__builtin_ctz(rem), below = (1u << k) - 1u;
+                rem &= rem - 1u;
+                const uint32_t closes = (cm >> k) & 1u;
+                // an opening bracket sits at the running depth in front of it, a closing one at the depth of its container
+                const int lv = before0 + (int)__builtin_popcount(om & below) - (int)__builtin_popcount(cm & below) - (int)closes - level0;
+                // a closing bracket BELOW the depth at the block's start: if nothing in the block pairs with it, its partner
+                // is in an earlier block -- or in front of this CALL (the residuals of msj_stage2_prep_segments)
+                if (closes && lv < kMatchBelow) cand_mask |= 1u << k;
+                const uint32_t enc = (uint32_t)min(max(lv + 1, 0), kMatchLevels + 1);
+                const uint16_t entry = (uint16_t)((8u * (uint32_t)lane + k) | (enc << 9));
+                if (closes)
+                    clist[cslot++] = entry;
+                else
+                    olist[oslot++] = entry;
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        // (a) the opening brackets' bits, (b) the level's words that hold one
+        for (uint32_t j0 = 0; j0 < n_open_w; j0 += 64u) {  // uniform: one round unless the wave holds more than 64
+            const uint32_t j = j0 + (uint32_t)lane;
+            if (j < n_open_w) {
+                const uint32_t e = olist[j], lv = (e >> 9) - 1u, t = (uint32_t)wave * 512u + (e & 511u);
+                if (lv < (uint32_t)kMatchLevels) {
+                    atomicOr(&bm[lv][t >> 5], 1u << (t & 31u));
+                    atomicOr(&bm_words[lv], 1ull << (t >> 5));
+                }
+            }
+        }
+        __syncthreads();
+        // (c) every closing bracket looks for the most recent opening one of its level
+        for (uint32_t j0 = 0; j0 < n_close_w; j0 += 64u) {  // uniform
+            const uint32_t j = j0 + (uint32_t)lane;
+            if (j < n_close_w) {
+                const uint32_t e = clist[j], lv = (e >> 9) - 1u;
+                if (lv < (uint32_t)kMatchLevels) {
+                    const uint32_t t = (uint32_t)wave * 512u + (e & 511u), w = t >> 5;
+                    uint32_t m = bm[lv][w] & ((1u << (t & 31u)) - 1u);
+                    uint32_t wi = w;
+                    if (m == 0u) {
+                        const uint64_t nz = bm_words[lv] & ((1ull << w) - 1ull);
+                        if (nz != 0ull) {
+                            wi = 63u - (uint32_t)__clzll((long long)nz);
+                            m = bm[lv][wi];
+                        }
+                    }
+                    if (m != 0u) {
+                        const uint32_t i = 32u * wi + 31u - (uint32_t)__clz((int)m);
+                        if (kMode == 1) {
+                            const uint32_t b0 = blk0 + match_bias;  // + the call's place in the shard (msj_stage2_prep_segments)
+                            s_match[t] = b0 + i;
+                            s_match[i] = b0 + t;
+                        } else {
+                            // the container's record: at the opening bracket's rank among the call's opening brackets
+                            const uint32_t ti = i >> 3;
+                            const uint32_t r = (uint32_t)sh.s_pre[ti] + (uint32_t)__builtin_popcount((uint32_t)sh.s_om[ti] & ((1u << (i & 7u)) - 1u));
+                            pairs_blk[r] = make_uint2(blk0 + i, blk0 + t);
+                        }
+                        atomicOr(&s_paired[w], 1u << (t & 31u));
+                        atomicOr(&s_paired[wi], 1u << (i & 31u));
+                    }
+                }
+            }
+        }
+        __syncthreads();
+#else   // the form of round 4 (kept for the A/B): every thread walks the set bits of its own bracket masks
         for (uint32_t rem = om; __ballot(rem != 0u) != 0ull;) {  // uniform
             if (rem != 0u) {
                 const uint32_t k = (uint32_t)__builtin_ctz(rem), below = (1u << k) - 1u;
@@ -475,6 +559,7 @@ __device__ __forceinline__ void apply_depth_block(DepthShared<kMode> &sh, const 
             }
         }
         __syncthreads();
+#endif
         // (d) the opening brackets nobody claimed: to the list match_brackets works through (any order)
         // (the thread's eight tokens are one byte of a word of s_paired)
         const uint32_t paired8 = s_paired[t0 >> 5] >> (t0 & 31u);

@@ -12,7 +12,7 @@ REPO="$(cd "$(dirname "$0")/.." && pwd)"
 cd /tmp && export TMPDIR=/tmp && cd "$REPO"
 OUT=/tmp/prof/$TAG   # the raw CSVs stay on the box (gpurun_out/ is limited to 64 MiB); the summaries are copied at the end
 rm -rf "$OUT"; mkdir -p "$OUT"
-ARGS="--steps 20 --warmup 5 --no-cpu-baseline $*"   # the driver's command (bench.py settles the clocks for 400 ms before the timed steps)
+ARGS="--steps 20 --warmup 5 --no-cpu-baseline --no-other-configs $*"   # the driver's command (bench.py settles the clocks for 400 ms before the timed steps)
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/kt" -- python3 bench.py $ARGS > "$OUT/kt.log" 2>&1 || { echo "kernel-trace pass failed"; tail -5 "$OUT/kt.log"; exit 1; }
 grep "\"metric\"" "$OUT/kt.log" | tail -1 > "$OUT/bench_line.json"
 ARGS="$ARGS --settle-ms 0 --no-ceilings"               # counters do not depend on the clocks: short runs for the PMC passes
