@@ -861,6 +861,62 @@ __device__ __forceinline__ void st_index_quad(uint8_t *p, const uint4 v) {
 #endif
 }
 
+__device__ __forceinline__ void copy_out(const KernelArgs &a, const EmitU &e, const uint32_t *stage,
+                                         const uint32_t lane, const uint32_t lane_p) {
+    // uniform 64-bit base + 32-bit lane offsets; full 16-byte quads in the body, the (at
+    // most two) partial quads at the ends element by element
+    uint8_t *out = reinterpret_cast<uint8_t *>(a.idx + (e.base - e.shift));  // out[4v] <-> stage[v]; 16-byte aligned
+    const uint8_t *src = reinterpret_cast<const uint8_t *>(stage);
+    const uint32_t q_lo0 = (e.shift + 3u) >> 2;       // first quad with all four elements valid
+    const uint32_t q_hi0 = e.vend >> 2;               // one past the last full quad
+    // The streaming stores cover whole 128-byte lines only: the quads of the (at most two) lines this tile shares with
+    // its neighbours leave as plain stores, which L2 merges with the neighbour's part -- a partially written line that
+    // leaves as a non-temporal store reaches memory on its own (WRITE_SIZE 0.883 GB for 0.831 GB of indices on the 1 GiB
+    // minified input).  Same box, alternating, 1 500 launches each (profiles/r03/ab_edge_plain.txt): minified 0.3289 ->
+    // 0.3183 ms, 0.3261 -> 0.3199 (+2 .. +3.4 %); pretty-printed +-0.5 %; UTF-8-heavy -0.7 .. -1.1 % -- where the
+    // instruction stream and not the traffic binds, the few extra instructions cost more than the lines save, so the
+    // edges are only taken apart for tiles with many indices (MSJ_EDGE_PLAIN_MIN; 0 = always, ~0 = never).
+#ifndef MSJ_EDGE_PLAIN_MIN
+#define MSJ_EDGE_PLAIN_MIN 512u
+#endif
+    uint32_t q_lo = q_lo0, q_hi = q_hi0;
+    if (e.vend - e.shift >= MSJ_EDGE_PLAIN_MIN) {  // uniform
+        const uint32_t a16 = (uint32_t)(reinterpret_cast<uintptr_t>(out) >> 4);  // the output's address in quads (uniform)
+        const uint32_t over = (a16 + q_hi0) & 7u;
+        q_lo = q_lo0 + ((8u - ((a16 + q_lo0) & 7u)) & 7u);   // first quad that starts a line
+        q_hi = q_hi0 >= over ? q_hi0 - over : 0u;            // one past the last quad that ends one
+        if (q_lo > q_hi0) q_lo = q_hi0;
+        if (q_hi < q_lo) q_hi = q_lo;
+        if (lane_p < 16u) {  // the edges: [q_lo0, q_lo) and [q_hi, q_hi0), at most seven quads each
+            const uint32_t q = lane_p < 8u ? q_lo0 + lane : q_hi + (lane - 8u);
+            const bool ok = lane_p < 8u ? q < q_lo : q < q_hi0;
+            if (ok) *reinterpret_cast<uint4 *>(out + 16u * q) = *reinterpret_cast<const uint4 *>(src + 16u * q);
+        }
+    }
+    // at most kStageWords / 256 = 4 rounds of 64 quads: one byte offset per lane, the rounds are
+    // immediate offsets of the LDS read and of the store; only the last round is partial
+    const uint32_t off = (q_lo + lane) * 16u;
+#pragma unroll
+    for (uint32_t k = 0; k < kStageWords / 256u; k++) {
+        if (q_lo + 64u * k >= q_hi) break;  // uniform
+        if (q_lo + 64u * (k + 1u) <= q_hi) {  // uniform: a full round, every lane stores
+            st_index_quad(out + off + 1024u * k, *reinterpret_cast<const uint4 *>(src + off + 1024u * k));
+        } else {  // the last round: the first (q_hi - q_lo - 64k) lanes
+            if (lane_p < q_hi - q_lo - 64u * k)
+                st_index_quad(out + off + 1024u * k, *reinterpret_cast<const uint4 *>(src + off + 1024u * k));
+            break;
+        }
+    }
+    // head (elements shift .. 4*q_lo) and tail (4*q_hi .. vend): < 8 elements in total, one
+    // element per lane of the first eight
+    if (lane_p < 8u) {
+        const bool head = lane_p < 4u;
+        const uint32_t v = head ? lane : 4u * q_hi0 + (lane - 4u);
+        const bool ok = head ? (v >= e.shift && v < 4u * q_lo0 && v < e.vend) : (v < e.vend && v >= 4u * q_lo0);
+        if (ok) *reinterpret_cast<uint32_t *>(out + 4u * v) = *reinterpret_cast<const uint32_t *>(src + 4u * v);
+    }
+}
+
 // kTypes (prototype): the type byte of four indices -- four byte gathers from the tile's bytes (L2 / MALL: the tile was
 // read two iterations ago), packed into the dword that lies beside the quad in types[].  Measured (scripts/fused_types.py,
 // profiles/r05/fused_types_*.txt): the gathers cost stage 1 0.235 ms per GiB minified (0.314 -> 0.549) -- 16 load
@@ -871,13 +927,13 @@ __device__ __forceinline__ void st_index_quad(uint8_t *p, const uint4 v) {
 __device__ __forceinline__ uint32_t gather_types4(const uint8_t *bytes, const uint4 v) {
     return (uint32_t)bytes[v.x] | ((uint32_t)bytes[v.y] << 8) | ((uint32_t)bytes[v.z] << 16) | ((uint32_t)bytes[v.w] << 24);
 }
-template <bool kTypes>
-__device__ __forceinline__ void copy_out(const KernelArgs &a, const EmitU &e, const uint32_t *stage,
+__device__ __forceinline__ void copy_out_types(const KernelArgs &a, const EmitU &e, const uint32_t *stage,
                                          const uint32_t lane, const uint32_t lane_p) {
     // types[] runs parallel to idx[]: element (e.base - e.shift) + v of either belongs to stage[v]; offsets are byte offsets
     // of the document (+ index_bias), so `bytes + offset` is the byte itself
-    uint8_t *tout = kTypes ? a.types + (e.base - e.shift) : nullptr;
-    const uint8_t *bytes = kTypes ? a.buf - a.index_bias : nullptr;
+    constexpr bool kTypes = true;
+    uint8_t *tout = a.types + (e.base - e.shift);
+    const uint8_t *bytes = a.buf - a.index_bias;
     // uniform 64-bit base + 32-bit lane offsets; full 16-byte quads in the body, the (at
     // most two) partial quads at the ends element by element
     uint8_t *out = reinterpret_cast<uint8_t *>(a.idx + (e.base - e.shift));  // out[4v] <-> stage[v]; 16-byte aligned
@@ -962,8 +1018,80 @@ __device__ __forceinline__ void lds_wave_sync() {
 // staging, no LDS.  (Plain stores: a block's store covers a part of one or two 128-byte lines and the next block's
 // store the rest; as non-temporal stores the parts reach memory one by one -- `[10,10,...`: 0.76 -> 1.09 ms per GiB.)
 __device__ __noinline__ void emit_dense(uint32_t *idx, const uint32_t tile_base, const uint64_t base, const uint32_t tlo,
+                                        const uint32_t thi, const uint32_t first_slot, const uint32_t lane) {
+    // out[k] = the tile's k-th index; wave-uniform (the arguments of a called function arrive in vector registers)
+    const uint64_t out = uniform64(reinterpret_cast<uint64_t>(idx + base));
+    const uint32_t tb = uniform32(tile_base);
+    for (uint32_t b = 0; b < 64u; b++) {  // uniform
+        const uint32_t mlo = bcast(tlo, (int)b), mhi = bcast(thi, (int)b);
+        if ((mlo | mhi) == 0u) continue;
+        const uint32_t slot0 = bcast(first_slot, (int)b);  // slot of the block's first index
+        const uint32_t rank = __builtin_amdgcn_mbcnt_hi(mhi, __builtin_amdgcn_mbcnt_lo(mlo, 0u));
+        const uint32_t off = (slot0 + rank) * 4u;
+        const uint32_t val = tb + b * 64u + lane;
+        const uint64_t m = u64(mlo, mhi);
+        uint64_t save;
+        asm volatile(
+            "s_mov_b64 %[save], exec\n"
+            "s_mov_b64 exec, %[m]\n"
+            "global_store_dword %[off], %[val], %[out]\n"
+            "s_mov_b64 exec, %[save]\n"
+            : [save] "=&s"(save)
+            : [m] "s"(m), [off] "v"(off), [val] "v"(val), [out] "s"(out)
+            : "memory");
+    }
+}
+
+// An index buffer that is too small (the launch reports CAPACITY): element-wise, clipped.
+__device__ __noinline__ void emit_general(uint32_t *idx, const uint64_t capacity, const uint32_t tile_base,
+                                          const uint64_t base, const uint32_t shift, const uint32_t vend,
+                                          uint32_t tlo, uint32_t thi, uint32_t vpos, uint32_t *stage,
+                                          const uint32_t lane) {
+    const uint32_t v0 = tile_base + lane * 64u;
+    for (uint32_t r0 = 0; r0 < vend; r0 += kStageWords) {
+        const uint32_t r1 = r0 + kStageWords;
+        while (tlo && vpos < r1) {
+            stage[vpos - r0] = v0 + (uint32_t)__builtin_ctz(tlo);
+            tlo &= tlo - 1;
+            vpos++;
+        }
+        if (!tlo) {
+            while (thi && vpos < r1) {
+                stage[vpos - r0] = v0 + 32u + (uint32_t)__builtin_ctz(thi);
+                thi &= thi - 1;
+                vpos++;
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        const uint32_t lim = vend < r1 ? vend : r1;
+        const uint64_t gbase = base - shift + r0;
+        for (uint32_t q = lane; 4u * q < lim - r0; q += 64u) {
+            const uint32_t vq = r0 + 4u * q;
+            const uint4 val = *reinterpret_cast<const uint4 *>(&stage[4u * q]);
+            const uint64_t g = gbase + 4u * q;
+            if (vq >= shift && vq + 4u <= lim && g + 4u <= capacity) {
+                *reinterpret_cast<uint4 *>(&idx[g]) = val;
+            } else {
+                const uint32_t vv[4] = {val.x, val.y, val.z, val.w};
+#pragma unroll
+                for (uint32_t j = 0; j < 4; j++) {
+                    const uint32_t v = vq + j;
+                    if (v >= shift && v < lim && g + j < capacity) idx[g + j] = vv[j];
+                }
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();  // stage is reused by the next round / next tile
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
+}
+
+// PROTOTYPE (kFlagEmitTypes): the same two with the type byte of every index written beside it
+__device__ __noinline__ void emit_dense_types(uint32_t *idx, const uint32_t tile_base, const uint64_t base, const uint32_t tlo,
                                         const uint32_t thi, const uint32_t first_slot, const uint32_t lane,
-                                        uint8_t *types = nullptr, const uint8_t *bytes = nullptr) {
+                                        uint8_t *types, const uint8_t *bytes) {
     // out[k] = the tile's k-th index; wave-uniform (the arguments of a called function arrive in vector registers)
     const uint64_t out = uniform64(reinterpret_cast<uint64_t>(idx + base));
     const uint32_t tb = uniform32(tile_base);
@@ -989,10 +1117,10 @@ __device__ __noinline__ void emit_dense(uint32_t *idx, const uint32_t tile_base,
 }
 
 // An index buffer that is too small (the launch reports CAPACITY): element-wise, clipped.
-__device__ __noinline__ void emit_general(uint32_t *idx, const uint64_t capacity, const uint32_t tile_base,
+__device__ __noinline__ void emit_general_types(uint32_t *idx, const uint64_t capacity, const uint32_t tile_base,
                                           const uint64_t base, const uint32_t shift, const uint32_t vend,
                                           uint32_t tlo, uint32_t thi, uint32_t vpos, uint32_t *stage,
-                                          const uint32_t lane, uint8_t *types = nullptr, const uint8_t *bytes = nullptr) {
+                                          const uint32_t lane, uint8_t *types, const uint8_t *bytes) {
     const uint32_t v0 = tile_base + lane * 64u;
     for (uint32_t r0 = 0; r0 < vend; r0 += kStageWords) {
         const uint32_t r1 = r0 + kStageWords;
@@ -1102,24 +1230,24 @@ template <bool kTypes = false>
 __device__ __forceinline__ void emit_store(const KernelArgs &a, const Shared &sh, const EmitU &e, const uint32_t wave,
                                            const uint32_t slot, uint32_t *stage, const uint32_t lane, const uint32_t lane_p) {
     if (e.mode == kEmitStaged) {  // uniform
-        copy_out<kTypes>(a, e, stage, lane, lane_p);
+        if (kTypes) copy_out_types(a, e, stage, lane, lane_p); else copy_out(a, e, stage, lane, lane_p);
     } else if (e.mode == kEmitStaged2) {
-        copy_out<kTypes>(a, emit_round(e, 0u), stage, lane, lane_p);
+        if (kTypes) copy_out_types(a, emit_round(e, 0u), stage, lane, lane_p); else copy_out(a, emit_round(e, 0u), stage, lane, lane_p);
         lds_wave_sync();  // the slice is reused by the second round
         const EmitV v = emit_lane(sh, wave, slot, lane, e);
         stage_indices_round(e, v, stage, lane64_of(lane), 1u);
         lds_wave_sync();
-        copy_out<kTypes>(a, emit_round(e, 1u), stage, lane, lane_p);
+        if (kTypes) copy_out_types(a, emit_round(e, 1u), stage, lane, lane_p); else copy_out(a, emit_round(e, 1u), stage, lane, lane_p);
     } else if (e.mode == kEmitDense) {
         const EmitV v = emit_lane(sh, wave, slot, lane, e);
         if (kTypes)
-            emit_dense(a.idx, e.tile_base, e.base, v.tlo, v.thi, v.vpos - e.shift, lane, a.types, a.buf - a.index_bias);
+            emit_dense_types(a.idx, e.tile_base, e.base, v.tlo, v.thi, v.vpos - e.shift, lane, a.types, a.buf - a.index_bias);
         else
             emit_dense(a.idx, e.tile_base, e.base, v.tlo, v.thi, v.vpos - e.shift, lane);
     } else if (e.mode == kEmitGeneral) {
         const EmitV v = emit_lane(sh, wave, slot, lane, e);
         if (kTypes)
-            emit_general(a.idx, a.capacity, e.tile_base, e.base, e.shift, e.vend, v.tlo, v.thi, v.vpos, stage, lane, a.types, a.buf - a.index_bias);
+            emit_general_types(a.idx, a.capacity, e.tile_base, e.base, e.shift, e.vend, v.tlo, v.thi, v.vpos, stage, lane, a.types, a.buf - a.index_bias);
         else
             emit_general(a.idx, a.capacity, e.tile_base, e.base, e.shift, e.vend, v.tlo, v.thi, v.vpos, stage, lane);
     }
