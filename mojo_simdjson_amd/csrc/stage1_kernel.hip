@@ -52,6 +52,13 @@
 // (profiles/r03/ab_wave_priority.txt; any level above the compute phase's does it, the levels differ by < 1 %);
 // the second tile of the compute phase one level above the first: another +1.5 % / +1.8 % / +3.5 %.  The ladder
 // 0, 1, 2, 3 follows a wave's progress through its iteration.
+// EXPERIMENT (round 5, off by default): request the NEXT range's first tile at the start of the present range's second
+// compute phase (its registers are free from there) and its second tile right before the barrier -- the ticket then has to
+// be known one iteration earlier (drawn two ranges ahead).  What it is for: on sparse input the range loop is a latency
+// chain (load -> compute -> barrier -> hand-over -> load), not issue-bound.
+#ifndef MSJ_EARLY_A
+#define MSJ_EARLY_A 0
+#endif
 #ifndef MSJ_PRIO_COORD
 #define MSJ_PRIO_COORD 2    // behind the barrier: fold, publish, hand-over, issue of the next range's loads
 #endif
@@ -175,6 +182,7 @@ struct Shared {
     uint32_t role;
     uint32_t shard;          // worker workgroups: the ticket shard they draw from
     uint32_t first_lo;       // ... and the base tile of their first range
+    uint32_t second_lo;      // MSJ_EARLY_A: ... and of their second (two draws at start-up)
     // worker workgroups: wave 0 hands the next range to the other waves with ONE 8-byte LDS store:
     // low word = base tile of the next range, high word = the iteration it is for (r + 1)
     uint64_t handoff __attribute__((aligned(8)));
@@ -1310,6 +1318,10 @@ __device__ __forceinline__ void worker_wave(const KernelArgs &a, Shared &sh, con
     MSJ_RSTAMP(a.ntiles + 4096u + blockIdx.x, 2, tid == 0);
     // LDS words every lane reads identically: uniform (tile indices and all control flow stay scalar)
     uint32_t lo_cur = uniform32(sh.first_lo);
+#if MSJ_EARLY_A
+    uint32_t lo_nxt = uniform32(sh.second_lo);  // the range behind lo_cur, known an iteration early
+    uint32_t nt_next = 0u;                      // ... and whether its bytes are requested non-temporally
+#endif
     const uint64_t count0 = uniform64(cin_count(a));  // launch invariants: read once
     const uint32_t carry0 = uniform32(cin_carry0(a));
     uint32_t timeout = 0;
@@ -1363,9 +1375,28 @@ __device__ __forceinline__ void worker_wave(const KernelArgs &a, Shared &sh, con
                 // the chunks the coalesced loads brought become this lane's block (the staging slice is free: the
                 // last emission's copy-out has been waited for)
                 chunks_to_block(blk[j], chunk_at);
+#if MSJ_EARLY_A
+                if (j == 1) {
+                    // the first tile's registers are free since its compute phase: the NEXT range's first tile goes there now
+                    // and has this compute phase, the barrier and the emission to arrive
+                    const uint32_t tn = lo_nxt + wave;
+                    if (nt_next) {
+                        asm volatile("; non-temporal early loads");
+                        load_block<true, true>(a, tn < ntiles ? tn : ntiles - 1u, lane_off, lane, blk[0]);
+                        asm volatile("; end of non-temporal early loads");
+                    } else {
+                        load_block<true, false>(a, tn < ntiles ? tn : ntiles - 1u, lane_off, lane, blk[0]);
+                    }
+                }
+#endif
                 now[j] = compute_tile(al, t_cur, lane, blk[j], carry0_p, timeout, agg_word);
                 lds_wave_sync_early();  // the next tile's chunks (or the emission) reuse the slice
             }
+#if MSJ_EARLY_A
+            else if (j == 1) {  // (a range whose second tile lies past the end: the next range's does too -- nothing to ask for,
+                                //  but the registers must hold SOMETHING loaded for the waits' bookkeeping: nothing is waited for)
+            }
+#endif
             if (j == 0) {
 #if MSJ_PRIO_COMPUTE2 != MSJ_PRIO_COMPUTE
                 __builtin_amdgcn_s_setprio(MSJ_PRIO_COMPUTE2);
@@ -1373,6 +1404,9 @@ __device__ __forceinline__ void worker_wave(const KernelArgs &a, Shared &sh, con
                 // the prefix word requested above has arrived (nothing younger is in flight yet) ...
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 touch_u64(rp_word);
+#if MSJ_EARLY_A
+                touch_block(blk[1]);  // ... and so has this range's second tile (requested before the last barrier)
+#endif
                 // ... and the next range's ticket is drawn: one compute + one staging phase
                 // ahead of its use, which covers the atomic's round trip
                 if (tid_p == 0) req_reg = ticket_request(ticket_ctr_p, 0u, 1u);
@@ -1383,6 +1417,22 @@ __device__ __forceinline__ void worker_wave(const KernelArgs &a, Shared &sh, con
             }
             MSJ_STAMP(valid_tile ? t_cur : ntiles - 1u, 7);
         }
+#if MSJ_EARLY_A
+        {   // the next range's SECOND tile: this range's has been consumed, its registers are free
+            const uint32_t c0 = now[0].tile_cnt, c1 = now[1].tile_cnt;
+            const uint32_t n0 = (c0 & 0xFFFFu) > (c0 >> 16) ? (c0 & 0xFFFFu) : (c0 >> 16);
+            const uint32_t n1 = (c1 & 0xFFFFu) > (c1 >> 16) ? (c1 & 0xFFFFu) : (c1 >> 16);
+            const uint32_t tn = lo_nxt + kWaves + wave;
+            if (nt_next) {
+                asm volatile("; non-temporal early loads B");
+                load_block<true, true>(a, tn < ntiles ? tn : ntiles - 1u, lane_off, lane, blk[1]);
+                asm volatile("; end of non-temporal early loads B");
+            } else {
+                load_block<true, false>(a, tn < ntiles ? tn : ntiles - 1u, lane_off, lane, blk[1]);
+            }
+            nt_next = (uniform32(n0 + n1) > kNtMaxIndices || ntiles < kNtMinTiles) ? 0u : 1u;  // for the range after that
+        }
+#endif
         const uint32_t srow = (lo_cur + kWaves + wave < ntiles) ? lo_cur + kWaves + wave : ntiles - 1u;  // stamp row (diagnostic builds)
         (void)srow;
         MSJ_STAMP(srow, 8);   // both tiles computed
@@ -1473,6 +1523,7 @@ __device__ __forceinline__ void worker_wave(const KernelArgs &a, Shared &sh, con
             }
             lo_next = (uint32_t)h;
         }
+#if !MSJ_EARLY_A
         {
             // the load policy follows the data (load_block): dense input -> plain loads
             const uint32_t c0 = now[0].tile_cnt, c1 = now[1].tile_cnt;
@@ -1487,6 +1538,7 @@ __device__ __forceinline__ void worker_wave(const KernelArgs &a, Shared &sh, con
                 asm volatile("; end of non-temporal range loads");
             }
         }
+#endif
         MSJ_RSTAMP(lo_cur, 8, tid == 0);  // range aggregate published (real time)
         // ---- 3. emit the range parked kDefer iterations ago; hand the next range over in between
         if (have_old) {
@@ -1511,10 +1563,18 @@ __device__ __forceinline__ void worker_wave(const KernelArgs &a, Shared &sh, con
         emit_stage(sh, e1, wave, slot0 + 1u, stage, lane, lane64);
         lds_wave_sync();
         MSJ_STAMP(srow, 15);  // tile B staged
+#if MSJ_EARLY_A
+        // the next range's FIRST tile has arrived (requested a compute phase, a barrier and an emission ago): loads return
+        // in order, so "at most the five younger loads outstanding" says so whatever the stores in between are doing.  Its
+        // second tile is waited for behind the next compute phase (the vmcnt(0) there).
+        asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+        touch_block(blk[0]);
+#else
         // the bytes requested above (and the first tile's stores) have had a whole staging phase
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #pragma unroll
         for (uint32_t j = 0; j < kBatch; j++) touch_block(blk[j]);
+#endif
         MSJ_STAMP(srow, 11);  // the next range's bytes have arrived
         emit_store<kTypes>(al, sh, e1, wave, slot0 + 1u, stage, lane, lane_p);
         lds_wave_sync();
@@ -1531,7 +1591,12 @@ __device__ __forceinline__ void worker_wave(const KernelArgs &a, Shared &sh, con
                 *reinterpret_cast<uint4 *>(sh.pend_meta[wave][slot]) =
                     make_uint4(t_cur < ntiles ? t_cur : 0xFFFFFFFFu, now[j].tile_cnt, in_cnt[j], in_state[j]);
         }
+#if MSJ_EARLY_A
+        lo_cur = lo_nxt;
+        lo_nxt = lo_next;  // (what the hand-over brought is the range after the next one)
+#else
         lo_cur = lo_next;
+#endif
         r++;
         ring = (ring + 1u == kDefer) ? 0u : ring + 1u;
     }
@@ -2012,6 +2077,10 @@ __device__ __forceinline__ void stage1_body(const KernelArgs &a) {
         sh.role = (shard == 0u && k == 0u) ? 0u : 1u;
         sh.shard = shard;
         sh.first_lo = ticket_range(k, shard, shards) * kRange;
+        if (MSJ_EARLY_A && sh.role != 0u) {
+            const uint32_t k2 = atomicAdd(reinterpret_cast<unsigned int *>(a.ws + (uint64_t)shard * kTicketStrideWords), 1u);
+            sh.second_lo = ticket_range(k2, shard, shards) * kRange;
+        }
         sh.handoff = 0ull;
     }
     __syncthreads();
