@@ -835,7 +835,7 @@ static int32_t tokens_chain_impl(msj_ctx *ctx, const uint8_t *d_buf, uint64_t le
         (reinterpret_cast<uintptr_t>(d_type) & 7u) || (reinterpret_cast<uintptr_t>(d_match) & 15u))  // match[] leaves as 16-byte stores
         return MSJ_ERR_BAD_ARGUMENT;
     if (!hip_ok(hipSetDevice(ctx->device))) return MSJ_ERR_HIP;
-    const uint64_t need = msj_stage2_prep_workspace_bytes(n, len, d_match != nullptr || d_pairs != nullptr);  // incl. the fused kernel's chunk aggregates and table
+    const uint64_t need = msj_stage2_prep_workspace_bytes(n, len, d_pairs ? 2 : (d_match != nullptr ? 1 : 0));  // incl. the fused kernel's chunk aggregates and table
     if (!ensure_tok_ws(ctx, need)) return MSJ_MEMALLOC;
     ctx->tok_doc_n = ~0ull;
     msj_token_opts o = ctx->tok_opts;
@@ -908,7 +908,7 @@ static int32_t prep_chain_impl(msj_ctx *ctx, const uint8_t *d_buf, uint64_t len,
         (reinterpret_cast<uintptr_t>(d_type) & 7u) || (reinterpret_cast<uintptr_t>(d_match) & 15u))  // match[] leaves as 16-byte stores
         return MSJ_ERR_BAD_ARGUMENT;
     if (!hip_ok(hipSetDevice(ctx->device))) return MSJ_ERR_HIP;
-    const uint64_t need = msj_stage2_prep_workspace_bytes(n, len, d_match != nullptr || d_pairs != nullptr);
+    const uint64_t need = msj_stage2_prep_workspace_bytes(n, len, d_pairs ? 2 : (d_match != nullptr ? 1 : 0));
     if (!ensure_tok_ws(ctx, need)) return MSJ_MEMALLOC;
     ctx->tok_doc_n = ~0ull;
     if (!ensure_span_fix(ctx)) return MSJ_MEMALLOC;

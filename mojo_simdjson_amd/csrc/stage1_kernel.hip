@@ -59,6 +59,9 @@
 #ifndef MSJ_EARLY_A
 #define MSJ_EARLY_A 0
 #endif
+#ifndef MSJ_TICKET_AT_TOP
+#define MSJ_TICKET_AT_TOP 0  // EXPERIMENT (round 5, off): see worker_wave
+#endif
 #ifndef MSJ_PRIO_COORD
 #define MSJ_PRIO_COORD 2    // behind the barrier: fold, publish, hand-over, issue of the next range's loads
 #endif
@@ -1361,6 +1364,11 @@ __device__ __forceinline__ void worker_wave(const KernelArgs &a, Shared &sh, con
         // ---- 1. compute
         Pending now[kBatch];
         uint32_t req_reg = 0;
+#if MSJ_TICKET_AT_TOP
+        // EXPERIMENT (round 5): the next range's ticket drawn at the TOP of the iteration -- both compute phases cover the
+        // atomic's round trip instead of one (on sparse input one phase is shorter than the round trip)
+        if (tid_p == 0) req_reg = ticket_request(ticket_ctr_p, 0u, 1u);
+#endif
 #pragma unroll
         for (uint32_t j = 0; j < kBatch; j++) {
             const uint32_t t_cur = lo_cur + kWaves * j + wave;
@@ -1402,6 +1410,10 @@ __device__ __forceinline__ void worker_wave(const KernelArgs &a, Shared &sh, con
                 __builtin_amdgcn_s_setprio(MSJ_PRIO_COMPUTE2);
 #endif
                 // the prefix word requested above has arrived (nothing younger is in flight yet) ...
+#if MSJ_TICKET_AT_TOP
+                // (wave 0's ticket is younger than the prefix word and may stay out: returns come in order)
+                if (wave_p == 0) asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); else
+#endif
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 touch_u64(rp_word);
 #if MSJ_EARLY_A
@@ -1409,7 +1421,9 @@ __device__ __forceinline__ void worker_wave(const KernelArgs &a, Shared &sh, con
 #endif
                 // ... and the next range's ticket is drawn: one compute + one staging phase
                 // ahead of its use, which covers the atomic's round trip
+#if !MSJ_TICKET_AT_TOP
                 if (tid_p == 0) req_reg = ticket_request(ticket_ctr_p, 0u, 1u);
+#endif
             }
             if (lane_p == 0) {
                 if (valid_tile) st_desc(&a.ws[kDescOffset + t_cur], agg_word);  // carries for t_cur + 1

@@ -315,7 +315,7 @@ constexpr int kMatchBelow = 4;
 // generic/stage2/tape_builder.mojo:235-272)
 template <int kMode>
 struct DepthShared {
-    static constexpr bool kMatch = kMode != 0;
+    static constexpr bool kMatch = kMode == 1 || kMode == 2;
     uint32_t bm[kMatch ? kMatchLevels : 1][kMatch ? kBlock / 32 : 1];  // opening brackets per level, one bit per token
     unsigned long long bm_words[kMatch ? kMatchLevels : 1];              // ... and which of a level's 64 words are not empty
     __attribute__((aligned(16))) uint32_t s_match[kMode == 1 ? kBlock : 4];
@@ -334,8 +334,9 @@ __device__ __forceinline__ void apply_depth_block(DepthShared<kMode> &sh, const 
                                                   int32_t *__restrict__ min64, int32_t *__restrict__ min512, uint32_t *__restrict__ opens,
                                                   uint4 *__restrict__ doc_agg, int32_t *__restrict__ block_mm,
                                                   uint32_t *__restrict__ match_blk, uint32_t *__restrict__ survivors, const uint32_t match_bias,
-                                                  const uint32_t want_closers, uint2 *__restrict__ pairs_blk, const uint32_t open_base) {
-    constexpr bool kMatch = kMode != 0;
+                                                  const uint32_t want_closers, uint2 *__restrict__ pairs_blk, const uint32_t open_base,
+                                                  uint32_t *__restrict__ brk_tok, int32_t *__restrict__ brk_depth, const uint32_t brk_base) {
+    constexpr bool kMatch = kMode == 1 || kMode == 2;
     // (the LDS lives in the kernel: two instantiations of this function must not own two copies of it)
     auto &bm = sh.bm;
     auto &bm_words = sh.bm_words;
@@ -399,6 +400,61 @@ __device__ __forceinline__ void apply_depth_block(DepthShared<kMode> &sh, const 
             rmn = min(rmn, before);
             rmx = max(rmx, before);
         }
+    }
+    if (kMode == 3) {
+        // Round 5, the pairs form: the call's BRACKETS leave as a compact list in token order -- {token | closing << 31,
+        // depth} each, 8 % of the minified workload's tokens -- and match_compact pairs them there: a block of 2 048
+        // brackets spans ~25 000 tokens, the bitmaps and look-ups are paid per bracket instead of per token, and this
+        // kernel stays the depths-only pass.  A bracket's slot needs no scan of its own: in front of any token
+        // opening + closing brackets = its slot and opening - closing = the running depth, both of which the thread has
+        // (slot = 2 x opening brackets in front - running depth relative to the call's start).
+        uint32_t om = 0, cm = 0;
+#pragma unroll
+        for (int k = 0; k < kPer; k++) {
+            om |= d[k] > 0 ? 1u << k : 0u;
+            cm |= d[k] < 0 ? 1u << k : 0u;
+        }
+        if (!kFull) om &= vm, cm &= vm;
+        const int before0 = out[0] + (d[0] < 0 ? 1 : 0);  // the running depth in front of this thread's first token
+        uint32_t excl_no = (uint32_t)(incl_no - no);
+        for (int w = 0; w < wave; w++) excl_no += (uint32_t)wave_no[w];
+        const uint32_t slot0 = 2u * excl_no - (uint32_t)(before0 - block_depth0);  // the thread's first bracket among the block's
+        // The entries leave through the wave's staging slice (free until the depths go out): a thread's brackets are few
+        // and scattered, and a store instruction per round of every thread's next bracket costs the same 64 address slots
+        // as a full one (measured: 298 us for this kernel that way, against 175 for the depths alone).  One word per bracket
+        // in LDS -- token inside the wave | closing << 9 | depth relative to the block's start << 10 -- then lane j takes
+        // the wave's j-th bracket: one round of two coalesced stores for up to 64 brackets.
+        const uint32_t nbk = (uint32_t)__builtin_popcount(om | cm);
+        const uint32_t incl_nb = wave_incl_sum(nbk);
+        const uint32_t n_w = (uint32_t)__builtin_amdgcn_readlane((int)incl_nb, 63);  // brackets of the wave
+        uint32_t *const blist = reinterpret_cast<uint32_t *>(&s_out[wave][0]);       // 512 entries
+        uint32_t ws = incl_nb - nbk;
+        for (uint32_t rem = om | cm; __ballot(rem != 0u) != 0ull;) {  // uniform: max over the lanes of their brackets (2 - 4)
+            if (rem != 0u) {
+                const uint32_t k = (uint32_t)__builtin_ctz(rem), below = (1u << k) - 1u;
+                rem &= rem - 1u;
+                const uint32_t closes = (cm >> k) & 1u;
+                // an opening bracket sits at the running depth in front of it, a closing one at the depth of its container
+                const int rel = before0 - block_depth0 + (int)__builtin_popcount(om & below) - (int)__builtin_popcount(cm & below) - (int)closes;
+                blist[ws++] = (8u * (uint32_t)lane + k) | (closes << 9) | ((uint32_t)rel << 10);
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        // the wave's first bracket: the slot of lane 0's first one
+        const uint32_t g_w = brk_base + (uint32_t)__builtin_amdgcn_readfirstlane((int)slot0);
+        for (uint32_t j0 = 0; j0 < n_w; j0 += 64u) {  // uniform
+            const uint32_t j = j0 + (uint32_t)lane;
+            if (j < n_w) {
+                const uint32_t e = blist[j];
+                brk_tok[g_w + j] = (blk0 + (uint32_t)wave * 512u + (e & 511u)) | ((e >> 9) << 31);
+                brk_depth[g_w + j] = block_depth0 + ((int)e >> 10);
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();  // (the depths are staged in the same slice below)
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     }
     bool surv_any = false;
     uint32_t surv_incl = 0, surv_slot = 0, surv_mine = 0, surv_mask = 0, cand_mask = 0, surv_rank0 = 0, surv_om = 0;
@@ -744,10 +800,10 @@ __global__ __launch_bounds__(kThreads) void apply_depth(const uint8_t *__restric
                                                         uint32_t *__restrict__ opens, uint4 *__restrict__ doc_agg,
                                                         int32_t *__restrict__ block_mm, const msj_tokens_result *__restrict__ prev,
                                                         uint32_t *__restrict__ match, uint32_t *__restrict__ survivors, uint32_t match_bias,
-                                                        uint32_t want_closers, uint2 *__restrict__ pairs) {
-    constexpr bool kMatch = kMode != 0;
+                                                        uint32_t want_closers, uint2 *__restrict__ pairs, uint32_t *__restrict__ brk_tok,
+                                                        int32_t *__restrict__ brk_depth) {
     // pairs: the number of opening brackets of the call in front of this block = where its containers' records start
-    const uint32_t open_base = kMode == 2 ? super_open[blockIdx.x / kSuper] + open_start[blockIdx.x] : 0u;
+    const uint32_t open_base = kMode >= 2 ? super_open[blockIdx.x / kSuper] + open_start[blockIdx.x] : 0u;
     // everything the block touches, as uniform (scalar) base pointers: the lanes add 32-bit offsets inside the block
     const uint64_t b0 = (uint64_t)blockIdx.x * kBlock;
     // tokens of this block: n < 2^31 (the entry points check), so 32-bit arithmetic and ONE s_min_u32.  (Written as a
@@ -757,16 +813,163 @@ __global__ __launch_bounds__(kThreads) void apply_depth(const uint8_t *__restric
     const uint32_t nrem = min((uint32_t)n - blockIdx.x * kBlock, kBlock);
     const int block_depth0 = (prev ? prev->final_depth : 0) + super_start[blockIdx.x / kSuper] + block_start[blockIdx.x];  // uniform
     int32_t *m8 = min8 ? min8 + (b0 >> 3) : nullptr, *m64 = min8 ? min64 + (b0 >> 6) : nullptr, *m512 = min8 ? min512 + (b0 >> 9) : nullptr;
+    // (compact list) the brackets of the call in front of this block: 2 x the opening ones - the depth they leave behind
+    const uint32_t brk_base = kMode == 3 ? 2u * open_base - (uint32_t)(super_start[blockIdx.x / kSuper] + block_start[blockIdx.x]) : 0u;
     __shared__ DepthShared<kMode> sh;
     if (nrem == kBlock)
         apply_depth_block<kMode, true>(sh, type + b0, nrem, block_depth0, depth + b0, m8, m64, m512, opens, doc_agg, block_mm,
                                        kMode == 1 ? match + b0 : nullptr, survivors, match_bias, want_closers,
-                                       kMode == 2 ? pairs + open_base : nullptr, open_base);
+                                       kMode == 2 ? pairs + open_base : nullptr, open_base, brk_tok, brk_depth, brk_base);
     else
         apply_depth_block<kMode, false>(sh, type + b0, nrem, block_depth0, depth + b0, m8, m64, m512, opens, doc_agg, block_mm,
                                         kMode == 1 ? match + b0 : nullptr, survivors, match_bias, want_closers,
-                                        kMode == 2 ? pairs + open_base : nullptr, open_base);
-    (void)kMatch;
+                                        kMode == 2 ? pairs + open_base : nullptr, open_base, brk_tok, brk_depth, brk_base);
+}
+
+// (3b) the same pass ORGANISED BY ROWS (round 5) for the calls without match[]: 64 tokens a row, lane l of row r holding
+// token 64 r + l.  A row's opening and closing brackets are two 64-bit masks -- the compares ARE the ballots -- and
+// everything the pass derives is a count of mask bits below the lane: the running depth in front of a token = depth in
+// front of the row (scalar) + opening - closing brackets below the lane (v_mbcnt pairs; no per-thread loop, no DPP scan),
+// the document counts are popcounts and find-last-bits of masks (scalar), and -- kCompact, the pairs form -- a bracket's
+// place in the COMPACT list of the call's brackets is the row's base (scalar) + the brackets below the lane.
+// A WAVE TAKES A WHOLE BLOCK of 2 048 tokens (32 rows, four chunks of eight), so a block's start depth from the scans is
+// all it needs: no prefix over the waves of a workgroup, no LDS, no barrier -- the waves of a workgroup are independent,
+// all 32 loads of a wave go out at once and their latency is paid once per 2 048 tokens.  (With a block per WORKGROUP,
+// 512 tokens a wave, the kernel was bound by the workgroup's lifetime -- load latency, barrier, ~1 us of arithmetic, the
+// list's round, barrier: 5 us per block at the 8 workgroups a CU holds, every dependent step added paid in full -- 267
+// us for the pairs form against 175 for the depths; apply_depth<3>, a per-thread loop over the set bits of eight tokens'
+// bracket masks, was bound by instruction issue: 356 vector instructions per wave of 512 tokens.)
+// The compact list (kCompact): {token | closing << 31, depth} per bracket in token order, which match_compact pairs.
+// A bracket's slot needs no scan of its own: in front of any token, opening + closing brackets = its slot and opening -
+// closing = the running depth, so the brackets in front of a block = 2 x the opening ones - the depth they leave behind.
+// profiles/r05/depth_rows_*.txt.
+__device__ __forceinline__ uint32_t bits_below(uint64_t m, uint32_t init) {  // init + bits of m below this lane
+    return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, init));
+}
+constexpr uint32_t kRowsWaves = kThreads / 64;  // blocks per workgroup: a wave each
+template <bool kCompact, bool kFull>
+__device__ __forceinline__ void depth_rows_wave(uint32_t *__restrict__ blist /* kCompact: 512 words of LDS, this wave's */,
+                                                const uint8_t *__restrict__ type_blk, const uint32_t blk /* block number */, const uint32_t nrem,
+                                                const int block_depth0, int32_t *__restrict__ depth_blk, uint4 *__restrict__ doc_agg,
+                                                int32_t *__restrict__ block_mm, uint32_t *__restrict__ brk_tok,
+                                                int32_t *__restrict__ brk_depth, const uint32_t brk_base) {
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t blk0 = blk * kBlock;
+    // the block's type bytes: 64 contiguous bytes per row and load, all of them asked for at once; a token that does not
+    // exist reads as a blank (no bracket)
+    uint32_t x[4][8];
+#pragma unroll
+    for (uint32_t c = 0; c < 4; c++)
+#pragma unroll
+        for (uint32_t r = 0; r < 8; r++) {
+            const uint32_t t = 512u * c + 64u * r + lane;
+            x[c][r] = (kFull || t < nrem) ? (uint32_t)type_blk[t] : 0x20u;
+        }
+    int D = block_depth0;  // running depth in front of the row (scalar)
+    uint32_t G = brk_base;  // (compact) the call's brackets in front of the chunk
+    int rmn = kNone, rmx = -kNone;  // minimum / maximum of the running depth AFTER each of this lane's tokens
+    uint32_t cnt = 0, ls = 0, lc = 0;  // scalar: document starts of the block, the last of them + 1, the last closing bracket at depth 0 + 1
+#pragma unroll
+    for (uint32_t c = 0; c < 4; c++) {
+        if (!kFull && 512u * c >= nrem) break;  // uniform
+        uint64_t up[8], dn[8];
+#pragma unroll
+        for (int r = 0; r < 8; r++) {
+            const uint32_t v = x[c][r] & 0xDFu;  // '[' '{' -> 5B, ']' '}' -> 5D
+            up[r] = __ballot(v == 0x5Bu);
+            dn[r] = __ballot(v == 0x5Du);
+        }
+        uint32_t S = 0;  // (compact) brackets of the chunk in front of the row
+#pragma unroll
+        for (uint32_t r = 0; r < 8; r++) {
+            const uint32_t t = 512u * c + 64u * r + lane;
+            // the masks as lane predicates (no second compare: the mask IS the execution mask / the select's condition)
+            const bool isup = __builtin_amdgcn_inverse_ballot_w64(up[r]);
+            // a closing bracket sits at the depth of its container, one below the running depth in front of it: the closing
+            // brackets AT or below the lane = those below the lane of the mask shifted down by one + its bit 0 (scalar)
+            const int out = (int)bits_below(up[r], (uint32_t)D) - (int)bits_below(dn[r] >> 1, (uint32_t)(dn[r] & 1ull));
+            const int after = out + (isup ? 1 : 0);
+            const bool exists = kFull || t < nrem;
+            if (exists) {
+                rmn = min(rmn, after);
+                rmx = max(rmx, after);
+                __builtin_nontemporal_store(out, depth_blk + t);  // 256 contiguous bytes per row: a write-once stream
+            }
+            // what the document split (documents_kernel.hip) would recompute from type[] and depth[]: tokens at depth 0 --
+            // no row of a large document holds one, the compare IS the ballot
+            const uint64_t zero = __ballot(exists && out == 0);
+            if (zero != 0ull) {  // uniform
+                const uint64_t zs = zero & ~dn[r], zc = zero & dn[r];
+                cnt += (uint32_t)__popcll(zs);
+                if (zs) ls = blk0 + 512u * c + 64u * r + 64u - (uint32_t)__clzll((long long)zs);
+                if (zc) lc = blk0 + 512u * c + 64u * r + 64u - (uint32_t)__clzll((long long)zc);
+            }
+            if (kCompact) {
+                const uint64_t m = up[r] | dn[r];
+                if (m != 0ull) {  // uniform
+                    const uint32_t pos = bits_below(m, S);
+                    // one word per bracket: token inside the chunk | closing << 9 | depth relative to the block's start << 10
+                    const uint32_t e = ((uint32_t)(out - block_depth0) << 10) | (__builtin_amdgcn_inverse_ballot_w64(dn[r]) ? 512u : 0u) | (64u * r + lane);
+                    if (__builtin_amdgcn_inverse_ballot_w64(m)) blist[pos] = e;
+                    S += (uint32_t)__popcll(m);
+                }
+            }
+            D += (int)__popcll(up[r]) - (int)__popcll(dn[r]);
+        }
+        if (kCompact && S != 0u) {  // uniform: lane j takes the chunk's j-th bracket, two coalesced stores per 64 of them
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            // (scalar bases, the lane's 32-bit offset behind them: no 64-bit vector arithmetic)
+            uint32_t *const bt = brk_tok + G;
+            int32_t *const bd = brk_depth + G;
+            const uint32_t tok0 = blk0 + 512u * c;
+#pragma unroll 1
+            for (uint32_t j0 = 0; j0 < S; j0 += 64u) {  // uniform: one round unless the chunk holds more than 64 brackets
+                const uint32_t j = j0 + lane;
+                if (j < S) {
+                    const uint32_t e = blist[j];
+                    bt[j] = (tok0 + (e & 511u)) | ((e >> 9) << 31);
+                    bd[j] = block_depth0 + ((int)e >> 10);
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();  // (the next chunk writes the list again)
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            G += S;
+        }
+    }
+    int w_rmn, w_rmx;
+    wave_min_max(rmn, rmx, w_rmn, w_rmx);
+    if (lane == 0u) {
+        doc_agg[blk] = make_uint4(cnt, ls, lc, 0);
+        // (words 1 and 2 of the block's aggregate: min_max_depth folds them into the result, as behind apply_depth)
+        block_mm[4 * (uint64_t)blk + 1] = w_rmn;
+        block_mm[4 * (uint64_t)blk + 2] = w_rmx;
+    }
+}
+template <bool kCompact>
+__global__ __launch_bounds__(kThreads) void depth_rows(const uint8_t *__restrict__ type, uint64_t n, uint32_t nblocks,
+                                                       const int32_t *__restrict__ block_start,
+                                                       const int32_t *__restrict__ super_start, const uint32_t *__restrict__ super_open,
+                                                       const uint32_t *__restrict__ open_start, int32_t *__restrict__ depth,
+                                                       uint4 *__restrict__ doc_agg, int32_t *__restrict__ block_mm,
+                                                       const msj_tokens_result *__restrict__ prev, uint32_t *__restrict__ brk_tok,
+                                                       int32_t *__restrict__ brk_depth) {
+    __shared__ uint32_t s_list[kCompact ? kRowsWaves : 1][kCompact ? 512 : 1];
+    const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const uint32_t blk = blockIdx.x * kRowsWaves + wave;
+    if (blk >= nblocks) return;  // uniform per wave (no barrier anywhere in the kernel)
+    const uint64_t b0 = (uint64_t)blk * kBlock;
+    const uint32_t nrem = min((uint32_t)n - blk * kBlock, kBlock);  // (32-bit: see apply_depth)
+    const int rel0 = super_start[blk / kSuper] + block_start[blk];  // depth in front of the block, relative to the call's start
+    const int block_depth0 = (prev ? prev->final_depth : 0) + rel0;
+    const uint32_t brk_base = kCompact ? 2u * (super_open[blk / kSuper] + open_start[blk]) - (uint32_t)rel0 : 0u;
+    uint32_t *blist = &s_list[kCompact ? wave : 0][0];
+    if (nrem == kBlock)
+        depth_rows_wave<kCompact, true>(blist, type + b0, blk, nrem, block_depth0, depth + b0, doc_agg, block_mm, brk_tok, brk_depth, brk_base);
+    else
+        depth_rows_wave<kCompact, false>(blist, type + b0, blk, nrem, block_depth0, depth + b0, doc_agg, block_mm, brk_tok, brk_depth, brk_base);
 }
 
 // (4) minimum / maximum of the running depth over the stream, from the per-block values apply_depth left in the block
@@ -851,16 +1054,16 @@ __global__ __launch_bounds__(1024) void build_upper_levels(const UpperLevels u) 
 // the 8 entries of group g at one level; a level's last group is read with a guard at its end (the padding of a
 // level is never written: only the brackets a block could not pair walk the tree, so the guard costs nothing that
 // shows and saves a fill of the tree in front of every call)
-__device__ __forceinline__ void load_group(const MinTree &t, int lev, uint32_t g, int v[8]) {
+__device__ __forceinline__ void load_group(const MinTree &t, int lev, uint32_t g, int v[8], const uint32_t cnt) {  // cnt: entries of the level
     const int32_t *p = t.lv[lev] + ((uint64_t)g << kFanShift);
-    if (((uint64_t)g << kFanShift) + 8u <= t.cnt[lev]) {
+    if (((uint64_t)g << kFanShift) + 8u <= cnt) {
         const int4 a = *reinterpret_cast<const int4 *>(p);
         const int4 b = *reinterpret_cast<const int4 *>(p + 4);
         v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w;
         v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
     } else {
 #pragma unroll
-        for (int k = 0; k < 8; k++) v[k] = (((uint64_t)g << kFanShift) + k < t.cnt[lev]) ? p[k] : kNone;
+        for (int k = 0; k < 8; k++) v[k] = (((uint64_t)g << kFanShift) + k < cnt) ? p[k] : kNone;
     }
 }
 // first k >= from with v[k] <= target, 8 if none
@@ -885,23 +1088,49 @@ __device__ __forceinline__ uint32_t first_le(const int v[8], uint32_t from, int 
 #ifndef MSJ_MATCH_LINEAR
 #define MSJ_MATCH_LINEAR 256
 #endif
+#ifndef MSJ_COMPACT_GRID
+#define MSJ_COMPACT_GRID 4096  // workgroups of match_compact at most (each strides over the blocks of 2 048 brackets)
+#endif
 constexpr uint32_t kLinear = MSJ_MATCH_LINEAR, kGroup = 8, kSteps = 8;  // 64 tokens per group and round
+// kCompact (round 5, the pairs form): the same walk over the COMPACT list of the call's brackets -- t_in.lv[0] is that
+// list's depth word per bracket, brk_tok its token word (bit 31: a closing bracket), an entry of the lists the bracket's
+// place in the compact list, and the number of brackets -- hence every level's count -- is only known on the device:
+// 2 x the opening brackets - the depth they leave behind (scan_blocks put both into the result).
+__device__ __forceinline__ uint32_t bracket_count(const msj_tokens_result *__restrict__ result, const msj_tokens_result *__restrict__ prev) {
+    return 2u * result->reserved - (uint32_t)(result->final_depth - (prev ? prev->final_depth : 0));
+}
+// entries of level `lev` of a tree over n0 entries: ceil(n0 / 8^lev) (a ceiling of ceilings is the ceiling of the product)
+__device__ __forceinline__ uint32_t level_entries(uint32_t n0, int lev) {
+    return (uint32_t)(((uint64_t)n0 + (1ull << (kFanShift * lev)) - 1ull) >> (kFanShift * lev));
+}
+__device__ __forceinline__ int level_number(uint32_t n0) {  // as the host lays the levels out: one more while the last holds more than 8
+    int nlev = 1;
+    while (nlev < kMaxLevels && level_entries(n0, nlev - 1) > 8u) nlev++;
+    return nlev;
+}
+template <bool kCompact>
 __global__ __launch_bounds__(256) void match_brackets(const uint8_t *__restrict__ type, const uint32_t *__restrict__ opens,
-                                                      const uint32_t *__restrict__ n_opens, const MinTree t,
+                                                      const uint32_t *__restrict__ n_opens, const MinTree t_in,
                                                       uint32_t *__restrict__ match, uint64_t list_capacity, uint32_t match_bias,
                                                       const msj_tokens_result *__restrict__ result, uint32_t *__restrict__ resid,
-                                                      uint2 *__restrict__ pairs) {
+                                                      uint2 *__restrict__ pairs, const uint32_t *__restrict__ brk_tok,
+                                                      const msj_tokens_result *__restrict__ prev) {
+    const MinTree &t = t_in;
+    // (compact: the counts follow from the call's number of brackets; computed, not kept in an array a loop would index)
+    const uint32_t n = kCompact ? bracket_count(result, prev) : t.cnt[0];
+    const int nlev = kCompact ? level_number(n) : t.nlev;
+    const auto count_of = [&](int lev) -> uint32_t { return kCompact ? level_entries(n, lev) : t.cnt[lev]; };
+    const bool two_words = !kCompact && pairs;  // (the in-block pairs form: token and rank per entry, the lists twice as long)
     // one list per blockIdx.y (kSurvivorShards of them), the lane groups of its workgroups stride over it
     const uint32_t total = n_opens[blockIdx.y * kSurvivorStride];
-    opens += (uint64_t)blockIdx.y * list_capacity * (pairs ? 2u : 1u);
+    opens += (uint64_t)blockIdx.y * list_capacity * (two_words ? 2u : 1u);
     const uint32_t lane = threadIdx.x & 63u, sub = lane & (kGroup - 1u), grp = lane / kGroup;
-    const uint32_t n = t.cnt[0];
     constexpr uint32_t per_wave = 64u / kGroup;
     const uint64_t wave0 = ((uint64_t)blockIdx.x * 4u + (threadIdx.x >> 6)) * per_wave, stride = (uint64_t)gridDim.x * 4u * per_wave;
     for (uint64_t w0 = wave0; w0 < total; w0 += stride) {  // uniform per wave
         const uint64_t w = w0 + grp;
-        const uint32_t entry = w < total ? opens[pairs ? 2u * w : w] : 0x80000000u;  // (pairs: two words per entry, the lists twice as long)
-        const uint32_t rank = (pairs && w < total) ? opens[2u * w + 1u] : 0u;
+        const uint32_t entry = w < total ? opens[two_words ? 2u * w : w] : 0x80000000u;
+        const uint32_t rank = (two_words && w < total) ? opens[2u * w + 1u] : 0u;
         const bool have = (entry >> 31) == 0u;  // (bit 31: a closing bracket listed for collect_closers)
         const uint32_t i = have ? entry : 0u;
         const int target = have ? t.lv[0][i] : kNone;
@@ -944,11 +1173,11 @@ __global__ __launch_bounds__(256) void match_brackets(const uint8_t *__restrict_
             for (int lev = 0; lev < kMaxLevels; lev++) {
                 at[lev] = p;
                 const uint32_t g = p >> kFanShift;
-                const bool in = lev < t.nlev && ((uint64_t)g << kFanShift) < t.cnt[lev];
+                const bool in = lev < nlev && ((uint64_t)g << kFanShift) < count_of(lev);
                 ga[lev] = gb[lev] = make_int4(kNone, kNone, kNone, kNone);
                 if (in) {
                     int v[8];
-                    load_group(t, lev, g, v);
+                    load_group(t, lev, g, v, count_of(lev));
                     ga[lev] = make_int4(v[0], v[1], v[2], v[3]);
                     gb[lev] = make_int4(v[4], v[5], v[6], v[7]);
                 }
@@ -969,12 +1198,19 @@ __global__ __launch_bounds__(256) void match_brackets(const uint8_t *__restrict_
                 int v[8];
                 for (int lev = lev_hit; lev > 0;) {  // descend: the first child that qualifies
                     lev--;
-                    load_group(t, lev, pos, v);
+                    load_group(t, lev, pos, v, count_of(lev));
                     pos = (pos << kFanShift) + first_le(v, 0u, target);
                 }
             }
         }
-        if (have && found && sub == 0u) {
+        if (kCompact) {
+            if (have && sub == 0u) {
+                // the record's place: the opening brackets in front of bracket i = (i + the depth in front of it) / 2
+                const uint32_t r = (i + (uint32_t)(target - (prev ? prev->final_depth : 0))) >> 1;
+                const uint32_t cj = found ? brk_tok[pos] : 0u;
+                pairs[r] = make_uint2(brk_tok[i], (cj >> 31) ? (cj & 0x7FFFFFFFu) : 0xFFFFFFFFu);
+            }
+        } else if (have && found && sub == 0u) {
             const uint32_t cj = type[pos];
             if (pairs) {
                 pairs[rank] = make_uint2(i, (cj == '}' || cj == ']') ? pos : 0xFFFFFFFFu);
@@ -1053,6 +1289,191 @@ __global__ __launch_bounds__(256) void stitch_partners(const msj_stitch_args a, 
     if (clipped) atomicOr(&results[a.n_segments - 1u].reserved, 0x80000000u);  // nesting deeper than MSJ_RESID_CAP at a border
 }
 
+
+// ---- the pairs form (round 5): bracket partners on the COMPACT list depth_rows<true> leaves -- brk_tok[j] = token |
+// closing << 31, brk_depth[j] = the bracket's depth, j in token order.  A workgroup takes 2 048 brackets (the containers of
+// ~25 000 tokens of the minified workload): the same level bitmaps as apply_depth<1> -- the partner of a closing bracket
+// at depth d is the most recent opening one at depth d in front of it -- but every lane's every slot is a bracket, the
+// depths are given (no scan), and far fewer containers span a border.  A container's record goes to the place of its
+// opening bracket among the call's opening ones: (slot + depth in front) / 2.  Opening brackets nobody claimed go on the
+// lists match_brackets<true> walks, with the three lowest levels of the min tree over brk_depth[] written on the way.
+// (Measured and dropped, profiles/r05/match_compact_history.txt: a WAVE per 2 048 brackets, 32 rows of 64, pairing through
+// the fact that the brackets of one level alternate -- a closing bracket's partner is the level's bracket in front of it:
+// the next lower bit of the level's ballot, or the one carried from the rows before in lane `level` of a register; no LDS,
+// no barrier -- is bit-exact and costs a loop over the levels present in every row: ~8 000 instructions per block against
+// 2 400 here, 183 us per GiB minified against 81.)
+constexpr uint32_t kCompactBlock = 2048;
+__global__ __launch_bounds__(256) void match_compact(const uint32_t *__restrict__ brk_tok, const int32_t *__restrict__ brk_depth,
+                                                     const msj_tokens_result *__restrict__ result, const msj_tokens_result *__restrict__ prev,
+                                                     uint2 *__restrict__ pairs, int32_t *__restrict__ min8, int32_t *__restrict__ min64,
+                                                     int32_t *__restrict__ min512, uint32_t *__restrict__ opens,
+                                                     uint32_t *__restrict__ survivors, uint64_t list_capacity) {
+    __shared__ uint32_t bm[kMatchLevels][kCompactBlock / 32];
+    __shared__ unsigned long long bm_words[kMatchLevels];
+    __shared__ uint32_t s_paired[kCompactBlock / 32];
+    __shared__ __attribute__((aligned(16))) uint32_t s_tok[kCompactBlock];
+    const int d_call = prev ? prev->final_depth : 0;
+    const uint32_t nbrk = bracket_count(result, prev);
+    const uint32_t ncb = (nbrk + kCompactBlock - 1u) / kCompactBlock;
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    const uint32_t p0 = 8u * threadIdx.x;  // this thread's first bracket inside the block
+    for (uint32_t cb = blockIdx.x; cb < ncb; cb += gridDim.x) {  // uniform
+        const uint32_t base = cb * kCompactBlock, nrem = min(nbrk - base, kCompactBlock);
+        {
+            uint32_t *z = &bm[0][0];
+#pragma unroll
+            for (int k = 0; k < kMatchLevels * (int)(kCompactBlock / 32) / 256; k++) z[threadIdx.x + k * 256] = 0u;
+            if (threadIdx.x < kCompactBlock / 32) s_paired[threadIdx.x] = 0u;
+        }
+        uint32_t tok[8];
+        int dep[8];
+        const uint32_t vm = p0 >= nrem ? 0u : (nrem - p0 >= 8u ? 0xFFu : (1u << (nrem - p0)) - 1u);
+        if (vm == 0xFFu) {
+            const uint4 a = *reinterpret_cast<const uint4 *>(brk_tok + base + p0), b = *reinterpret_cast<const uint4 *>(brk_tok + base + p0 + 4u);
+            const int4 c = *reinterpret_cast<const int4 *>(brk_depth + base + p0), e = *reinterpret_cast<const int4 *>(brk_depth + base + p0 + 4u);
+            tok[0] = a.x, tok[1] = a.y, tok[2] = a.z, tok[3] = a.w, tok[4] = b.x, tok[5] = b.y, tok[6] = b.z, tok[7] = b.w;
+            dep[0] = c.x, dep[1] = c.y, dep[2] = c.z, dep[3] = c.w, dep[4] = e.x, dep[5] = e.y, dep[6] = e.z, dep[7] = e.w;
+        } else {
+#pragma unroll
+            for (int k = 0; k < 8; k++) {
+                const bool in = (vm >> k) & 1u;
+                tok[k] = in ? brk_tok[base + p0 + k] : 0u;
+                dep[k] = in ? brk_depth[base + p0 + k] : kNone;
+            }
+        }
+        *reinterpret_cast<uint4 *>(&s_tok[p0]) = make_uint4(tok[0], tok[1], tok[2], tok[3]);
+        *reinterpret_cast<uint4 *>(&s_tok[p0 + 4u]) = make_uint4(tok[4], tok[5], tok[6], tok[7]);
+        uint32_t cm = 0;
+#pragma unroll
+        for (int k = 0; k < 8; k++) cm |= (tok[k] >> 31) << k;
+        cm &= vm;
+        const uint32_t om = ~cm & vm;
+        // the levels kept: from kMatchBelow below the running depth in front of the block's first bracket (uniform, scalar loads)
+        const int level0 = brk_depth[base] + (int)(brk_tok[base] >> 31) - kMatchBelow;
+        __syncthreads();
+        // (a) the opening brackets' bits (a thread's eight brackets share a word)
+        const uint32_t word = p0 >> 5, sh0 = p0 & 31u;
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            const uint32_t lv = (uint32_t)(dep[k] - level0);
+            if (((om >> k) & 1u) && lv < (uint32_t)kMatchLevels) atomicOr(&bm[lv][word], 1u << (sh0 + k));
+        }
+        __syncthreads();
+        // (b) the level's words that hold one (every lane here holds brackets: 64 lanes OR-ing one summary word would
+        // serialise; a wave takes four levels, the compare of a level's 64 words IS the ballot)
+#pragma unroll
+        for (uint32_t q = 0; q < kMatchLevels / 4u; q++) {
+            const uint32_t lv = 4u * wave + q;
+            const uint64_t nz = __ballot(bm[lv][lane] != 0u);
+            if (lane == 0u) bm_words[lv] = nz;
+        }
+        __syncthreads();
+        // (c) every closing bracket looks for the most recent opening one of its level
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            const uint32_t lv = (uint32_t)(dep[k] - level0);
+            if (((cm >> k) & 1u) && lv < (uint32_t)kMatchLevels) {
+                uint32_t m = bm[lv][word] & ((1u << (sh0 + k)) - 1u);
+                uint32_t wi = word;
+                if (m == 0u) {
+                    const uint64_t nz = bm_words[lv] & ((1ull << word) - 1ull);
+                    if (nz != 0ull) {
+                        wi = 63u - (uint32_t)__clzll((long long)nz);
+                        m = bm[lv][wi];
+                    }
+                }
+                if (m != 0u) {
+                    const uint32_t i = 32u * wi + 31u - (uint32_t)__clz((int)m);
+                    const uint32_t r = (base + i + (uint32_t)(dep[k] - d_call)) >> 1;
+                    pairs[r] = make_uint2(s_tok[i], tok[k] & 0x7FFFFFFFu);
+                    atomicOr(&s_paired[wi], 1u << (i & 31u));
+                }
+            }
+        }
+        __syncthreads();
+        // (d) the opening brackets nobody claimed: to the lists match_brackets<true> works through (any order)
+        {
+            const uint32_t surv = om & ~(s_paired[word] >> sh0);
+            const uint32_t mine = (uint32_t)__builtin_popcount(surv);
+            if (__ballot(mine != 0u) != 0ull) {  // uniform per wave
+                const uint32_t incl = wave_incl_sum(mine);
+                const uint32_t shard = cb % kSurvivorShards;
+                uint32_t slot0 = 0;
+                if (lane == 63u) slot0 = atomicAdd(survivors + shard * kSurvivorStride, incl);
+                uint32_t slot = (uint32_t)__builtin_amdgcn_readlane((int)slot0, 63) + incl - mine;
+                uint32_t *list = opens + (uint64_t)shard * list_capacity;
+#pragma unroll
+                for (int k = 0; k < 8; k++)
+                    if ((surv >> k) & 1u) list[slot++] = base + p0 + (uint32_t)k;
+            }
+        }
+        // (e) the three lowest levels of the 8-ary min tree over brk_depth[] (as apply_depth<1> over depth[])
+        {
+            int m = kNone;
+#pragma unroll
+            for (int k = 0; k < 8; k++) m = min(m, dep[k]);  // (a bracket that does not exist: kNone)
+            if (vm) min8[(base >> 3) + threadIdx.x] = m;
+            asm volatile(
+                "s_nop 1\n\t"
+                "v_min_i32_dpp %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
+                "s_nop 1\n\t"
+                "v_min_i32_dpp %0, %0, %0 row_shr:2 row_mask:0xf bank_mask:0xf\n\t"
+                "s_nop 1\n\t"
+                "v_min_i32_dpp %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xf\n\t"
+                "s_nop 1"
+                : "+v"(m));
+            if ((threadIdx.x & 7u) == 7u && (p0 & ~63u) < nrem) min64[(base >> 6) + (threadIdx.x >> 3)] = m;
+            asm volatile(
+                "v_min_i32_dpp %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xf\n\t"
+                "s_nop 1\n\t"
+                "v_min_i32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+                "s_nop 1\n\t"
+                "v_min_i32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"
+                "s_nop 1"
+                : "+v"(m));
+            if (lane == 63u && wave * 512u < nrem) min512[(base >> 9) + wave] = m;
+        }
+        __syncthreads();  // (the next round zeroes what (d) read)
+    }
+}
+
+// levels 4 and 5 of the min tree over the compact list: the counts come from the device (the grid is laid out for n)
+__global__ __launch_bounds__(256) void build_level_compact(const int32_t *__restrict__ in, int32_t *__restrict__ out, int lev,
+                                                           const msj_tokens_result *__restrict__ result, const msj_tokens_result *__restrict__ prev) {
+    const uint32_t nbrk = bracket_count(result, prev);
+    if (lev >= level_number(nbrk)) return;
+    const uint32_t o = blockIdx.x * 256u + threadIdx.x;
+    const uint32_t n_in = level_entries(nbrk, lev - 1), n_out = level_entries(nbrk, lev);
+    if (o >= n_out) return;
+    int m = kNone;
+    for (uint32_t k = 0; k <= kFanMask; k++) {
+        const uint32_t i = (o << kFanShift) + k;
+        if (i < n_in) m = min(m, in[i]);
+    }
+    out[o] = m;
+}
+// ... and the levels from 6 on in one workgroup, as build_upper_levels
+__global__ __launch_bounds__(1024) void build_upper_levels_compact(const MinTree t, const msj_tokens_result *__restrict__ result,
+                                                                   const msj_tokens_result *__restrict__ prev) {
+    const uint32_t nbrk = bracket_count(result, prev);
+    const int nlev = level_number(nbrk);
+    for (int k = 6; k < nlev; k++) {  // uniform
+        const int32_t *in = t.lv[k - 1];
+        int32_t *out = const_cast<int32_t *>(t.lv[k]);
+        const uint32_t n_in = level_entries(nbrk, k - 1), n_out = level_entries(nbrk, k);
+        for (uint32_t o = threadIdx.x; o < n_out; o += 1024u) {
+            int m = kNone;
+            for (uint32_t j = 0; j <= kFanMask; j++) {
+                const uint32_t i = (o << kFanShift) + j;
+                if (i < n_in) m = min(m, in[i]);
+            }
+            out[o] = m;
+        }
+        __threadfence_block();
+        __syncthreads();
+    }
+}
+
 }  // namespace msj_tokens
 
 // workspace: 4 int32 per block (aggregates) + start depth + start slot in the list of opening
@@ -1083,14 +1504,18 @@ extern "C" void *msj_tokens_doc_aggregates(int32_t *d_ws, uint64_t n) {
 static uint64_t head_words(uint64_t n) {  // ... + the same six words per run of kSuper blocks
     return block_words(n) + ((6 * super_count(n) + 7u) & ~7ull);
 }
+// with_match: 0 = depths only, 1 = + match[] (the min tree over depth[], 64 scratch words, the lists of opening brackets
+// left to the tree -- kept at two words per entry -- and their counters), 2 = + pairs[] (round 5: the brackets of the call
+// as a compact list -- a token word and a depth word each, n of them at most -- the min tree over THAT list's depths, one
+// word per entry of the lists)
+static uint64_t compact_words(uint64_t n) { return (n + 7u) & ~7ull; }
 extern "C" uint64_t msj_tokens_workspace_bytes(uint64_t n, int with_match) {
-    // (matching: the min tree, 64 scratch words, the list of opening brackets left to the tree -- one uint32 per token
-    // at most -- and its counter)
     const uint64_t nb = (n + msj_tokens::kBlock - 1) / msj_tokens::kBlock;
-    // (the lists twice: the pairs form keeps two words per entry)
-    return (head_words(n) + (with_match ? tree_words(n) + 64 + 2 * msj_tokens::kSurvivorShards * msj_tokens::survivor_capacity(nb) +
-                                              (uint64_t)msj_tokens::kSurvivorShards * msj_tokens::kSurvivorStride
-                                        : 0)) * sizeof(int32_t);
+    uint64_t w = head_words(n);
+    if (with_match) w += tree_words(n) + 64 + (uint64_t)msj_tokens::kSurvivorShards * msj_tokens::kSurvivorStride;
+    if (with_match == 1) w += 2 * msj_tokens::kSurvivorShards * msj_tokens::survivor_capacity(nb);
+    if (with_match == 2) w += 2 * compact_words(n) + msj_tokens::kSurvivorShards * msj_tokens::survivor_capacity(nb);
+    return w * sizeof(int32_t);
 }
 
 // scan of the block aggregates (already in d_ws), depth of every token, bracket partners
@@ -1106,9 +1531,14 @@ static int launch_depth_passes(const uint32_t *d_idx, uint64_t n, uint8_t *d_typ
     int32_t *tree = d_ws + head_words(n);  // 32-byte aligned inside the workspace
     uint2 *d_pairs = reinterpret_cast<uint2 *>(o.d_pairs);
     const bool want_match = (d_match != nullptr || d_pairs != nullptr) && n > 0;
-    uint32_t *opens = want_match ? reinterpret_cast<uint32_t *>(tree + tree_words(n) + 64) : nullptr;
-    // ... kSurvivorShards lists (room for two words per entry: the pairs form), then their counters (zeroed by scan_blocks)
-    uint32_t *survivors = want_match ? opens + 2 * kSurvivorShards * survivor_capacity(nb) : nullptr;
+    const bool compact = want_match && d_pairs != nullptr;
+    // the workspace behind the tree (msj_tokens_workspace_bytes): [compact: the bracket list, a token and a depth word
+    // each,] kSurvivorShards lists (match[]: room for two words per entry), then their counters (zeroed by scan_blocks)
+    uint32_t *behind = want_match ? reinterpret_cast<uint32_t *>(tree + tree_words(n) + 64) : nullptr;
+    uint32_t *brk_tok = compact ? behind : nullptr;
+    int32_t *brk_depth = compact ? reinterpret_cast<int32_t *>(behind + compact_words(n)) : nullptr;
+    uint32_t *opens = compact ? behind + 2 * compact_words(n) : behind;
+    uint32_t *survivors = want_match ? opens + (compact ? 1u : 2u) * kSurvivorShards * survivor_capacity(nb) : nullptr;
     const uint32_t nsuper = (uint32_t)super_count(n);
     int32_t *super_agg = d_ws + block_words(n), *super_start = super_agg + 4 * (uint64_t)nsuper;
     uint32_t *super_open = reinterpret_cast<uint32_t *>(super_start + nsuper);
@@ -1116,12 +1546,14 @@ static int launch_depth_passes(const uint32_t *d_idx, uint64_t n, uint8_t *d_typ
     uint32_t *resid = (want_match && !d_pairs) ? o.d_resid : nullptr;
     hipLaunchKernelGGL(scan_blocks, dim3(1), dim3(1024), 0, s, super_agg, nb ? nsuper : 0u, super_start, super_open, d_result, n, o.d_prev,
                        survivors, resid);
-    // levels of the min tree: 1..3 come out of apply_depth, the rest from build_level
+    // levels of the min tree (over depth[]; compact: over the bracket list's depth words, laid out for n brackets, the
+    // counts of a call known on the device only): 1..3 come out of apply_depth / match_compact, the rest from build_level
     MinTree t;
-    t.lv[0] = d_depth;
+    t.lv[0] = compact ? brk_depth : d_depth;
     t.cnt[0] = (uint32_t)n;
     t.nlev = 1;
     int32_t *lvl[kMaxLevels] = {nullptr};
+    for (int k = 1; k < kMaxLevels; k++) t.lv[k] = nullptr, t.cnt[k] = 0;
     if (want_match) {
         int32_t *p = tree;
         while (t.cnt[t.nlev - 1] > 8 && t.nlev < kMaxLevels) {
@@ -1137,17 +1569,33 @@ static int launch_depth_passes(const uint32_t *d_idx, uint64_t n, uint8_t *d_typ
     int32_t *l1 = want_match ? (t.nlev > 1 ? lvl[1] : tree) : nullptr;
     int32_t *l2 = want_match ? (t.nlev > 2 ? lvl[2] : tree + tree_words(n) + 8) : nullptr;
     int32_t *l3 = want_match ? (t.nlev > 3 ? lvl[3] : tree + tree_words(n) + 40) : nullptr;
-    if (nb && want_match && d_pairs)
-        hipLaunchKernelGGL(apply_depth<2>, dim3(nb), dim3(kThreads), 0, s, d_type, n, start, super_start, super_open, d_depth, l1, l2, l3,
-                           open_start, opens, doc_agg, agg, o.d_prev, d_match, survivors, 0u, 0u, d_pairs);
+    int32_t *const no_level = nullptr;
+    uint32_t *const no_brk = nullptr;
+    if (nb && compact)
+        hipLaunchKernelGGL(depth_rows<true>, dim3((nb + kRowsWaves - 1u) / kRowsWaves), dim3(kThreads), 0, s, d_type, n, nb, start, super_start, super_open,
+                           open_start, d_depth, doc_agg, agg, o.d_prev, brk_tok, brk_depth);
     else if (nb && want_match)
         hipLaunchKernelGGL(apply_depth<1>, dim3(nb), dim3(kThreads), 0, s, d_type, n, start, super_start, super_open, d_depth, l1, l2, l3,
-                           open_start, opens, doc_agg, agg, o.d_prev, d_match, survivors, o.match_bias, resid ? 1u : 0u, static_cast<uint2 *>(nullptr));
+                           open_start, opens, doc_agg, agg, o.d_prev, d_match, survivors, o.match_bias, resid ? 1u : 0u, static_cast<uint2 *>(nullptr),
+                           no_brk, no_level);
     else if (nb)
-        hipLaunchKernelGGL(apply_depth<0>, dim3(nb), dim3(kThreads), 0, s, d_type, n, start, super_start, super_open, d_depth, l1, l2, l3,
-                           open_start, opens, doc_agg, agg, o.d_prev, d_match, survivors, 0u, 0u, static_cast<uint2 *>(nullptr));
+        hipLaunchKernelGGL(depth_rows<false>, dim3((nb + kRowsWaves - 1u) / kRowsWaves), dim3(kThreads), 0, s, d_type, n, nb, start, super_start, super_open,
+                           open_start, d_depth, doc_agg, agg, o.d_prev, no_brk, no_level);
     if (nb) hipLaunchKernelGGL(min_max_depth, dim3(nb < kMinMaxGroups * 256u ? (nb + 255u) / 256u : kMinMaxGroups), dim3(256), 0, s, agg, nb, d_result);
-    if (want_match) {
+    const uint32_t lists = nb < kSurvivorShards ? nb : kSurvivorShards;
+    const uint32_t per_list = nb / kSurvivorShards / 8u + 1u;  // ~2 survivors per block, 16 brackets per workgroup and round
+    if (compact) {
+        // the brackets' partners on the compact list: in-block pairs, the tree's levels above (grids laid out for n
+        // brackets, the kernels take the call's count from the result), the containers that span a block of brackets
+        const uint32_t ncb_max = (uint32_t)((n + kCompactBlock - 1) / kCompactBlock);
+        hipLaunchKernelGGL(match_compact, dim3(ncb_max < MSJ_COMPACT_GRID ? ncb_max : MSJ_COMPACT_GRID), dim3(256), 0, s, brk_tok, brk_depth, d_result,
+                           o.d_prev, d_pairs, l1, l2, l3, opens, survivors, survivor_capacity(nb));
+        for (int k = 4; k < t.nlev && k < 6; k++)
+            hipLaunchKernelGGL(build_level_compact, dim3((t.cnt[k] + 255u) / 256u), dim3(256), 0, s, t.lv[k - 1], lvl[k], k, d_result, o.d_prev);
+        if (t.nlev > 6) hipLaunchKernelGGL(build_upper_levels_compact, dim3(1), dim3(1024), 0, s, t, d_result, o.d_prev);
+        hipLaunchKernelGGL(match_brackets<true>, dim3(per_list < MSJ_MATCH_GRID ? per_list : MSJ_MATCH_GRID, lists), dim3(256), 0, s, d_type, opens,
+                           survivors, t, d_match, survivor_capacity(nb), 0u, d_result, resid, d_pairs, brk_tok, o.d_prev);
+    } else if (want_match) {
         for (int k = 4; k < t.nlev && k < 6; k++)
             hipLaunchKernelGGL(build_level, dim3((t.cnt[k] + 255u) / 256u), dim3(256), 0, s, t.lv[k - 1], t.cnt[k - 1], lvl[k], t.cnt[k]);
         if (t.nlev > 6) {
@@ -1165,10 +1613,8 @@ static int launch_depth_passes(const uint32_t *d_idx, uint64_t n, uint8_t *d_typ
         // (the lane groups of 32 workgroups stride over each of the lists)
         // (block b appends to list b mod kSurvivorShards: a short call uses the first nb lists only, and a list then holds
         // the survivors of nb / kSurvivorShards blocks -- the grid follows, instead of 8 192 workgroups for a handful of tokens)
-        const uint32_t lists = nb < kSurvivorShards ? nb : kSurvivorShards;
-        const uint32_t per_list = nb / kSurvivorShards / 8u + 1u;  // ~2 survivors per block, 16 brackets per workgroup and round
-        hipLaunchKernelGGL(match_brackets, dim3(per_list < MSJ_MATCH_GRID ? per_list : MSJ_MATCH_GRID, lists), dim3(256), 0, s, d_type, opens,
-                           survivors, t, d_match, survivor_capacity(nb), o.match_bias, d_result, resid, d_pairs);
+        hipLaunchKernelGGL(match_brackets<false>, dim3(per_list < MSJ_MATCH_GRID ? per_list : MSJ_MATCH_GRID, lists), dim3(256), 0, s, d_type, opens,
+                           survivors, t, d_match, survivor_capacity(nb), o.match_bias, d_result, resid, d_pairs, no_brk, o.d_prev);
         if (resid)  // the closing brackets whose partner lies in front of this call (behind match_brackets: it writes both ends)
             hipLaunchKernelGGL(collect_closers, dim3(per_list < 8u ? per_list : 8u, lists), dim3(256), 0, s, opens, survivors, survivor_capacity(nb),
                                d_depth, d_match, o.d_prev, resid);
@@ -2510,7 +2956,7 @@ int msj_launch_stage2_prep(const uint8_t *d_buf, uint64_t len, const uint32_t *d
     if (nb64 > 0x7FFFFFFFull) return (int)hipErrorInvalidValue;
     const uint32_t nb = (uint32_t)nb64;
     // the fused kernel's aggregates live behind the token pre-pass's own workspace (16-byte aligned)
-    const int wm = d_match != nullptr || o.d_pairs != nullptr;
+    const int wm = o.d_pairs ? 2 : (d_match != nullptr ? 1 : 0);
     int4 *sub = sub_of(d_ws, n, wm);
     if (n && by_tiles(o, n, len)) {
         launch_token_tiles<true, true>(d_buf, len, d_idx, n, d_end, d_flags, d_type, sub, table_of(d_ws, n, wm), d_fix, s, o);
@@ -2586,7 +3032,7 @@ int msj_launch_tokens(const uint8_t *d_buf, uint64_t len, const uint32_t *d_idx,
     const uint64_t nb64 = (n + kBlock - 1) / kBlock;
     if (nb64 > 0x7FFFFFFFull) return (int)hipErrorInvalidValue;
     const uint32_t nb = (uint32_t)nb64;
-    const int wm = d_match != nullptr || o.d_pairs != nullptr;
+    const int wm = o.d_pairs ? 2 : (d_match != nullptr ? 1 : 0);
     int4 *sub = sub_of(d_ws, n, wm);
     if (n && by_tiles(o, n, len)) {
         launch_token_tiles<true, false>(d_buf, len, d_idx, n, nullptr, nullptr, d_type, sub, table_of(d_ws, n, wm), nullptr, s, o);

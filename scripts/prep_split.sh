@@ -1,6 +1,6 @@
 #!/bin/bash
 # per-kernel split of msj_stage2_prep_device with bracket partners (rocprofv3 --kernel-trace --stats), for several builds:
-#   scripts/prep_split.sh <workload> [lib.so ...]     (no lib = the product)
+#   scripts/prep_split.sh <workload> [lib.so ...]     (no lib = the product; PAIRS=1: the compact list instead of match[])
 REPO="$(cd "$(dirname "$0")/.." && pwd)"
 cd /tmp && export TMPDIR=/tmp && cd "$REPO"
 W=${1:-minified}; shift
@@ -8,7 +8,7 @@ for l in "${@:-}"; do
   rm -rf /tmp/prep_kt
   A=""; [ -n "$l" ] && A="--lib $l"
   echo "== ${l:-product} $W"
-  timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prep_kt -- python3 scripts/prep_prof.py $W --match --iters 100 --warm 50 $A > /tmp/prep_kt.log 2>&1 || { tail -5 /tmp/prep_kt.log; exit 1; }
+  timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prep_kt -- python3 scripts/prep_prof.py $W $([ -n "$PAIRS" ] && echo --pairs || echo --match) --iters 100 --warm 50 $A > /tmp/prep_kt.log 2>&1 || { tail -5 /tmp/prep_kt.log; exit 1; }
   grep -v amdgpu /tmp/prep_kt.log | tail -1
   python3 - <<'PY'
 import csv, glob
