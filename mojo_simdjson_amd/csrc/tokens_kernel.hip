@@ -292,7 +292,8 @@ __global__ __launch_bounds__(1024) void scan_blocks(const int32_t *__restrict__ 
     if (resid && threadIdx.x < 4) resid[threadIdx.x] = 0u;  // the counts of this call's residual brackets (match_brackets, collect_closers)
 }
 
-// (3) depth of every token -- and, kMatch, the partner of every bracket whose container closes inside the block:
+// (3) depth of every token AND match[] -- a partner index per token -- for the calls that ask for it (the calls without,
+// and the pairs form, take depth_rows below): the partner of every bracket whose container closes inside the block,
 // the stack of start_container / end_container (generic/stage2/tape_builder.mojo:235-272) as a data-parallel step.
 // The partner of a closing bracket at depth d is the MOST RECENT opening bracket at depth d in front of it (brackets
 // of one depth alternate: between two closing ones the running depth must come back up through an opening one), so
@@ -302,41 +303,31 @@ __global__ __launch_bounds__(1024) void scan_blocks(const int32_t *__restrict__ 
 // (never initialised: one bit per token in s_paired says which of its words hold a partner),
 // which leaves as one coalesced stream (no fill of match[] in front, no scattered writes); opening brackets nobody
 // claimed (their container ends in a later block, or lies outside the levels) go on the survivors' list, which
-// match_brackets resolves through the min tree as before.  1 GiB minified: of 8.6 M containers ... survive.
+// match_brackets resolves through the min tree.
 constexpr int kMatchLevels = 16;
 constexpr int kMatchBelow = 4;
 // kFull: every token of the block exists (all blocks of a call but the last): no guards against n at all -- they were
 // 64-bit compares, eight per loop (round 5: 661 -> ~450 vector instructions per wave together with block-relative
 // 32-bit addressing, the DPP minima and the skipped document counts; profiles/r05/apply_depth_*.txt).
-// kMode: 0 = depths only; 1 = + match[] (a partner index per token: 4 bytes per token out); 2 = + pairs[] (round 5: one
-// {open, close} record per CONTAINER, in the order of the opening brackets -- 8 bytes per container instead of 4 per token:
-// 0.64 instead of 4 bytes per token of the minified workload; what a consumer that walks the tokens in order takes one
-// entry of at every opening bracket, the way start_container pushes and end_container pops,
-// generic/stage2/tape_builder.mojo:235-272)
-template <int kMode>
 struct DepthShared {
-    static constexpr bool kMatch = kMode == 1 || kMode == 2;
-    uint32_t bm[kMatch ? kMatchLevels : 1][kMatch ? kBlock / 32 : 1];  // opening brackets per level, one bit per token
-    unsigned long long bm_words[kMatch ? kMatchLevels : 1];              // ... and which of a level's 64 words are not empty
-    __attribute__((aligned(16))) uint32_t s_match[kMode == 1 ? kBlock : 4];
-    uint32_t s_paired[kMatch ? kBlock / 32 : 1];                         // one bit per token: it has a partner
-    uint16_t s_pre[kMode == 2 ? kThreads : 2];                           // pairs: opening brackets of the block in front of each thread's tokens
-    uint8_t s_om[kMode == 2 ? kThreads : 4];                             // ... and which of the thread's eight tokens are opening brackets
+    uint32_t bm[kMatchLevels][kBlock / 32];               // opening brackets per level, one bit per token
+    unsigned long long bm_words[kMatchLevels];            // ... and which of a level's 64 words are not empty
+    __attribute__((aligned(16))) uint32_t s_match[kBlock];
+    uint32_t s_paired[kBlock / 32];                       // one bit per token: it has a partner
     int wave_sum[kThreads / 64];
     int wave_no[kThreads / 64];
     int wave_rmn[kThreads / 64], wave_rmx[kThreads / 64];
     uint32_t doc_cnt[kThreads / 64], doc_start[kThreads / 64], doc_close[kThreads / 64];
     __attribute__((aligned(16))) int s_out[kThreads / 64][512];          // the depths' way out (1 KiB contiguous per store instruction)
 };
-template <int kMode, bool kFull>
-__device__ __forceinline__ void apply_depth_block(DepthShared<kMode> &sh, const uint8_t *__restrict__ type, const uint32_t nrem /* tokens of this block */,
+template <bool kFull>
+__device__ __forceinline__ void apply_depth_block(DepthShared &sh, const uint8_t *__restrict__ type, const uint32_t nrem /* tokens of this block */,
                                                   const int block_depth0, int32_t *__restrict__ depth_blk, int32_t *__restrict__ min8,
                                                   int32_t *__restrict__ min64, int32_t *__restrict__ min512, uint32_t *__restrict__ opens,
                                                   uint4 *__restrict__ doc_agg, int32_t *__restrict__ block_mm,
                                                   uint32_t *__restrict__ match_blk, uint32_t *__restrict__ survivors, const uint32_t match_bias,
-                                                  const uint32_t want_closers, uint2 *__restrict__ pairs_blk, const uint32_t open_base,
-                                                  uint32_t *__restrict__ brk_tok, int32_t *__restrict__ brk_depth, const uint32_t brk_base) {
-    constexpr bool kMatch = kMode == 1 || kMode == 2;
+                                                  const uint32_t want_closers) {
+    constexpr bool kMatch = true;
     // (the LDS lives in the kernel: two instantiations of this function must not own two copies of it)
     auto &bm = sh.bm;
     auto &bm_words = sh.bm_words;
@@ -401,63 +392,8 @@ __device__ __forceinline__ void apply_depth_block(DepthShared<kMode> &sh, const 
             rmx = max(rmx, before);
         }
     }
-    if (kMode == 3) {
-        // Round 5, the pairs form: the call's BRACKETS leave as a compact list in token order -- {token | closing << 31,
-        // depth} each, 8 % of the minified workload's tokens -- and match_compact pairs them there: a block of 2 048
-        // brackets spans ~25 000 tokens, the bitmaps and look-ups are paid per bracket instead of per token, and this
-        // kernel stays the depths-only pass.  A bracket's slot needs no scan of its own: in front of any token
-        // opening + closing brackets = its slot and opening - closing = the running depth, both of which the thread has
-        // (slot = 2 x opening brackets in front - running depth relative to the call's start).
-        uint32_t om = 0, cm = 0;
-#pragma unroll
-        for (int k = 0; k < kPer; k++) {
-            om |= d[k] > 0 ? 1u << k : 0u;
-            cm |= d[k] < 0 ? 1u << k : 0u;
-        }
-        if (!kFull) om &= vm, cm &= vm;
-        const int before0 = out[0] + (d[0] < 0 ? 1 : 0);  // the running depth in front of this thread's first token
-        uint32_t excl_no = (uint32_t)(incl_no - no);
-        for (int w = 0; w < wave; w++) excl_no += (uint32_t)wave_no[w];
-        const uint32_t slot0 = 2u * excl_no - (uint32_t)(before0 - block_depth0);  // the thread's first bracket among the block's
-        // The entries leave through the wave's staging slice (free until the depths go out): a thread's brackets are few
-        // and scattered, and a store instruction per round of every thread's next bracket costs the same 64 address slots
-        // as a full one (measured: 298 us for this kernel that way, against 175 for the depths alone).  One word per bracket
-        // in LDS -- token inside the wave | closing << 9 | depth relative to the block's start << 10 -- then lane j takes
-        // the wave's j-th bracket: one round of two coalesced stores for up to 64 brackets.
-        const uint32_t nbk = (uint32_t)__builtin_popcount(om | cm);
-        const uint32_t incl_nb = wave_incl_sum(nbk);
-        const uint32_t n_w = (uint32_t)__builtin_amdgcn_readlane((int)incl_nb, 63);  // brackets of the wave
-        uint32_t *const blist = reinterpret_cast<uint32_t *>(&s_out[wave][0]);       // 512 entries
-        uint32_t ws = incl_nb - nbk;
-        for (uint32_t rem = om | cm; __ballot(rem != 0u) != 0ull;) {  // uniform: max over the lanes of their brackets (2 - 4)
-            if (rem != 0u) {
-                const uint32_t k = (uint32_t)__builtin_ctz(rem), below = (1u << k) - 1u;
-                rem &= rem - 1u;
-                const uint32_t closes = (cm >> k) & 1u;
-                // an opening bracket sits at the running depth in front of it, a closing one at the depth of its container
-                const int rel = before0 - block_depth0 + (int)__builtin_popcount(om & below) - (int)__builtin_popcount(cm & below) - (int)closes;
-                blist[ws++] = (8u * (uint32_t)lane + k) | (closes << 9) | ((uint32_t)rel << 10);
-            }
-        }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        // the wave's first bracket: the slot of lane 0's first one
-        const uint32_t g_w = brk_base + (uint32_t)__builtin_amdgcn_readfirstlane((int)slot0);
-        for (uint32_t j0 = 0; j0 < n_w; j0 += 64u) {  // uniform
-            const uint32_t j = j0 + (uint32_t)lane;
-            if (j < n_w) {
-                const uint32_t e = blist[j];
-                brk_tok[g_w + j] = (blk0 + (uint32_t)wave * 512u + (e & 511u)) | ((e >> 9) << 31);
-                brk_depth[g_w + j] = block_depth0 + ((int)e >> 10);
-            }
-        }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();  // (the depths are staged in the same slice below)
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    }
     bool surv_any = false;
-    uint32_t surv_incl = 0, surv_slot = 0, surv_mine = 0, surv_mask = 0, cand_mask = 0, surv_rank0 = 0, surv_om = 0;
+    uint32_t surv_incl = 0, surv_slot = 0, surv_mine = 0, surv_mask = 0, cand_mask = 0;
     if (kMatch) {
         const int level0 = block_depth0 - kMatchBelow;
         // (a) the opening brackets' bits (the zeroing above is behind the barrier that published wave_sum).  Brackets are
@@ -472,14 +408,6 @@ __device__ __forceinline__ void apply_depth_block(DepthShared<kMode> &sh, const 
         }
         if (!kFull) om &= vm, cm &= vm;  // (a blank stands in for a token that does not exist: no bracket anyway)
         const int before0 = out[0] + (d[0] < 0 ? 1 : 0);  // the running depth in front of this thread's first token
-        uint32_t excl_no = 0;  // pairs: opening brackets of the block in front of this thread's tokens = their rank
-        if (kMode == 2) {
-            excl_no = (uint32_t)(incl_no - no);
-            for (int w = 0; w < wave; w++) excl_no += (uint32_t)wave_no[w];
-            sh.s_pre[threadIdx.x] = (uint16_t)excl_no;
-            sh.s_om[threadIdx.x] = (uint8_t)om;  // (visible behind the barrier between (a) and (c))
-        }
-#ifndef MSJ_MATCH_PER_THREAD
         // Round 5: the wave's brackets are COMPACTED first.  A thread holds 0 .. 8 of them (4 % of the minified workload's
         // tokens open a container, 4 % close one: ~40 per wave of 512 tokens), and a loop in which every thread walks its
         // own runs max-over-lanes rounds of the whole body -- 2 to 3 of the 22-instruction insertion and of the
@@ -545,16 +473,9 @@ __device__ __forceinline__ void apply_depth_block(DepthShared<kMode> &sh, const 
                     }
                     if (m != 0u) {
                         const uint32_t i = 32u * wi + 31u - (uint32_t)__clz((int)m);
-                        if (kMode == 1) {
-                            const uint32_t b0 = blk0 + match_bias;  // + the call's place in the shard (msj_stage2_prep_segments)
-                            s_match[t] = b0 + i;
-                            s_match[i] = b0 + t;
-                        } else {
-                            // the container's record: at the opening bracket's rank among the call's opening brackets
-                            const uint32_t ti = i >> 3;
-                            const uint32_t r = (uint32_t)sh.s_pre[ti] + (uint32_t)__builtin_popcount((uint32_t)sh.s_om[ti] & ((1u << (i & 7u)) - 1u));
-                            pairs_blk[r] = make_uint2(blk0 + i, blk0 + t);
-                        }
+                        const uint32_t b0 = blk0 + match_bias;  // + the call's place in the shard (msj_stage2_prep_segments)
+                        s_match[t] = b0 + i;
+                        s_match[i] = b0 + t;
                         atomicOr(&s_paired[w], 1u << (t & 31u));
                         atomicOr(&s_paired[wi], 1u << (i & 31u));
                     }
@@ -562,66 +483,10 @@ __device__ __forceinline__ void apply_depth_block(DepthShared<kMode> &sh, const 
             }
         }
         __syncthreads();
-#else   // the form of round 4 (kept for the A/B): every thread walks the set bits of its own bracket masks
-        for (uint32_t rem = om; __ballot(rem != 0u) != 0ull;) {  // uniform
-            if (rem != 0u) {
-                const uint32_t k = (uint32_t)__builtin_ctz(rem), below = (1u << k) - 1u;
-                rem &= rem - 1u;
-                const uint32_t lv = (uint32_t)(before0 + (int)__builtin_popcount(om & below) - (int)__builtin_popcount(cm & below) - level0);
-                if (lv < (uint32_t)kMatchLevels) {
-                    atomicOr(&bm[lv][(t0 + k) >> 5], 1u << ((t0 + k) & 31u));
-                    atomicOr(&bm_words[lv], 1ull << ((t0 + k) >> 5));  // (b) ... and the level's words that hold a bit
-                }
-            }
-        }
-        __syncthreads();
-        // (c) every closing bracket looks for the most recent opening one of its level
-        for (uint32_t rem = cm; __ballot(rem != 0u) != 0ull;) {  // uniform
-            if (rem != 0u) {
-                const uint32_t k = (uint32_t)__builtin_ctz(rem), below = (1u << k) - 1u;
-                rem &= rem - 1u;
-                // a closing bracket sits at the depth of its container: one below the running depth in front of it
-                const uint32_t lv = (uint32_t)(before0 + (int)__builtin_popcount(om & below) - (int)__builtin_popcount(cm & below) - 1 - level0);
-                // a closing bracket BELOW the depth at the block's start: if nothing in the block pairs with it, its partner
-                // is in an earlier block -- or in front of this CALL (the residuals of msj_stage2_prep_segments)
-                if ((int)lv < kMatchBelow) cand_mask |= 1u << k;
-                if (lv < (uint32_t)kMatchLevels) {
-                    const uint32_t t = t0 + k, w = t >> 5;
-                    uint32_t m = bm[lv][w] & ((1u << (t & 31u)) - 1u);
-                    uint32_t wi = w;
-                    if (m == 0u) {
-                        const uint64_t nz = bm_words[lv] & ((1ull << w) - 1ull);
-                        if (nz != 0ull) {
-                            wi = 63u - (uint32_t)__clzll((long long)nz);
-                            m = bm[lv][wi];
-                        }
-                    }
-                    if (m != 0u) {
-                        const uint32_t i = 32u * wi + 31u - (uint32_t)__clz((int)m);
-                        if (kMode == 1) {
-                            const uint32_t b0 = blk0 + match_bias;  // + the call's place in the shard (msj_stage2_prep_segments)
-                            s_match[t] = b0 + i;
-                            s_match[i] = b0 + t;
-                        } else {
-                            // the container's record: at the opening bracket's rank among the call's opening brackets
-                            const uint32_t ti = i >> 3;
-                            const uint32_t r = (uint32_t)sh.s_pre[ti] + (uint32_t)__builtin_popcount((uint32_t)sh.s_om[ti] & ((1u << (i & 7u)) - 1u));
-                            pairs_blk[r] = make_uint2(blk0 + i, blk0 + t);
-                        }
-                        atomicOr(&s_paired[w], 1u << (t & 31u));
-                        atomicOr(&s_paired[wi], 1u << (i & 31u));
-                    }
-                }
-            }
-        }
-        __syncthreads();
-#endif
         // (d) the opening brackets nobody claimed: to the list match_brackets works through (any order)
         // (the thread's eight tokens are one byte of a word of s_paired)
         const uint32_t paired8 = s_paired[t0 >> 5] >> (t0 & 31u);
         surv_mask = om & ~paired8;
-        surv_rank0 = excl_no;
-        surv_om = om;
         // ... and (a shard call only) the closing brackets below the block's start depth that nothing in the block paired:
         // bits 8..15, listed with bit 31 set; match_brackets skips them, collect_closers keeps those still unpaired
         if (want_closers) surv_mask |= (cand_mask & ~paired8 & 0xFFu) << 8;
@@ -636,9 +501,7 @@ __device__ __forceinline__ void apply_depth_block(DepthShared<kMode> &sh, const 
         surv_mine = mine;
         // (e) the block's slice of match[]: 1 KiB contiguous per store instruction, like the depths below
         const uint32_t wb = (uint32_t)wave * 512u;
-        if (kMode != 1) {
-            // pairs: nothing per token
-        } else if (kFull || wb + 512u <= nrem) {  // uniform per wave
+        if (kFull || wb + 512u <= nrem) {  // uniform per wave
             typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
             // tokens 4 lane .. 4 lane + 3 of the wave's first and second half: a nibble of s_paired each
             const uint32_t q0 = wb + 4u * lane, q1 = q0 + 256u;
@@ -770,20 +633,10 @@ __device__ __forceinline__ void apply_depth_block(DepthShared<kMode> &sh, const 
         const uint32_t shard = blockIdx.x % kSurvivorShards;
         uint32_t *list = opens + (uint64_t)shard * survivor_capacity(gridDim.x);
         uint32_t slot = (uint32_t)__builtin_amdgcn_readlane((int)surv_slot, 63) + surv_incl - surv_mine;
-        if (kMode == 2) {  // two words per entry: the token and its rank among the call's opening brackets (the record's place)
-            list += (uint64_t)shard * survivor_capacity(gridDim.x);  // (the lists are twice as long)
-#pragma unroll
-            for (int k = 0; k < kPer; k++)
-                if ((surv_mask >> k) & 1u) {
-                    list[2u * slot] = blk0 + t0 + (uint32_t)k;
-                    list[2u * slot + 1u] = open_base + surv_rank0 + (uint32_t)__builtin_popcount(surv_om & ((1u << k) - 1u));
-                    slot++;
-                }
-        } else
 #pragma unroll
         for (int k = 0; k < kPer; k++)
             if ((surv_mask >> k) & 1u) list[slot++] = blk0 + t0 + (uint32_t)k;
-        if (kMode != 2 && (surv_mask >> 8)) {
+        if (surv_mask >> 8) {
 #pragma unroll
             for (int k = 0; k < kPer; k++)
                 if ((surv_mask >> (8 + k)) & 1u) list[slot++] = (blk0 + t0 + (uint32_t)k) | 0x80000000u;
@@ -791,19 +644,13 @@ __device__ __forceinline__ void apply_depth_block(DepthShared<kMode> &sh, const 
     }
 }
 
-template <int kMode>
 __global__ __launch_bounds__(kThreads) void apply_depth(const uint8_t *__restrict__ type, uint64_t n,
                                                         const int32_t *__restrict__ block_start, const int32_t *__restrict__ super_start,
-                                                        const uint32_t *__restrict__ super_open, int32_t *__restrict__ depth,
-                                                        int32_t *__restrict__ min8, int32_t *__restrict__ min64,
-                                                        int32_t *__restrict__ min512, const uint32_t *__restrict__ open_start,
-                                                        uint32_t *__restrict__ opens, uint4 *__restrict__ doc_agg,
+                                                        int32_t *__restrict__ depth, int32_t *__restrict__ min8, int32_t *__restrict__ min64,
+                                                        int32_t *__restrict__ min512, uint32_t *__restrict__ opens, uint4 *__restrict__ doc_agg,
                                                         int32_t *__restrict__ block_mm, const msj_tokens_result *__restrict__ prev,
                                                         uint32_t *__restrict__ match, uint32_t *__restrict__ survivors, uint32_t match_bias,
-                                                        uint32_t want_closers, uint2 *__restrict__ pairs, uint32_t *__restrict__ brk_tok,
-                                                        int32_t *__restrict__ brk_depth) {
-    // pairs: the number of opening brackets of the call in front of this block = where its containers' records start
-    const uint32_t open_base = kMode >= 2 ? super_open[blockIdx.x / kSuper] + open_start[blockIdx.x] : 0u;
+                                                        uint32_t want_closers) {
     // everything the block touches, as uniform (scalar) base pointers: the lanes add 32-bit offsets inside the block
     const uint64_t b0 = (uint64_t)blockIdx.x * kBlock;
     // tokens of this block: n < 2^31 (the entry points check), so 32-bit arithmetic and ONE s_min_u32.  (Written as a
@@ -812,18 +659,14 @@ __global__ __launch_bounds__(kThreads) void apply_depth(const uint8_t *__restric
     // behind the stream's end into the minimum / maximum depth: found by test_stage2_prep_1gib_replicated.)
     const uint32_t nrem = min((uint32_t)n - blockIdx.x * kBlock, kBlock);
     const int block_depth0 = (prev ? prev->final_depth : 0) + super_start[blockIdx.x / kSuper] + block_start[blockIdx.x];  // uniform
-    int32_t *m8 = min8 ? min8 + (b0 >> 3) : nullptr, *m64 = min8 ? min64 + (b0 >> 6) : nullptr, *m512 = min8 ? min512 + (b0 >> 9) : nullptr;
-    // (compact list) the brackets of the call in front of this block: 2 x the opening ones - the depth they leave behind
-    const uint32_t brk_base = kMode == 3 ? 2u * open_base - (uint32_t)(super_start[blockIdx.x / kSuper] + block_start[blockIdx.x]) : 0u;
-    __shared__ DepthShared<kMode> sh;
+    int32_t *m8 = min8 + (b0 >> 3), *m64 = min64 + (b0 >> 6), *m512 = min512 + (b0 >> 9);
+    __shared__ DepthShared sh;
     if (nrem == kBlock)
-        apply_depth_block<kMode, true>(sh, type + b0, nrem, block_depth0, depth + b0, m8, m64, m512, opens, doc_agg, block_mm,
-                                       kMode == 1 ? match + b0 : nullptr, survivors, match_bias, want_closers,
-                                       kMode == 2 ? pairs + open_base : nullptr, open_base, brk_tok, brk_depth, brk_base);
+        apply_depth_block<true>(sh, type + b0, nrem, block_depth0, depth + b0, m8, m64, m512, opens, doc_agg, block_mm, match + b0, survivors,
+                                match_bias, want_closers);
     else
-        apply_depth_block<kMode, false>(sh, type + b0, nrem, block_depth0, depth + b0, m8, m64, m512, opens, doc_agg, block_mm,
-                                        kMode == 1 ? match + b0 : nullptr, survivors, match_bias, want_closers,
-                                        kMode == 2 ? pairs + open_base : nullptr, open_base, brk_tok, brk_depth, brk_base);
+        apply_depth_block<false>(sh, type + b0, nrem, block_depth0, depth + b0, m8, m64, m512, opens, doc_agg, block_mm, match + b0, survivors,
+                                 match_bias, want_closers);
 }
 
 // (3b) the same pass ORGANISED BY ROWS (round 5) for the calls without match[]: 64 tokens a row, lane l of row r holding
@@ -1120,17 +963,15 @@ __global__ __launch_bounds__(256) void match_brackets(const uint8_t *__restrict_
     const uint32_t n = kCompact ? bracket_count(result, prev) : t.cnt[0];
     const int nlev = kCompact ? level_number(n) : t.nlev;
     const auto count_of = [&](int lev) -> uint32_t { return kCompact ? level_entries(n, lev) : t.cnt[lev]; };
-    const bool two_words = !kCompact && pairs;  // (the in-block pairs form: token and rank per entry, the lists twice as long)
     // one list per blockIdx.y (kSurvivorShards of them), the lane groups of its workgroups stride over it
     const uint32_t total = n_opens[blockIdx.y * kSurvivorStride];
-    opens += (uint64_t)blockIdx.y * list_capacity * (two_words ? 2u : 1u);
+    opens += (uint64_t)blockIdx.y * list_capacity;
     const uint32_t lane = threadIdx.x & 63u, sub = lane & (kGroup - 1u), grp = lane / kGroup;
     constexpr uint32_t per_wave = 64u / kGroup;
     const uint64_t wave0 = ((uint64_t)blockIdx.x * 4u + (threadIdx.x >> 6)) * per_wave, stride = (uint64_t)gridDim.x * 4u * per_wave;
     for (uint64_t w0 = wave0; w0 < total; w0 += stride) {  // uniform per wave
         const uint64_t w = w0 + grp;
-        const uint32_t entry = w < total ? opens[two_words ? 2u * w : w] : 0x80000000u;
-        const uint32_t rank = (two_words && w < total) ? opens[2u * w + 1u] : 0u;
+        const uint32_t entry = w < total ? opens[w] : 0x80000000u;
         const bool have = (entry >> 31) == 0u;  // (bit 31: a closing bracket listed for collect_closers)
         const uint32_t i = have ? entry : 0u;
         const int target = have ? t.lv[0][i] : kNone;
@@ -1212,14 +1053,10 @@ __global__ __launch_bounds__(256) void match_brackets(const uint8_t *__restrict_
             }
         } else if (have && found && sub == 0u) {
             const uint32_t cj = type[pos];
-            if (pairs) {
-                pairs[rank] = make_uint2(i, (cj == '}' || cj == ']') ? pos : 0xFFFFFFFFu);
-            } else if (cj == '}' || cj == ']') {
+            if (cj == '}' || cj == ']') {
                 match[i] = pos + match_bias;
                 match[pos] = i + match_bias;
             }
-        } else if (have && sub == 0u && pairs) {
-            pairs[rank] = make_uint2(i, 0xFFFFFFFFu);  // never closed inside this call
         } else if (have && sub == 0u && resid) {
             // never closed inside this call: the unclosed opening brackets nest, so the one at depth `target` is entry
             // final_depth - 1 - target of the call's residual list (msj_stage2_prep_segments stitches the segments)
@@ -1505,16 +1342,15 @@ static uint64_t head_words(uint64_t n) {  // ... + the same six words per run of
     return block_words(n) + ((6 * super_count(n) + 7u) & ~7ull);
 }
 // with_match: 0 = depths only, 1 = + match[] (the min tree over depth[], 64 scratch words, the lists of opening brackets
-// left to the tree -- kept at two words per entry -- and their counters), 2 = + pairs[] (round 5: the brackets of the call
-// as a compact list -- a token word and a depth word each, n of them at most -- the min tree over THAT list's depths, one
-// word per entry of the lists)
+// left to the tree and their counters), 2 = + pairs[] (round 5: the same over the call's brackets as a compact list -- a
+// token word and a depth word each, n of them at most -- which comes on top)
 static uint64_t compact_words(uint64_t n) { return (n + 7u) & ~7ull; }
 extern "C" uint64_t msj_tokens_workspace_bytes(uint64_t n, int with_match) {
     const uint64_t nb = (n + msj_tokens::kBlock - 1) / msj_tokens::kBlock;
     uint64_t w = head_words(n);
     if (with_match) w += tree_words(n) + 64 + (uint64_t)msj_tokens::kSurvivorShards * msj_tokens::kSurvivorStride;
-    if (with_match == 1) w += 2 * msj_tokens::kSurvivorShards * msj_tokens::survivor_capacity(nb);
-    if (with_match == 2) w += 2 * compact_words(n) + msj_tokens::kSurvivorShards * msj_tokens::survivor_capacity(nb);
+    if (with_match) w += msj_tokens::kSurvivorShards * msj_tokens::survivor_capacity(nb);
+    if (with_match == 2) w += 2 * compact_words(n);
     return w * sizeof(int32_t);
 }
 
@@ -1533,12 +1369,12 @@ static int launch_depth_passes(const uint32_t *d_idx, uint64_t n, uint8_t *d_typ
     const bool want_match = (d_match != nullptr || d_pairs != nullptr) && n > 0;
     const bool compact = want_match && d_pairs != nullptr;
     // the workspace behind the tree (msj_tokens_workspace_bytes): [compact: the bracket list, a token and a depth word
-    // each,] kSurvivorShards lists (match[]: room for two words per entry), then their counters (zeroed by scan_blocks)
+    // each,] kSurvivorShards lists, then their counters (zeroed by scan_blocks)
     uint32_t *behind = want_match ? reinterpret_cast<uint32_t *>(tree + tree_words(n) + 64) : nullptr;
     uint32_t *brk_tok = compact ? behind : nullptr;
     int32_t *brk_depth = compact ? reinterpret_cast<int32_t *>(behind + compact_words(n)) : nullptr;
     uint32_t *opens = compact ? behind + 2 * compact_words(n) : behind;
-    uint32_t *survivors = want_match ? opens + (compact ? 1u : 2u) * kSurvivorShards * survivor_capacity(nb) : nullptr;
+    uint32_t *survivors = want_match ? opens + kSurvivorShards * survivor_capacity(nb) : nullptr;
     const uint32_t nsuper = (uint32_t)super_count(n);
     int32_t *super_agg = d_ws + block_words(n), *super_start = super_agg + 4 * (uint64_t)nsuper;
     uint32_t *super_open = reinterpret_cast<uint32_t *>(super_start + nsuper);
@@ -1575,9 +1411,8 @@ static int launch_depth_passes(const uint32_t *d_idx, uint64_t n, uint8_t *d_typ
         hipLaunchKernelGGL(depth_rows<true>, dim3((nb + kRowsWaves - 1u) / kRowsWaves), dim3(kThreads), 0, s, d_type, n, nb, start, super_start, super_open,
                            open_start, d_depth, doc_agg, agg, o.d_prev, brk_tok, brk_depth);
     else if (nb && want_match)
-        hipLaunchKernelGGL(apply_depth<1>, dim3(nb), dim3(kThreads), 0, s, d_type, n, start, super_start, super_open, d_depth, l1, l2, l3,
-                           open_start, opens, doc_agg, agg, o.d_prev, d_match, survivors, o.match_bias, resid ? 1u : 0u, static_cast<uint2 *>(nullptr),
-                           no_brk, no_level);
+        hipLaunchKernelGGL(apply_depth, dim3(nb), dim3(kThreads), 0, s, d_type, n, start, super_start, d_depth, l1, l2, l3, opens, doc_agg, agg, o.d_prev,
+                           d_match, survivors, o.match_bias, resid ? 1u : 0u);
     else if (nb)
         hipLaunchKernelGGL(depth_rows<false>, dim3((nb + kRowsWaves - 1u) / kRowsWaves), dim3(kThreads), 0, s, d_type, n, nb, start, super_start, super_open,
                            open_start, d_depth, doc_agg, agg, o.d_prev, no_brk, no_level);

@@ -2,7 +2,7 @@
 """Randomised parity stress of the f rows on the GPU box (not part of pytest: runs for minutes).
 
 Byte soups (tests/stress.py's alphabets plus number- and string-heavy ones) through stage 1, then
-msj_stage2_prep_device with bracket matching, msj_tokens_device and msj_token_spans_device, each compared with
+msj_stage2_prep_device with bracket matching, the pairs form, msj_tokens_device and msj_token_spans_device, each compared with
 the definitions in oracle/tokens_oracle.c token by token: type, depth, final / min / max depth, partner, span end,
 span flags; every fourth case also in two or three chained pieces (the depth carried from call to call).  Every third case runs with a lowered MSJ_SPANS_LDS_LIMIT-like stretch length (long strings) so that the
 per-token path from global memory is taken too.
@@ -31,6 +31,7 @@ EXTRA = [
 def main():
     import torch
 
+    from mojo_simdjson_amd import _lib
     from mojo_simdjson_amd.device import Stage1Device
 
     budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
@@ -67,6 +68,17 @@ def main():
             bad = int(np.argmax((got_f != wf) | (got_e != we)))
             raise AssertionError(f"{tag}: token {bad} at {idx[bad]}: end {got_e[bad]} / flags {got_f[bad]} != {we[bad]} / {wf[bad]}: "
                                  f"{data[idx[bad]:idx[bad] + 40]!r}")
+        # the pairs form (round 5): one {open, close} record per container = the definition's match[] read at the opening
+        # brackets, through the fused call and through msj_tokens_pairs_device in turn
+        opens = np.nonzero((wt == ord("{")) | (wt == ord("[")))[0]
+        wm = helpers.oracle_match(wt)
+        tp_, dp_, pr, _, _, d_tr = dev.stage2_prep_pairs(d_buf, n, d_idx, k, spans=cases % 2 == 0)
+        rr = _lib.MsjTokensResult.from_buffer_copy(d_tr.cpu().numpy().tobytes())
+        assert rr.reserved == len(opens) and (rr.final_depth, rr.min_depth, rr.max_depth) == ((final, mn, mx) if k else (rr.final_depth, rr.min_depth, rr.max_depth)), tag + ": pairs result"
+        got_p = pr[:len(opens)].cpu().numpy().view(np.uint32)
+        want_p = np.stack([opens.astype(np.uint32), wm[opens]], axis=1) if len(opens) else np.zeros((0, 2), dtype=np.uint32)
+        assert np.array_equal(got_p, want_p), tag + ": pairs"
+        assert np.array_equal(tp_.cpu().numpy(), wt) and np.array_equal(dp_.cpu().numpy(), wd), tag + ": pairs call type / depth"
         t2, d2, res2 = dev.tokens(d_buf, n, d_idx, k)[:3]
         assert np.array_equal(t2.cpu().numpy(), wt) and np.array_equal(d2.cpu().numpy(), wd), tag + ": msj_tokens_device"
         e2, f2 = dev.token_spans(d_buf, n, d_idx, k)
@@ -84,9 +96,14 @@ def main():
                     tp, dp, _, mp = dev.tokens(d_buf, n, d_idx[a:], b - a, match=True, d_result=buf, sync=False, d_prev=prev)
                 assert np.array_equal(tp.cpu().numpy(), wt[a:b]) and np.array_equal(dp.cpu().numpy(), wd[a:b]), f"{tag}: chained [{a}, {b})"
                 assert np.array_equal(mp.cpu().numpy().view(np.uint32), helpers.oracle_match(wt[a:b])), f"{tag}: chained partners [{a}, {b})"
+                # ... and as the pairs form: the piece's own containers, the depth carried
+                _, dq, pq, _, _, bq = dev.stage2_prep_pairs(d_buf, n, d_idx[a:], b - a, spans=False, d_prev=prev)
+                op = np.nonzero((wt[a:b] == ord("{")) | (wt[a:b] == ord("[")))[0]
+                wmp = helpers.oracle_match(wt[a:b])
+                wantq = np.stack([op.astype(np.uint32), wmp[op]], axis=1) if len(op) else np.zeros((0, 2), dtype=np.uint32)
+                assert np.array_equal(pq[:len(op)].cpu().numpy().view(np.uint32), wantq), f"{tag}: chained pairs [{a}, {b})"
+                assert np.array_equal(dq.cpu().numpy(), wd[a:b]), f"{tag}: chained pairs depth [{a}, {b})"
                 prev = buf
-            from mojo_simdjson_amd import _lib
-
             r = _lib.MsjTokensResult.from_buffer_copy(prev.cpu().numpy().tobytes())
             assert (r.final_depth, r.min_depth, r.max_depth) == (final, mn, mx), f"{tag}: chained result {cuts}"
         cases += 1
