@@ -934,7 +934,10 @@ __device__ __forceinline__ uint32_t first_le(const int v[8], uint32_t from, int 
 #ifndef MSJ_COMPACT_GRID
 #define MSJ_COMPACT_GRID 4096  // workgroups of match_compact at most (each strides over the blocks of 2 048 brackets)
 #endif
-constexpr uint32_t kLinear = MSJ_MATCH_LINEAR, kGroup = 8, kSteps = 8;  // 64 tokens per group and round
+#ifndef MSJ_MATCH_LINEAR_COMPACT
+#define MSJ_MATCH_LINEAR_COMPACT 64  // on the compact list: one round (the partners of the brackets a block of 2 048 brackets left over are mostly further away: 30.0 us against 33.9 with four rounds, 57 with none)
+#endif
+constexpr uint32_t kLinear = MSJ_MATCH_LINEAR, kLinearCompact = MSJ_MATCH_LINEAR_COMPACT, kGroup = 8, kSteps = 8;  // 64 tokens per group and round
 // kCompact (round 5, the pairs form): the same walk over the COMPACT list of the call's brackets -- t_in.lv[0] is that
 // list's depth word per bracket, brk_tok its token word (bit 31: a closing bracket), an entry of the lists the bracket's
 // place in the compact list, and the number of brackets -- hence every level's count -- is only known on the device:
@@ -980,7 +983,7 @@ __global__ __launch_bounds__(256) void match_brackets(const uint8_t *__restrict_
         // What bounds this kernel is the LONGEST dependent chain of loads of any one bracket (the root array of a 64 MiB
         // document: 84 us, whatever the grid), so loads whose addresses do not depend on loaded data go out together:
         // four steps of the linear scan per round, and every level of the climb at once.
-        for (uint32_t round = 0; round < kLinear / (kSteps * kGroup); round++) {  // uniform
+        for (uint32_t round = 0; round < (kCompact ? kLinearCompact : kLinear) / (kSteps * kGroup); round++) {  // uniform
             int v4[kSteps];
 #pragma unroll
             for (uint32_t q = 0; q < kSteps; q++) {
@@ -1138,7 +1141,9 @@ __global__ __launch_bounds__(256) void stitch_partners(const msj_stitch_args a, 
 // the fact that the brackets of one level alternate -- a closing bracket's partner is the level's bracket in front of it:
 // the next lower bit of the level's ballot, or the one carried from the rows before in lane `level` of a register; no LDS,
 // no barrier -- is bit-exact and costs a loop over the levels present in every row: ~8 000 instructions per block against
-// 2 400 here, 183 us per GiB minified against 81.)
+// 2 400 here, 183 us per GiB minified against 81; a wave per 2 048 brackets WITH these bitmaps, kept per piece of 512 in the
+// wave's own LDS, the level's last opening bracket carried from piece to piece: 117 - 128 us -- 8 400 waves of ~60 us each
+// do not fill the chip, and the wait for a piece's words is a wait for the stores of the piece in front.)
 constexpr uint32_t kCompactBlock = 2048;
 __global__ __launch_bounds__(256) void match_compact(const uint32_t *__restrict__ brk_tok, const int32_t *__restrict__ brk_depth,
                                                      const msj_tokens_result *__restrict__ result, const msj_tokens_result *__restrict__ prev,
