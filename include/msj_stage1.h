@@ -480,6 +480,9 @@ int32_t msj_token_spans_device(msj_ctx *ctx, const uint8_t *d_buf, uint64_t len,
  * the consumer that walks the tokens in order and takes one record at every opening bracket, the way the reference's
  * stage 2 pushes in start_container and pops in end_container (generic/stage2/tape_builder.mojo:235-272).  Same arguments
  * and results otherwise as msj_tokens_chain_device / msj_stage2_prep_chain_device without d_match; d_pairs 8-byte aligned.
+ * The faster of the two partner forms (1 GiB minified: 1.00 ms per call against 1.17 with d_match): the call keeps the
+ * brackets of its tokens as a compact list in the context's workspace (8 more bytes per token of capacity) and pairs them
+ * there.
  */
 typedef struct msj_bracket_pair {
     uint32_t open, close;

@@ -6,6 +6,7 @@ timeout -k 10 120 python tests/stress_documents.py 30 305 > $out/stress_document
 for w in minified utf8 pretty4; do
   python scripts/prep_prof.py $w 2>&1 | grep -v amdgpu | tail -1 | tee -a $out/rates.txt
   python scripts/prep_prof.py $w --match 2>&1 | grep -v amdgpu | tail -1 | tee -a $out/rates.txt
+  python scripts/prep_prof.py $w --pairs 2>&1 | grep -v amdgpu | tail -1 | tee -a $out/rates.txt
 done
-MATCH=1 bash scripts/prep_ab.sh libs minified ${2:-scripts/ab/r5_tokens_before.so} 2>&1 | grep -v amdgpu | tee $out/ab_match.txt
-bash scripts/prep_split.sh minified "" 2>&1 | grep -E "^==|msj_tokens" | tee $out/split.txt
+[ -n "$2" ] && MATCH=1 bash scripts/prep_ab.sh libs minified $2 2>&1 | grep -v amdgpu | tee $out/ab_match.txt
+(bash scripts/split_any.sh "minified --match"; bash scripts/split_any.sh "minified --pairs") 2>&1 | grep -E "^==|msj_tokens" | tee $out/split.txt
