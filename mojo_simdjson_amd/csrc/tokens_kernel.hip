@@ -287,7 +287,7 @@ __global__ __launch_bounds__(1024) void scan_blocks(const int32_t *__restrict__ 
         result->max_depth = none ? 0 : mx;
         result->reserved = carry_opens;  // number of opening brackets
     }
-    // apply_depth<true> appends the opening brackets it could not pair inside their block: one counter per list shard
+    // apply_depth / match_compact append the opening brackets they could not pair inside their block: one counter per list shard
     if (survivors && threadIdx.x < kSurvivorShards) survivors[threadIdx.x * kSurvivorStride] = 0u;
     if (resid && threadIdx.x < 4) resid[threadIdx.x] = 0u;  // the counts of this call's residual brackets (match_brackets, collect_closers)
 }
@@ -680,12 +680,12 @@ __global__ __launch_bounds__(kThreads) void apply_depth(const uint8_t *__restric
 // all 32 loads of a wave go out at once and their latency is paid once per 2 048 tokens.  (With a block per WORKGROUP,
 // 512 tokens a wave, the kernel was bound by the workgroup's lifetime -- load latency, barrier, ~1 us of arithmetic, the
 // list's round, barrier: 5 us per block at the 8 workgroups a CU holds, every dependent step added paid in full -- 267
-// us for the pairs form against 175 for the depths; apply_depth<3>, a per-thread loop over the set bits of eight tokens'
+// us for the pairs form against 175 for the depths; the per-thread form of apply_depth, a loop over the set bits of eight tokens'
 // bracket masks, was bound by instruction issue: 356 vector instructions per wave of 512 tokens.)
 // The compact list (kCompact): {token | closing << 31, depth} per bracket in token order, which match_compact pairs.
 // A bracket's slot needs no scan of its own: in front of any token, opening + closing brackets = its slot and opening -
 // closing = the running depth, so the brackets in front of a block = 2 x the opening ones - the depth they leave behind.
-// profiles/r05/depth_rows_*.txt.
+// profiles/r05/depth_pass_forms.txt.
 __device__ __forceinline__ uint32_t bits_below(uint64_t m, uint32_t init) {  // init + bits of m below this lane
     return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, init));
 }
@@ -1132,7 +1132,7 @@ __global__ __launch_bounds__(256) void stitch_partners(const msj_stitch_args a, 
 
 // ---- the pairs form (round 5): bracket partners on the COMPACT list depth_rows<true> leaves -- brk_tok[j] = token |
 // closing << 31, brk_depth[j] = the bracket's depth, j in token order.  A workgroup takes 2 048 brackets (the containers of
-// ~25 000 tokens of the minified workload): the same level bitmaps as apply_depth<1> -- the partner of a closing bracket
+// ~25 000 tokens of the minified workload): the same level bitmaps as apply_depth -- the partner of a closing bracket
 // at depth d is the most recent opening one at depth d in front of it -- but every lane's every slot is a bracket, the
 // depths are given (no scan), and far fewer containers span a border.  A container's record goes to the place of its
 // opening bracket among the call's opening ones: (slot + depth in front) / 2.  Opening brackets nobody claimed go on the
@@ -1249,7 +1249,7 @@ __global__ __launch_bounds__(256) void match_compact(const uint32_t *__restrict_
                     if ((surv >> k) & 1u) list[slot++] = base + p0 + (uint32_t)k;
             }
         }
-        // (e) the three lowest levels of the 8-ary min tree over brk_depth[] (as apply_depth<1> over depth[])
+        // (e) the three lowest levels of the 8-ary min tree over brk_depth[] (as apply_depth over depth[])
         {
             int m = kNone;
 #pragma unroll
@@ -1448,7 +1448,7 @@ static int launch_depth_passes(const uint32_t *d_idx, uint64_t n, uint8_t *d_typ
             u.nlev = t.nlev;
             hipLaunchKernelGGL(build_upper_levels, dim3(1), dim3(1024), 0, s, u);
         }
-        // match[] is complete for every container that closes inside a block (apply_depth<true> wrote the whole array);
+        // match[] is complete for every container that closes inside a block (apply_depth wrote the whole array);
         // what is left -- a container that spans a block border, or lies outside the levels a block keeps -- walks the tree
         // (the lane groups of 32 workgroups stride over each of the lists)
         // (block b appends to list b mod kSurvivorShards: a short call uses the first nb lists only, and a list then holds

@@ -530,7 +530,7 @@ def test_stage2_prep_1gib_replicated(dev, workload, mode, reps, request):
         assert torch.equal(ev[k].to(torch.int64) & 0xFFFFFFFF, want_e), k
 
 
-# ---- round 4: bracket partners inside a block (apply_depth<true>), the depth carried from call to call, segments ----
+# ---- round 4: bracket partners inside a block (apply_depth), the depth carried from call to call, segments ----
 @pytest.mark.gpu
 def test_bracket_partners_around_the_block_levels(dev, span_mode):
     """The partner of a bracket is settled inside its block of 2 048 tokens where its container closes there and lies
