@@ -32,6 +32,27 @@ def test_header_symbols_exported():
     assert b"gfx950" in lib.msj_version()
 
 
+def test_token_workspace_sizes():
+    """The token calls' workspace (host arithmetic, no GPU): grows with the token count, the match[] form adds the min
+    tree and the lists of brackets left to it, the pairs form the compact bracket list on top (a token and a depth word
+    per token of capacity, csrc/tokens_kernel.hip)."""
+    from mojo_simdjson_amd import _lib
+
+    lib = _lib.load()
+    f = lib.msj_stage2_prep_workspace_bytes
+    f.restype = ctypes.c_uint64
+    f.argtypes = [ctypes.c_uint64, ctypes.c_uint64, ctypes.c_int]
+    prev = (0, 0, 0)
+    for n in (0, 1, 7, 2047, 2048, 2049, 1 << 20, (1 << 27) + 5, (1 << 31) - 1):
+        plain, match, pairs = (f(n, 6 * n + 1, m) for m in (0, 1, 2))
+        assert 0 < plain <= match <= pairs and plain % 4 == 0 and match % 4 == 0 and pairs % 4 == 0
+        assert pairs - match >= 8 * n  # the compact list
+        assert match - plain >= 4 * n  # lists of one word per bracket a block may leave over
+        assert (plain, match, pairs) >= prev
+        prev = (plain, match, pairs)
+    assert f((1 << 31) - 1, (1 << 32) - 1, 2) < 40 * (1 << 31)  # (a bound a caller can budget with: < 40 bytes per token)
+
+
 def test_struct_layouts():
     from mojo_simdjson_amd import _lib
 
