@@ -33,6 +33,19 @@
 
 namespace msj_tokens {
 
+#ifdef MSJ_TILE_STAMPS
+// diagnostic build only (scripts/tile_stamps.py, scripts/compact_stamps.py): 100 MHz real-time stamps, eight per wave of
+// token_tiles / per wave and block of match_compact
+__device__ unsigned long long *g_tile_stamps = nullptr;
+#define MSJ_STAMP_AT(slot, k)                                                                             \
+    do {                                                                                                  \
+        if ((threadIdx.x & 63u) == 0 && g_tile_stamps) g_tile_stamps[(uint64_t)(slot) * 8 + (k)] = __builtin_amdgcn_s_memrealtime(); \
+    } while (0)
+#else
+#define MSJ_STAMP_AT(slot, k) do {} while (0)
+#endif
+#define MSJ_TSTAMP(k) MSJ_STAMP_AT((uint64_t)blockIdx.x * kTgWaves + wave, k)
+
 constexpr int kThreads = 256;
 constexpr int kPer = 8;                        // structurals per thread
 constexpr uint32_t kBlock = kThreads * kPer;   // per workgroup
@@ -1161,6 +1174,8 @@ __global__ __launch_bounds__(256) void match_compact(const uint32_t *__restrict_
     const uint32_t p0 = 8u * threadIdx.x;  // this thread's first bracket inside the block
     for (uint32_t cb = blockIdx.x; cb < ncb; cb += gridDim.x) {  // uniform
         const uint32_t base = cb * kCompactBlock, nrem = min(nbrk - base, kCompactBlock);
+#define MSJ_CSTAMP(k) MSJ_STAMP_AT((uint64_t)cb * 4u + wave, k)
+        MSJ_CSTAMP(0);
         {
             uint32_t *z = &bm[0][0];
 #pragma unroll
@@ -1192,7 +1207,9 @@ __global__ __launch_bounds__(256) void match_compact(const uint32_t *__restrict_
         const uint32_t om = ~cm & vm;
         // the levels kept: from kMatchBelow below the running depth in front of the block's first bracket (uniform, scalar loads)
         const int level0 = brk_depth[base] + (int)(brk_tok[base] >> 31) - kMatchBelow;
+        MSJ_CSTAMP(1);
         __syncthreads();
+        MSJ_CSTAMP(2);
         // (a) the opening brackets' bits (a thread's eight brackets share a word)
         const uint32_t word = p0 >> 5, sh0 = p0 & 31u;
 #pragma unroll
@@ -1201,6 +1218,7 @@ __global__ __launch_bounds__(256) void match_compact(const uint32_t *__restrict_
             if (((om >> k) & 1u) && lv < (uint32_t)kMatchLevels) atomicOr(&bm[lv][word], 1u << (sh0 + k));
         }
         __syncthreads();
+        MSJ_CSTAMP(3);
         // (b) the level's words that hold one (every lane here holds brackets: 64 lanes OR-ing one summary word would
         // serialise; a wave takes four levels, the compare of a level's 64 words IS the ballot)
 #pragma unroll
@@ -1210,6 +1228,7 @@ __global__ __launch_bounds__(256) void match_compact(const uint32_t *__restrict_
             if (lane == 0u) bm_words[lv] = nz;
         }
         __syncthreads();
+        MSJ_CSTAMP(4);
         // (c) every closing bracket looks for the most recent opening one of its level
 #pragma unroll
         for (int k = 0; k < 8; k++) {
@@ -1233,6 +1252,7 @@ __global__ __launch_bounds__(256) void match_compact(const uint32_t *__restrict_
             }
         }
         __syncthreads();
+        MSJ_CSTAMP(5);
         // (d) the opening brackets nobody claimed: to the lists match_brackets<true> works through (any order)
         {
             const uint32_t surv = om & ~(s_paired[word] >> sh0);
@@ -1249,6 +1269,7 @@ __global__ __launch_bounds__(256) void match_compact(const uint32_t *__restrict_
                     if ((surv >> k) & 1u) list[slot++] = base + p0 + (uint32_t)k;
             }
         }
+        MSJ_CSTAMP(6);
         // (e) the three lowest levels of the 8-ary min tree over brk_depth[] (as apply_depth over depth[])
         {
             int m = kNone;
@@ -1276,6 +1297,8 @@ __global__ __launch_bounds__(256) void match_compact(const uint32_t *__restrict_
             if (lane == 63u && wave * 512u < nrem) min512[(base >> 9) + wave] = m;
         }
         __syncthreads();  // (the next round zeroes what (d) read)
+        MSJ_CSTAMP(7);
+#undef MSJ_CSTAMP
     }
 }
 
@@ -2300,16 +2323,6 @@ __device__ __forceinline__ uint64_t lane_carries(uint64_t gen, uint64_t prop, ui
     return s ^ a ^ b;
 }
 
-#ifdef MSJ_TILE_STAMPS
-// diagnostic build only (scripts/tile_stamps.py): six 100 MHz real-time stamps per wave of token_tiles
-__device__ unsigned long long *g_tile_stamps = nullptr;
-#define MSJ_TSTAMP(k)                                                                                              \
-    do {                                                                                                           \
-        if (lane == 0 && g_tile_stamps) g_tile_stamps[((uint64_t)blockIdx.x * kTgWaves + wave) * 8 + (k)] = __builtin_amdgcn_s_memrealtime(); \
-    } while (0)
-#else
-#define MSJ_TSTAMP(k) do {} while (0)
-#endif
 
 template <bool kFused, bool kSpans>
 __global__ __launch_bounds__(kTgThreads) void token_tiles(const uint8_t *__restrict__ buf, uint64_t len, const uint32_t *__restrict__ idx,
