@@ -476,7 +476,7 @@ int32_t msj_token_spans_device(msj_ctx *ctx, const uint8_t *d_buf, uint64_t len,
  * Bracket partners as a COMPACT LIST (round 5): d_pairs[k] = {token index of the k-th opening bracket of the call, token
  * index of the bracket that closes its container, 0xFFFFFFFF if it is never closed inside the call}, k in the order of
  * the opening brackets; d_result->reserved is their number, the array needs room for as many (n at most).  Eight bytes per
- * CONTAINER instead of the four bytes per TOKEN of d_match -- brackets are 8 % of the minified workload's tokens -- for
+ * CONTAINER instead of the four bytes per TOKEN of d_match -- brackets are 12 % of the minified workload's tokens -- for
  * the consumer that walks the tokens in order and takes one record at every opening bracket, the way the reference's
  * stage 2 pushes in start_container and pops in end_container (generic/stage2/tape_builder.mojo:235-272).  Same arguments
  * and results otherwise as msj_tokens_chain_device / msj_stage2_prep_chain_device without d_match; d_pairs 8-byte aligned.

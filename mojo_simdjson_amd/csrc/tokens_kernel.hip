@@ -410,7 +410,7 @@ __device__ __forceinline__ void apply_depth_block(DepthShared &sh, const uint8_t
     if (kMatch) {
         const int level0 = block_depth0 - kMatchBelow;
         // (a) the opening brackets' bits (the zeroing above is behind the barrier that published wave_sum).  Brackets are
-        // few (4 % of the tokens of the minified workload are opening ones): a thread walks the SET BITS of its eight
+        // few (6 % of the tokens of the minified workload are opening ones): a thread walks the SET BITS of its eight
         // tokens' bracket masks, so a wave runs max-over-lanes(brackets per thread) rounds, not eight; the depth of
         // token k follows from the masks (depth in front of the thread + opening - closing brackets below k).
         uint32_t om = 0, cm = 0;
@@ -421,8 +421,8 @@ __device__ __forceinline__ void apply_depth_block(DepthShared &sh, const uint8_t
         }
         if (!kFull) om &= vm, cm &= vm;  // (a blank stands in for a token that does not exist: no bracket anyway)
         const int before0 = out[0] + (d[0] < 0 ? 1 : 0);  // the running depth in front of this thread's first token
-        // Round 5: the wave's brackets are COMPACTED first.  A thread holds 0 .. 8 of them (4 % of the minified workload's
-        // tokens open a container, 4 % close one: ~40 per wave of 512 tokens), and a loop in which every thread walks its
+        // Round 5: the wave's brackets are COMPACTED first.  A thread holds 0 .. 8 of them (6 % of the minified workload's
+        // tokens open a container, 6 % close one: ~60 per wave of 512 tokens), and a loop in which every thread walks its
         // own runs max-over-lanes rounds of the whole body -- 2 to 3 of the 22-instruction insertion and of the
         // 45-instruction look-up -- with a third of the lanes busy.  So a thread only works out WHERE its brackets are and at
         // which level (one short round per bracket), writes a 16-bit entry per bracket -- token inside the wave | level + 1
@@ -1145,7 +1145,7 @@ __global__ __launch_bounds__(256) void stitch_partners(const msj_stitch_args a, 
 
 // ---- the pairs form (round 5): bracket partners on the COMPACT list depth_rows<true> leaves -- brk_tok[j] = token |
 // closing << 31, brk_depth[j] = the bracket's depth, j in token order.  A workgroup takes 2 048 brackets (the containers of
-// ~25 000 tokens of the minified workload): the same level bitmaps as apply_depth -- the partner of a closing bracket
+// ~17 000 tokens of the minified workload): the same level bitmaps as apply_depth -- the partner of a closing bracket
 // at depth d is the most recent opening one at depth d in front of it -- but every lane's every slot is a bracket, the
 // depths are given (no scan), and far fewer containers span a border.  A container's record goes to the place of its
 // opening bracket among the call's opening ones: (slot + depth in front) / 2.  Opening brackets nobody claimed go on the
