@@ -861,9 +861,13 @@ def test_bracket_pairs_compact_list(dev, span_mode, spans):
         _check_pairs(dev, synth.workload(name, 8 << 20).tobytes(), name, spans)
     rng = np.random.default_rng(23)
     alphabet = np.frombuffer(b'{}[]{}[],: "a1', dtype=np.uint8)
-    for n in (1, 2, 7, 8, 9, 2047, 2048, 2049, 4096 * 3 + 5, 100000, 1 << 20):
+    # (2 048 tokens = a block of the depth pass = a wave; four blocks a workgroup; 2 048 brackets a block of the pairing)
+    for n in (1, 2, 7, 8, 9, 63, 64, 65, 511, 512, 513, 2047, 2048, 2049, 8191, 8192, 8193, 4096 * 3 + 5, 24577, 100000, 1 << 20):
         soup = alphabet[rng.integers(0, len(alphabet), n)].tobytes().replace(b'"', b"x")
         _check_pairs(dev, soup, f"bracket soup {n}", spans)
+    for n in (2048, 8192, 8193, 70000):  # every token a bracket: the compact list as long as the token stream
+        only = np.frombuffer(b"[]{}[[]]", dtype=np.uint8)[rng.integers(0, 8, n)].tobytes()
+        _check_pairs(dev, only, f"brackets only {n}", spans)
     _check_pairs(dev, b"[" * 300000 + b"]" * 299999, "deep", spans)
     _check_pairs(dev, b"]" * 5000 + b"[" * 7, "underflow", spans)
     _check_pairs(dev, b"[" + b"[1]," * 3000 + b"[" * 20 + b"1" + b"]" * 20 + b",[[2]]" * 3000 + b"]", "mixed nests over many blocks", spans)
