@@ -133,6 +133,21 @@ def load():
     lib.msj_tokens_chain_device.argtypes = lib.msj_tokens_device.argtypes[:-1] + [ctypes.c_void_p, ctypes.c_void_p]
     lib.msj_stage2_prep_chain_device.restype = ctypes.c_int32
     lib.msj_stage2_prep_chain_device.argtypes = lib.msj_stage2_prep_device.argtypes[:-1] + [ctypes.c_void_p, ctypes.c_void_p]
+    # (round 5) the pairs form, the types prototype, the placement report: every 64-bit argument declared -- an undeclared
+    # Python int goes over as a C int, and a buffer length over 2 GiB arrived truncated (found by the 3.94 GiB pairs test)
+    lib.msj_stage2_prep_pairs_device.restype = ctypes.c_int32
+    lib.msj_stage2_prep_pairs_device.argtypes = [ctypes.c_void_p, u8p, ctypes.c_uint64, u32p, ctypes.c_uint64] + [ctypes.c_void_p] * 8
+    lib.msj_tokens_pairs_device.restype = ctypes.c_int32
+    lib.msj_tokens_pairs_device.argtypes = [ctypes.c_void_p, u8p, ctypes.c_uint64, u32p, ctypes.c_uint64] + [ctypes.c_void_p] * 6
+    lib.msj_stage1_types_device.restype = ctypes.c_int32
+    lib.msj_stage1_types_device.argtypes = [ctypes.c_void_p, u8p, ctypes.c_uint64, u32p, ctypes.c_uint64, ctypes.c_void_p, ctypes.c_void_p,
+                                            ctypes.c_void_p, ctypes.c_uint32]
+    lib.msj_depth_from_types_device.restype = ctypes.c_int32
+    lib.msj_depth_from_types_device.argtypes = [ctypes.c_void_p, u8p, ctypes.c_uint64] + [ctypes.c_void_p] * 5
+    lib.msj_host_placement.restype = ctypes.c_int32
+    lib.msj_host_placement.argtypes = [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_uint64]
+    lib.msj_debug_numa_node_of.restype = ctypes.c_int32
+    lib.msj_debug_numa_node_of.argtypes = [ctypes.c_void_p]
     lib.msj_stage2_prep_segments.restype = ctypes.c_int32
     lib.msj_stage2_prep_segments.argtypes = [ctypes.c_void_p, u8p, ctypes.c_void_p, ctypes.c_uint32, u32p] + [ctypes.c_void_p] * 7 + \
         [ctypes.POINTER(ctypes.c_uint64), ctypes.c_void_p]

@@ -128,6 +128,10 @@ def lib():
         L.msj_exchange_release.argtypes = [ctypes.POINTER(MsjExchange)]
         L.msj_debug_set_segment_bytes.restype = i32
         L.msj_debug_set_segment_bytes.argtypes = [vp, u64]
+        L.msj_copy_to_host.restype = i32
+        L.msj_copy_to_host.argtypes = [vp, vp, vp, u64, vp]
+        L.msj_copy_to_device.restype = i32
+        L.msj_copy_to_device.argtypes = [vp, vp, ctypes.c_char_p, u64, vp]
         _bound = True
     return L
 
@@ -272,8 +276,6 @@ class ShardedStage1:
 
     def _create(self):
         L = lib()
-        L.msj_copy_to_host.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint64, ctypes.c_void_p]
-        L.msj_copy_to_device.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_char_p, ctypes.c_uint64, ctypes.c_void_p]
         x = MsjExchange()
         native = dist.get_backend(self.group) == "nccl" and self.exchange == "rccl"
         if native:

@@ -30,6 +30,17 @@ def test_header_symbols_exported():
         assert hasattr(lib, n), f"{n} declared in include/msj_stage1.h but not exported"
     assert lib.msj_tile_bytes() == 4096
     assert b"gfx950" in lib.msj_version()
+    # ... and the Python binding declares the arguments of every one of them: an undeclared Python int goes over as a
+    # 32-bit C int (a 3.94 GiB buffer length arrived truncated at the round-5 entry points until they were declared)
+    from mojo_simdjson_amd import sharded
+
+    sharded.lib()  # (the N-GPU entry points are declared there)
+    called = set()
+    for f in os.listdir(PKG):
+        if f.endswith(".py"):
+            called |= set(re.findall(r"\.(msj_[a-z0-9_]+)\(", open(os.path.join(PKG, f)).read()))
+    undeclared = sorted(n for n in called & set(names) if getattr(lib, n).argtypes is None)
+    assert not undeclared, f"the package calls these without declared argtypes: {undeclared}"
 
 
 def test_token_workspace_sizes():
