@@ -803,17 +803,19 @@ def test_types_from_stage1_prototype(dev):
     b = u.tobytes()
     idx_u = _stage1(oracle, b)
     wt, wd, _ = helpers.oracle_tokens(b, idx_u)
-    reps = 16
-    d_buf = torch.from_numpy(u).to(dev.device).repeat(reps)
     nu = len(idx_u)
-    d_idx = torch.empty(nu * reps + 16, dtype=torch.int32, device=dev.device)
-    d_types = torch.empty(nu * reps + 16, dtype=torch.uint8, device=dev.device)
-    d_res = dev.new_carry()
-    dev.index_types(d_buf, d_idx, d_types, d_res)
-    assert int(dev.fetch(d_res).count) == nu * reps
-    assert torch.equal(d_types[:nu * reps].view(reps, -1), torch.from_numpy(wt).to(dev.device).expand(reps, -1))
-    d_depth, _, _ = dev.depth_from_types(d_types, nu * reps)
-    assert torch.equal(d_depth[:nu * reps].view(reps, -1), torch.from_numpy(wd).to(dev.device).expand(reps, -1))
+    for reps in (16, 63):  # 1 GiB; 3.94 GiB = the top of what one uint32 segment holds
+        d_buf = torch.from_numpy(u).to(dev.device).repeat(reps)
+        d_idx = torch.empty(nu * reps + 16, dtype=torch.int32, device=dev.device)
+        d_types = torch.empty(nu * reps + 16, dtype=torch.uint8, device=dev.device)
+        d_res = dev.new_carry()
+        dev.index_types(d_buf, d_idx, d_types, d_res)
+        assert int(dev.fetch(d_res).count) == nu * reps
+        assert torch.equal(d_types[:nu * reps].view(reps, -1), torch.from_numpy(wt).to(dev.device).expand(reps, -1)), reps
+        d_depth, _, _ = dev.depth_from_types(d_types, nu * reps)
+        assert torch.equal(d_depth[:nu * reps].view(reps, -1), torch.from_numpy(wd).to(dev.device).expand(reps, -1)), reps
+        del d_buf, d_idx, d_types, d_depth
+        torch.cuda.empty_cache()
 
 
 def _check_pairs(dev, data, where, spans):
