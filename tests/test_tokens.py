@@ -874,6 +874,9 @@ def test_bracket_pairs_compact_list(dev, span_mode, spans):
     _check_pairs(dev, b"]" * 5000 + b"[" * 7, "underflow", spans)
     _check_pairs(dev, b"[" + b"[1]," * 3000 + b"[" * 20 + b"1" + b"]" * 20 + b",[[2]]" * 3000 + b"]", "mixed nests over many blocks", spans)
     _check_pairs(dev, b" ", "no structurals", spans)
+    _check_pairs(dev, b'"a" 1 true "b" 2.5 null ' * 700, "tokens but no bracket at all", spans)
+    _check_pairs(dev, b'[1,{"a":' * 3000, "opening brackets only", spans)
+    _check_pairs(dev, b'1],"a"},' * 3000, "closing brackets only", spans)
     # full size
     u = synth.workload("minified", 64 << 20)
     oracle = helpers.load_oracle()
