@@ -1155,7 +1155,7 @@ __global__ __launch_bounds__(256) void stitch_partners(const msj_stitch_args a, 
 // the next lower bit of the level's ballot, or the one carried from the rows before in lane `level` of a register; no LDS,
 // no barrier -- is bit-exact and costs a loop over the levels present in every row: ~8 000 instructions per block against
 // 2 400 here, 183 us per GiB minified against 81; a wave per 2 048 brackets WITH these bitmaps, kept per piece of 512 in the
-// wave's own LDS, the level's last opening bracket carried from piece to piece: 117 - 128 us -- 8 400 waves of ~60 us each
+// wave's own LDS, the level's last opening bracket carried from piece to piece: 117 - 128 us -- 12 200 waves of ~40 us each
 // do not fill the chip, and the wait for a piece's words is a wait for the stores of the piece in front.)
 constexpr uint32_t kCompactBlock = 2048;
 __global__ __launch_bounds__(256) void match_compact(const uint32_t *__restrict__ brk_tok, const int32_t *__restrict__ brk_depth,
