@@ -2103,11 +2103,20 @@ static uint32_t span_lds_limit(const msj_token_opts &o) { return o.lds_limit < k
 #define MSJ_TG_HALO_BLOCKS 32
 #endif
 constexpr uint32_t kTgTiles = MSJ_TG_TILES;
-constexpr uint32_t kTgWaves = kTgTiles + 1;            // one wave per tile + one for the halo
-constexpr uint32_t kTgThreads = 64 * kTgWaves;
-constexpr uint32_t kTgBytes = kTgTiles * 4096u;        // bytes of the buffer per workgroup
 constexpr uint32_t kTgHaloBlocks = MSJ_TG_HALO_BLOCKS;  // 2 KiB behind them (<= 64: one wave)
+#ifdef MSJ_TG_OVERLAP
+// EXPERIMENT (round 5, measured slower, profiles/r05/token_tiles_parts.txt): no wave of its own for the halo -- every wave
+// stages and classifies a full tile, the groups advance by the staged range less the halo, which the next group classifies
+// again as the start of its first tile (redundant work halo / advance instead of one wave in kTgTiles + 1)
+constexpr uint32_t kTgWaves = kTgTiles;
+constexpr uint32_t kTgBytes = kTgTiles * 4096u - kTgHaloBlocks * 64u;
+constexpr uint32_t kTgBlocks = kTgTiles * 64;
+#else
+constexpr uint32_t kTgWaves = kTgTiles + 1;            // one wave per tile + one for the halo
+constexpr uint32_t kTgBytes = kTgTiles * 4096u;        // bytes of the buffer per workgroup
 constexpr uint32_t kTgBlocks = kTgTiles * 64 + kTgHaloBlocks;
+#endif
+constexpr uint32_t kTgThreads = 64 * kTgWaves;
 constexpr uint32_t kTgStage = kTgBlocks * 64;          // bytes staged
 constexpr uint32_t kTgMapWords = kSpanMapFront + 2 * kTgBlocks + 4;
 constexpr uint32_t kChunk = 128;                       // tokens per wave iteration
